@@ -1,0 +1,171 @@
+"""CPU restatement of the photometric-reprojection + SSIM + smoothness loss path.
+
+Reference (all under /root/reference/DepthNetworks/monodepth2 unless prefixed):
+  disp_to_depth               layers.py:16-25
+  BackprojectDepth.forward    layers.py:139-168
+  Project3D.forward           layers.py:171-198
+  get_smooth_loss             layers.py:207-220
+  SSIM.forward                layers.py:223-253
+  generate_images_pred        trainer.py:472-523
+  compute_reprojection_loss   trainer.py:525-537
+  compute_losses              trainer.py:539-674
+  DepthHints compute_losses   ../depth-hints/trainer.py:557-741
+
+Plain differentiable PyTorch; works in fp32 and fp64.  Test infrastructure only
+(see oracle/__init__.py).  Pinned by tests/golden/loss_*.npz, which were produced by
+running the reference source itself (oracle/make_goldens.py).
+"""
+import torch
+import torch.nn.functional as F
+
+MIN_DEPTH = 0.1      # options.py:69-72
+MAX_DEPTH = 100.0    # options.py:73-76
+SMOOTH_WT = 1e-3     # options.py:61-64 (--disparity_smoothness)
+
+
+def disp_to_depth(disp, min_depth=MIN_DEPTH, max_depth=MAX_DEPTH):
+    """layers.py:16-25."""
+    min_disp = 1 / max_depth
+    max_disp = 1 / min_depth
+    scaled_disp = min_disp + (max_disp - min_disp) * disp
+    depth = 1 / scaled_disp
+    return scaled_disp, depth
+
+
+def backproject(depth, inv_K):
+    """layers.py:163-168 -- depth [B,1,H,W], inv_K [B,4,4] -> cam points [B,4,H*W]."""
+    B, _, H, W = depth.shape
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=depth.dtype), torch.arange(W, dtype=depth.dtype), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, dtype=depth.dtype)], 0)
+    pix = pix.unsqueeze(0).repeat(B, 1, 1)
+    cam = torch.matmul(inv_K[:, :3, :3], pix)
+    cam = depth.view(B, 1, -1) * cam
+    ones = torch.ones(B, 1, H * W, dtype=depth.dtype)
+    return torch.cat([cam, ones], 1)
+
+
+def project3d(points, K, T, H, W, eps=1e-7):
+    """layers.py:182-198 -- returns the normalised sampling grid [B,H,W,2]."""
+    B = points.shape[0]
+    P = torch.matmul(K, T)[:, :3, :]
+    cam = torch.matmul(P, points)
+    pix = cam[:, :2, :] / (cam[:, 2, :].unsqueeze(1) + eps)
+    pix = pix.view(B, 2, H, W).permute(0, 2, 3, 1)
+    x = pix[..., 0] / (W - 1)
+    y = pix[..., 1] / (H - 1)
+    pix = torch.stack([x, y], -1)
+    return (pix - 0.5) * 2
+
+
+def ssim(x, y):
+    """layers.py:239-253."""
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+    x = F.pad(x, [1, 1, 1, 1], mode="reflect")
+    y = F.pad(y, [1, 1, 1, 1], mode="reflect")
+    mu_x = F.avg_pool2d(x, 3, 1)
+    mu_y = F.avg_pool2d(y, 3, 1)
+    sigma_x = F.avg_pool2d(x ** 2, 3, 1) - mu_x ** 2
+    sigma_y = F.avg_pool2d(y ** 2, 3, 1) - mu_y ** 2
+    sigma_xy = F.avg_pool2d(x * y, 3, 1) - mu_x * mu_y
+    n = (2 * mu_x * mu_y + C1) * (2 * sigma_xy + C2)
+    d = (mu_x ** 2 + mu_y ** 2 + C1) * (sigma_x + sigma_y + C2)
+    return torch.clamp((1 - n / d) / 2, 0, 1)
+
+
+def get_smooth_loss(disp, img):
+    """layers.py:207-220."""
+    gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
+    gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
+    gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
+    giy = torch.mean(torch.abs(img[:, :, :-1, :] - img[:, :, 1:, :]), 1, keepdim=True)
+    gdx = gdx * torch.exp(-gix)
+    gdy = gdy * torch.exp(-giy)
+    return gdx.mean() + gdy.mean()
+
+
+def normalised_smooth_loss(disp, color):
+    """trainer.py:662-664."""
+    mean_disp = disp.mean(2, True).mean(3, True)
+    norm_disp = disp / (mean_disp + 1e-7)
+    return get_smooth_loss(norm_disp, color)
+
+
+def compute_reprojection_loss(pred, target, no_ssim=False):
+    """trainer.py:525-537."""
+    l1 = torch.abs(target - pred).mean(1, True)
+    if no_ssim:
+        return l1
+    return 0.85 * ssim(pred, target).mean(1, True) + 0.15 * l1
+
+
+def warp_view(disp, source, K, inv_K, T, H, W, min_depth=MIN_DEPTH, max_depth=MAX_DEPTH):
+    """One (scale, frame) body of generate_images_pred, trainer.py:481-519.
+    Returns (depth [B,1,H,W], sample grid [B,H,W,2], warped colour [B,3,H,W])."""
+    disp_up = F.interpolate(disp, [H, W], mode="bilinear", align_corners=False)
+    _, depth = disp_to_depth(disp_up, min_depth, max_depth)
+    cam = backproject(depth, inv_K)
+    grid = project3d(cam, K, T, H, W)
+    warped = F.grid_sample(source, grid, padding_mode="border", align_corners=True)
+    return depth, grid, warped
+
+
+def generate_images_pred(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), H=None, W=None):
+    """trainer.py:472-523 (non-v1_multiscale, automasking on, no posecnn)."""
+    if H is None:
+        H, W = inputs[("color", 0, 0)].shape[-2:]
+    for scale in scales:
+        for frame_id in frame_ids[1:]:
+            T = inputs["stereo_T"] if frame_id == "s" else outputs[("cam_T_cam", 0, frame_id)]
+            depth, grid, warped = warp_view(outputs[("disp", scale)], inputs[("color", frame_id, 0)],
+                                            inputs[("K", 0)], inputs[("inv_K", 0)], T, H, W)
+            outputs[("depth", 0, scale)] = depth
+            outputs[("sample", frame_id, scale)] = grid
+            outputs[("color", frame_id, scale)] = warped
+            outputs[("color_identity", frame_id, scale)] = inputs[("color", frame_id, 0)]
+
+
+def compute_losses(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), noise=None,
+                   smooth_wt=SMOOTH_WT, variant="md2"):
+    """trainer.py:588-674 (variant="md2") or depth-hints/trainer.py:638-741
+    (variant="dh", no depth hints), photometric + smoothness part only.
+
+    ``noise``: dict scale -> tensor shaped like the identity loss ([B,F,H,W] for md2,
+    [B,1,H,W] for dh), the already-scaled tie-break term (reference: randn*1e-5,
+    trainer.py:642-645); None -> zeros.
+    Returns (losses dict, per-scale dict of to_optimise maps)."""
+    losses, maps = {}, {}
+    total = 0
+    for scale in scales:
+        disp = outputs[("disp", scale)]
+        color = inputs[("color", 0, scale)]
+        target = inputs[("color", 0, 0)]
+        reproj = torch.cat([compute_reprojection_loss(outputs[("color", f, scale)], target)
+                            for f in frame_ids[1:]], 1)
+        ident = torch.cat([compute_reprojection_loss(inputs[("color", f, 0)], target)
+                           for f in frame_ids[1:]], 1)
+        if variant == "md2":
+            if noise is not None:
+                ident = ident + noise[scale]
+            combined = torch.cat((ident, reproj), dim=1)
+            to_opt, idxs = torch.min(combined, dim=1)
+            outputs["identity_selection/{}".format(scale)] = (idxs > ident.shape[1] - 1).float()
+            loss = to_opt.mean()
+            maps[scale] = to_opt
+        else:
+            ident, _ = torch.min(ident, dim=1, keepdim=True)
+            reproj, _ = torch.min(reproj, dim=1, keepdim=True)
+            if noise is not None:
+                ident = ident + noise[scale]
+            idxs = torch.argmin(torch.cat([reproj, ident], dim=1), dim=1, keepdim=True)
+            mask = (idxs != 1).float()
+            rl = (reproj * mask).sum() / (mask.sum() + 1e-7)
+            outputs["identity_selection/{}".format(scale)] = (1 - mask).float()
+            losses["reproj_loss/{}".format(scale)] = rl
+            loss = rl
+            maps[scale] = reproj * mask
+        smooth = normalised_smooth_loss(disp, color)
+        loss = loss + smooth_wt * smooth / (2 ** scale)
+        total = total + loss
+        losses["loss/{}".format(scale)] = loss
+    losses["loss"] = total / len(scales)
+    return losses, maps

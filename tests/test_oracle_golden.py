@@ -1,0 +1,153 @@
+"""Pin the CPU oracle against golden vectors produced by the reference source itself
+(oracle/make_goldens.py).  Same-library fp32 arithmetic -> tight tolerances."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import attack_ref, loss_ref
+from oracle.synth import TinyDepthNet, kitti_like, make_loss_case, make_object
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_layers_small(golden):
+    g = golden("layers_small")
+    x, y, disp = t(g["x"]), t(g["y"]), t(g["disp"])
+    K, inv_K, T = t(g["K"]), t(g["inv_K"]), t(g["T"])
+    torch.testing.assert_close(loss_ref.ssim(x, y), t(g["ssim"]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(loss_ref.get_smooth_loss(disp, x), t(g["smooth"]), rtol=1e-6, atol=0)
+    scaled, depth = loss_ref.disp_to_depth(disp)
+    torch.testing.assert_close(scaled, t(g["scaled_disp"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(depth, t(g["depth"]), rtol=1e-6, atol=0)
+    cam = loss_ref.backproject(depth, inv_K)
+    torch.testing.assert_close(cam, t(g["cam_points"]), rtol=1e-5, atol=1e-6)
+    grid = loss_ref.project3d(cam, K, T, 24, 80)
+    torch.testing.assert_close(grid, t(g["grid"]), rtol=1e-5, atol=1e-6)
+
+
+def _run_oracle_loss(case, noise, variant):
+    inputs, disps = case
+    outputs = {}
+    leaves = []
+    for s, d in enumerate(disps):
+        d = d.clone().requires_grad_(True)
+        leaves.append(d)
+        outputs[("disp", s)] = d
+    loss_ref.generate_images_pred(inputs, outputs)
+    losses, _ = loss_ref.compute_losses(inputs, outputs, noise=noise, variant=variant)
+    losses["loss"].backward()
+    return losses, outputs, leaves
+
+
+@pytest.mark.parametrize("variant", ["md2", "dh"])
+@pytest.mark.parametrize("name", ["small", "cfg1"])
+def test_loss_path(golden, variant, name):
+    g = golden("loss_%s_%s" % (variant, name))
+    B, H, W, seed = [int(v) for v in g["shape"]]
+    case = make_loss_case(B, H, W, seed)
+    gen = torch.Generator().manual_seed(seed + 100)
+    noise = {s: torch.randn(B, 1, H, W, generator=gen) * 0.00001 for s in range(4)}
+    for tag, nz in (("nonoise", None), ("noise", noise)):
+        losses, outputs, leaves = _run_oracle_loss(case, nz, variant)
+        torch.testing.assert_close(losses["loss"], t(g[tag + "_loss"]), rtol=2e-6, atol=0)
+        for s in range(4):
+            torch.testing.assert_close(losses["loss/%d" % s], t(g["%s_loss_%d" % (tag, s)]), rtol=2e-6, atol=0)
+            sel = np.unpackbits(g["%s_identity_selection_%d" % (tag, s)])[:B * H * W].reshape(B, H, W)
+            mine = outputs["identity_selection/%d" % s].reshape(B, H, W).numpy()
+            assert (mine != sel).mean() < 1e-5
+            key = "%s_grad_disp_%d" % (tag, s)
+            if key in g.files:
+                torch.testing.assert_close(leaves[s].grad, t(g[key]), rtol=1e-4, atol=1e-9)
+            else:
+                torch.testing.assert_close(leaves[s].grad[:, :, ::3, ::3], t(g[key + "_sub3"]), rtol=1e-4, atol=1e-9)
+                torch.testing.assert_close(leaves[s].grad.double().sum((1, 2, 3)), t(g[key + "_sum"]),
+                                           rtol=1e-5, atol=1e-9)
+            if variant == "dh":
+                torch.testing.assert_close(losses["reproj_loss/%d" % s], t(g["%s_reproj_loss_%d" % (tag, s)]),
+                                           rtol=2e-6, atol=0)
+        if tag == "nonoise" and name == "small":
+            for s in range(4):
+                torch.testing.assert_close(outputs[("color", "s", s)], t(g["nonoise_warped_%d" % s]),
+                                           rtol=1e-5, atol=1e-6)
+            torch.testing.assert_close(outputs[("depth", 0, 0)], t(g["nonoise_depth_0"]), rtol=1e-6, atol=0)
+            torch.testing.assert_close(outputs[("sample", "s", 0)], t(g["nonoise_sample_0"]), rtol=1e-5, atol=1e-6)
+
+
+def test_geometry_quads(golden):
+    g = golden("geometry")
+    obj, mask = make_object()
+    pt = attack_ref.PhysicalTransRef(obj, mask, dist_range=attack_ref.TRAIN_DIST_RANGE)
+    assert np.array_equal(np.array(pt.pos_obj_img_start, dtype=np.int32), g["start"])
+    adv_K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    adv_K[0, :] *= 1242
+    adv_K[1, :] *= 375
+    for i, z0 in enumerate(pt.dist_range):
+        for j, al in enumerate(pt.angle_range):
+            assert np.array_equal(pt.obj_pos_on_image(z0, al), g["quads"][i, j]), (z0, al)
+            assert np.array_equal(pt.obj_pos_on_image(z0, al, adv_K), g["quads_K"][i, j]), (z0, al)
+    o, m, _, _ = pt.project(batch_size=2, z0_sample=[5.0, 9.4], alpha_sample=[-30, 15])
+    torch.testing.assert_close(o[:, :, 150:260:11, 400:900:7], t(g["proj_img_rows"]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(m[:, :, 150:260:11, 400:900:7], t(g["proj_mask_rows"]), rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(o.double().sum((2, 3)), t(g["proj_img_sum"]), rtol=1e-9, atol=0)
+
+
+def _seed_all(seed):
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def test_phy_obj_atk_linf(golden):
+    g = golden("atk_linf")
+    Ba, steps, seed = [int(v) for v in g["shape"]]
+    obj, mask = make_object()
+    scenes = kitti_like(Ba, 3, 375, 1242, torch.Generator().manual_seed(31))
+    model = TinyDepthNet(seed=5)
+    model.train()
+    _seed_all(seed)
+    adv_s, ben_s, m_out, patch = attack_ref.phy_obj_atk(model, obj, mask, scenes, Ba, eps=0.1, alpha=0.02,
+                                                        steps=steps, dist_range=attack_ref.TRAIN_DIST_RANGE)
+    assert model.training
+    # sign() steps: a flipped sign on a ~0 gradient moves one texel by 2*alpha; none expected same-library
+    torch.testing.assert_close(patch[:, :, ::2, ::2], t(g["patch_sub"]), rtol=0, atol=1e-6)
+    torch.testing.assert_close(patch.double().sum(), t(g["patch_sum"]), rtol=1e-7, atol=0)
+    torch.testing.assert_close(adv_s[:, :, 120:300:9, 300:800:5], t(g["adv_rows"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ben_s[:, :, 120:300:9, 300:800:5], t(g["ben_rows"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m_out[:, :, 120:300:9, 300:800:5], t(g["mask_rows"]), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(m_out.double().sum((1, 2, 3)), t(g["mask_out_sum"]), rtol=1e-7, atol=0)
+    assert float((patch - obj).abs().max()) <= 0.1 + 1e-6
+
+
+def test_phy_obj_atk_l0(golden):
+    g = golden("atk_l0")
+    Ba, steps, seed = [int(v) for v in g["shape"]]
+    obj, mask = make_object()
+    scenes = kitti_like(Ba, 3, 375, 1242, torch.Generator().manual_seed(31))
+    model = TinyDepthNet(seed=5)
+    _seed_all(seed)
+    rec = []
+    adv_s, ben_s, m_out, patch = attack_ref.phy_obj_atk_l0(model, obj, mask, scenes, Ba, adam_lr=0.5, steps=steps,
+                                                           mask_wt=0.06, l0_thresh=0.1,
+                                                           dist_range=attack_ref.TRAIN_DIST_RANGE, record=rec)
+    torch.testing.assert_close(patch[:, :, ::2, ::2], t(g["patch_sub"]), rtol=0, atol=1e-5)
+    torch.testing.assert_close(patch.double().sum(), t(g["patch_sum"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(adv_s.double().sum((2, 3)), t(g["adv_sum"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(ben_s.double().sum((2, 3)), t(g["ben_sum"]), rtol=1e-6, atol=0)
+    assert len(rec) >= steps
+
+
+@pytest.mark.parametrize("targeted", [True, False])
+def test_pgd_depth(golden, targeted):
+    g = golden("atk_pgd_%s" % ("targeted" if targeted else "untargeted"))
+    B, steps, seed = [int(v) for v in g["shape"]]
+    imgs = kitti_like(B, 3, 320, 1024, torch.Generator().manual_seed(33))
+    model = TinyDepthNet(seed=5)
+    _seed_all(seed)
+    adv, clean = attack_ref.pgd_depth(model, imgs, eps=0.03, alpha=2 / 255, steps=steps, targeted=targeted)
+    torch.testing.assert_close(adv[:, :, ::16, ::8], t(g["adv_rows"]), rtol=0, atol=1e-6)
+    torch.testing.assert_close(adv.double().sum((2, 3)), t(g["adv_sum"]), rtol=1e-7, atol=0)
+    assert abs(float((adv - clean).abs().max()) - float(g["delta_absmax"])) < 1e-7
