@@ -1,0 +1,69 @@
+"""Build libdmh_hip.so (the C-ABI HIP library) in-tree for gfx950.
+
+    python -m depthmodelhardening_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the tree.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(REPO, "include")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libdmh_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
+
+SOURCES = ["runtime.hip", "photo_loss.hip", "smooth_loss.hip", "eot_paste.hip", "attack_ops.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + INCLUDE]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "dmh_hip.h")]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        if force or _stale(o, [s] + headers):
+            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + r.stdout)
+        return r.stdout
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        for out in ex.map(run, jobs):
+            if verbose and out.strip():
+                print(out)
+    objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
+    if force or jobs or _stale(LIB_PATH, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

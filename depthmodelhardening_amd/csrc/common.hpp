@@ -1,0 +1,95 @@
+// Shared host/device helpers for libdmh_hip.so (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "dmh_hip.h"
+
+namespace dmh {
+
+constexpr int WAVE = 64;
+
+// ---- host-side error reporting ---------------------------------------------------------
+extern thread_local char g_err[512];
+
+inline int fail(int code, const char* fmt, const char* a = "", long long b = 0, long long c = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+    return code;
+}
+
+#define DMH_REQUIRE(cond, msg)                                                     \
+    do {                                                                            \
+        if (!(cond)) return dmh::fail(DMH_EINVAL, "%s: requirement failed: " msg, __func__); \
+    } while (0)
+
+inline int check_launch(const char* fn) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(g_err, sizeof(g_err), "%s: launch failed: %s", fn, hipGetErrorString(e));
+        return DMH_ELAUNCH;
+    }
+    return DMH_OK;
+}
+
+// ---- device helpers ----------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) v += __shfl_down(v, o, WAVE);
+    return v;
+}
+
+// Sum over a block of NT threads (NT multiple of 64, <= 1024); result valid in thread 0.
+// `red` is LDS scratch of at least NT/64 floats.  Fixed order -> bitwise reproducible.
+template <int NT>
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & (WAVE - 1), w = threadIdx.x / WAVE;
+    __syncthreads();
+    if (lane == 0) red[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < NT / WAVE; ++i) t += red[i];
+    }
+    return t;
+}
+
+__device__ __forceinline__ int reflect_idx(int p, int n) {
+    // ReflectionPad2d(1) index map, then clamped so that far-out-of-range halo slots stay in bounds
+    p = p < 0 ? -p : p;
+    p = p >= n ? 2 * (n - 1) - p : p;
+    return min(max(p, 0), n - 1);
+}
+
+// Philox4x32-10 counter-based generator (Salmon et al., SC'11).
+struct Philox {
+    uint32_t k0, k1;
+    __device__ __forceinline__ Philox(uint64_t seed) : k0((uint32_t)seed), k1((uint32_t)(seed >> 32)) {}
+    __device__ __forceinline__ uint4 operator()(uint64_t ctr_lo, uint64_t ctr_hi) const {
+        uint32_t c0 = (uint32_t)ctr_lo, c1 = (uint32_t)(ctr_lo >> 32), c2 = (uint32_t)ctr_hi,
+                 c3 = (uint32_t)(ctr_hi >> 32);
+        uint32_t a = k0, b = k1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            const uint32_t n0 = hi1 ^ c1 ^ a, n1 = lo1, n2 = hi0 ^ c3 ^ b, n3 = lo0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            a += 0x9E3779B9u;
+            b += 0xBB67AE85u;
+        }
+        return make_uint4(c0, c1, c2, c3);
+    }
+};
+
+// two uniform 32-bit words -> one N(0,1) sample (Box-Muller)
+__device__ __forceinline__ float normal_from_bits(uint32_t u0, uint32_t u1) {
+    const float a = ((float)u0 + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
+    const float b = (float)u1 * 2.3283064365386963e-10f;           // [0,1)
+    return sqrtf(-2.0f * __logf(a)) * __cosf(6.283185307179586f * b);
+}
+
+}  // namespace dmh

@@ -1,0 +1,381 @@
+"""Autograd-aware Python faces of the HIP kernels in libdmh_hip.so.
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd graph; every op
+below is one or a few launches of hand-written gfx950 kernels through the C ABI
+(include/dmh_hip.h).  There is no eager/CPU fallback: CPU tensors raise RuntimeError.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import torch
+
+from . import _native as N
+
+LossOut = namedtuple("LossOut", ["fin", "sel", "to_opt"])
+
+_philox_state = {"seed": None, "offset": 0}
+
+
+def _philox(device, count):
+    """(seed, offset) for the in-kernel tie-break noise; follows torch.manual_seed."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    seed = torch.cuda.default_generators[idx].initial_seed()
+    if _philox_state["seed"] != seed:
+        _philox_state["seed"], _philox_state["offset"] = seed, 0
+    off = _philox_state["offset"]
+    _philox_state["offset"] = off + count
+    return seed & 0xFFFFFFFFFFFFFFFF, off
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _photo_args(cfg, target, sources, Ts, K, inv_K, disps, noises):
+    a = N.PhotoArgs()
+    B, _, H, W = target.shape
+    a.target = N.ptr(target)
+    for f, (s_, t_) in enumerate(zip(sources, Ts)):
+        if tuple(s_.shape) != (B, 3, H, W) or tuple(t_.shape) != (B, 4, 4):
+            raise RuntimeError("photometric loss: source/T shape mismatch %s %s" % (tuple(s_.shape), tuple(t_.shape)))
+        a.source[f] = N.ptr(s_)
+        a.T[f] = N.ptr(t_)
+    if tuple(K.shape) != (B, 4, 4) or tuple(inv_K.shape) != (B, 4, 4):
+        raise RuntimeError("photometric loss: K / inv_K must be [B,4,4]")
+    a.K, a.inv_K = N.ptr(K), N.ptr(inv_K)
+    for s, d in enumerate(disps):
+        if d.dim() != 4 or d.shape[0] != B or d.shape[1] != 1:
+            raise RuntimeError("photometric loss: disp[%d] must be [B,1,Hs,Ws]" % s)
+        a.disp[s] = N.ptr(d)
+        a.Hs[s], a.Ws[s] = d.shape[2], d.shape[3]
+    a.B, a.H, a.W = B, H, W
+    a.num_frames, a.num_scales = len(sources), len(disps)
+    a.min_depth, a.max_depth = cfg["min_depth"], cfg["max_depth"]
+    a.variant = N.VARIANT_MD2 if cfg["variant"] == "md2" else N.VARIANT_DH
+    a.automask, a.no_ssim = int(cfg["automask"]), int(cfg["no_ssim"])
+    a.noise_mode = cfg["noise_mode"]
+    if cfg["noise_mode"] == N.NOISE_TENSOR:
+        nf = len(sources) if cfg["variant"] == "md2" else 1
+        for s, z in enumerate(noises):
+            if tuple(z.shape) != (B, nf, H, W):
+                raise RuntimeError("photometric loss: noise[%d] must be [B,%d,H,W]" % (s, nf))
+            a.noise[s] = N.ptr(z)
+    a.seed, a.offset = cfg.get("seed", 0), cfg.get("offset", 0)
+    return a
+
+
+def _smooth_args(disps, colors):
+    a = N.SmoothArgs()
+    B = disps[0].shape[0]
+    for s, (d, c) in enumerate(zip(disps, colors)):
+        if tuple(c.shape) != (B, 3, d.shape[2], d.shape[3]):
+            raise RuntimeError("smoothness: color[%d] %s does not match disp %s" % (s, tuple(c.shape), tuple(d.shape)))
+        a.disp[s], a.color[s] = N.ptr(d), N.ptr(c)
+        a.Hs[s], a.Ws[s] = d.shape[2], d.shape[3]
+    a.B, a.num_scales = B, len(disps)
+    return a
+
+
+class _PhotoSmoothLoss(torch.autograd.Function):
+    """K1 + K2 + finalise.  Tensor args: target, K, inv_K, then F sources, F Ts, NS colors,
+    (NS noises), NS disps."""
+
+    @staticmethod
+    def forward(ctx, cfg, target, K, inv_K, *rest):
+        F, NS = cfg["F"], cfg["NS"]
+        sources, Ts = rest[:F], rest[F:2 * F]
+        colors = rest[2 * F:2 * F + NS]
+        pos = 2 * F + NS
+        noises = ()
+        if cfg["noise_mode"] == N.NOISE_TENSOR:
+            noises = rest[pos:pos + NS]
+            pos += NS
+        disps = rest[pos:pos + NS]
+        if any(t.requires_grad for t in Ts):
+            raise NotImplementedError("gradient w.r.t. camera poses (cam_T_cam) is not implemented in the fused "
+                                      "photometric kernel yet; stereo training (frame_ids [0,'s']) does not need it")
+        lib = N.lib()
+        B, _, H, W = target.shape
+        dev = target.device
+        a = _photo_args(cfg, target, sources, Ts, K, inv_K, disps, noises)
+        sm = _smooth_args(disps, colors)
+        sel = [torch.empty((B, H, W), device=dev, dtype=torch.float32) for _ in range(NS)]
+        to_opt = [torch.empty((B, H, W), device=dev, dtype=torch.float32) if cfg["want_to_opt"] else None
+                  for _ in range(NS)]
+        pp = torch.empty(lib.dmh_photo_partials_size(B, H, W, NS), device=dev, dtype=torch.float32)
+        sp = torch.empty(lib.dmh_smooth_partials_size(C.byref(sm)), device=dev, dtype=torch.float32)
+        fin = torch.empty(N.FIN_SIZE, device=dev, dtype=torch.float32)
+        sstats = torch.empty((NS, B, 2), device=dev, dtype=torch.float32)
+        st = N.stream()
+        N.check(lib.dmh_photo_loss_fwd(C.byref(a), N.ptr_array(sel), N.ptr_array(to_opt), N.ptr(pp), st))
+        N.check(lib.dmh_smooth_loss_fwd(C.byref(sm), N.ptr(sp), st))
+        N.check(lib.dmh_loss_finalize(N.ptr(pp), N.ptr(sp), B, H, W, C.byref(sm), a.variant, cfg["smooth_wt"],
+                                      N.ptr(fin), N.ptr(sstats), st))
+        ctx.cfg = cfg
+        ctx.save_for_backward(target, K, inv_K, fin, sstats, *sources, *Ts, *colors, *disps, *sel)
+        outs = [fin] + sel + [t for t in to_opt if t is not None]
+        ctx.mark_non_differentiable(*outs[1:])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_fin, *unused):
+        cfg = ctx.cfg
+        F, NS = cfg["F"], cfg["NS"]
+        sv = ctx.saved_tensors
+        target, K, inv_K, fin, sstats = sv[:5]
+        sources, Ts = sv[5:5 + F], sv[5 + F:5 + 2 * F]
+        colors = sv[5 + 2 * F:5 + 2 * F + NS]
+        disps = sv[5 + 2 * F + NS:5 + 2 * F + 2 * NS]
+        sel = sv[5 + 2 * F + 2 * NS:5 + 2 * F + 3 * NS]
+        lib = N.lib()
+        B, _, H, W = target.shape
+        dev = target.device
+        gvec = _c(g_fin.to(torch.float32))
+        cfg_b = dict(cfg, noise_mode=N.NOISE_NONE)
+        a = _photo_args(cfg_b, target, sources, Ts, K, inv_K, disps, ())
+        sm = _smooth_args(disps, colors)
+        st = N.stream()
+        g_up = [torch.empty((B, H, W), device=dev, dtype=torch.float32) for _ in range(NS)]
+        N.check(lib.dmh_photo_loss_bwd(C.byref(a), N.ptr_array(sel), N.ptr(gvec), N.ptr(fin), N.ptr_array(g_up), st))
+        g_disp = []
+        for s, d in enumerate(disps):
+            Hs, Ws = d.shape[2], d.shape[3]
+            if (Hs, Ws) == (H, W):
+                g_disp.append(g_up[s].view(B, 1, H, W))
+            else:
+                g = torch.empty_like(d)
+                N.check(lib.dmh_upsample_bilinear_adjoint(N.ptr(g_up[s]), N.ptr(g), B, H, W, Hs, Ws, 0, st))
+                g_disp.append(g)
+        N.check(lib.dmh_smooth_loss_bwd(C.byref(sm), N.ptr(gvec), N.ptr(sstats), cfg["smooth_wt"],
+                                        N.ptr_array(g_disp), 1, st))
+        n_mid = 2 * F + NS + (NS if cfg["noise_mode"] == N.NOISE_TENSOR else 0)
+        return (None, None, None, None) + (None,) * n_mid + tuple(g_disp)
+
+
+def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_depth=0.1, max_depth=100.0,
+                            variant="md2", automask=True, no_ssim=False, smooth_wt=1e-3, noise="philox",
+                            want_to_opt=False):
+    """Fused photometric-reprojection + SSIM + auto-mask + smoothness loss over all scales.
+
+    target [B,3,H,W]; sources / Ts: one per non-target frame; disps[s] [B,1,H/2^s,W/2^s];
+    colors[s] = inputs[("color",0,s)].  ``noise``: "philox" (in-kernel randn*1e-5, the reference's
+    tie-break of MD2/trainer.py:642-645), None, or a list of NS already-scaled tensors.
+    Returns LossOut(fin, sel, to_opt): fin[FIN_*] is differentiable w.r.t. the disparities.
+    """
+    F, NS = len(sources), len(disps)
+    if not (1 <= F <= N.MAX_FRAMES and 1 <= NS <= N.MAX_SCALES):
+        raise RuntimeError("photometric loss supports 1..4 source frames and 1..4 scales")
+    if variant not in ("md2", "dh"):
+        raise RuntimeError("variant must be 'md2' or 'dh'")
+    B, _, H, W = target.shape
+    cfg = dict(F=F, NS=NS, min_depth=float(min_depth), max_depth=float(max_depth), variant=variant,
+               automask=bool(automask), no_ssim=bool(no_ssim), smooth_wt=float(smooth_wt), want_to_opt=want_to_opt)
+    noises = ()
+    if noise is None or not automask:
+        cfg["noise_mode"] = N.NOISE_NONE
+    elif isinstance(noise, str):
+        cfg["noise_mode"] = N.NOISE_PHILOX
+        cfg["seed"], cfg["offset"] = _philox(target.device, NS * B * F * H * W)
+    else:
+        cfg["noise_mode"] = N.NOISE_TENSOR
+        noises = tuple(_c(z) for z in noise)
+    args = (_c(target), _c(K), _c(inv_K)) + tuple(_c(s) for s in sources) + tuple(_c(t) for t in Ts) + \
+        tuple(_c(c) for c in colors) + noises + tuple(_c(d) for d in disps)
+    outs = _PhotoSmoothLoss.apply(cfg, *args)
+    fin, sel = outs[0], list(outs[1:1 + NS])
+    to_opt = list(outs[1 + NS:]) if want_to_opt else [None] * NS
+    return LossOut(fin, sel, to_opt)
+
+
+class _WarpView(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, source, disp, K, inv_K, T, H, W, min_depth, max_depth):
+        lib = N.lib()
+        B = source.shape[0]
+        Hs, Ws = disp.shape[2], disp.shape[3]
+        dev = source.device
+        depth = torch.empty((B, 1, H, W), device=dev, dtype=torch.float32)
+        sample = torch.empty((B, H, W, 2), device=dev, dtype=torch.float32)
+        color = torch.empty((B, 3, H, W), device=dev, dtype=torch.float32)
+        N.check(lib.dmh_warp_view_fwd(N.ptr(source), N.ptr(disp), N.ptr(K), N.ptr(inv_K), N.ptr(T), B, H, W, Hs, Ws,
+                                      min_depth, max_depth, N.ptr(depth), N.ptr(sample), N.ptr(color), N.stream()))
+        ctx.save_for_backward(source, disp, K, inv_K, T)
+        ctx.geo = (H, W, min_depth, max_depth)
+        ctx.mark_non_differentiable(sample)
+        return depth, sample, color
+
+    @staticmethod
+    def backward(ctx, g_depth, g_sample, g_color):
+        source, disp, K, inv_K, T = ctx.saved_tensors
+        H, W, min_depth, max_depth = ctx.geo
+        lib = N.lib()
+        B = source.shape[0]
+        Hs, Ws = disp.shape[2], disp.shape[3]
+        g_up = torch.empty((B, H, W), device=source.device, dtype=torch.float32)
+        gc = _c(g_color) if g_color is not None else None
+        gd = _c(g_depth) if g_depth is not None else None
+        st = N.stream()
+        N.check(lib.dmh_warp_view_bwd(N.ptr(source), N.ptr(disp), N.ptr(K), N.ptr(inv_K), N.ptr(T), B, H, W, Hs, Ws,
+                                      min_depth, max_depth, N.ptr(gc), N.ptr(gd), N.ptr(g_up), st))
+        if (Hs, Ws) == (H, W):
+            g = g_up.view(B, 1, H, W)
+        else:
+            g = torch.empty_like(disp)
+            N.check(lib.dmh_upsample_bilinear_adjoint(N.ptr(g_up), N.ptr(g), B, H, W, Hs, Ws, 0, st))
+        return None, g, None, None, None, None, None, None, None
+
+
+def warp_view(source, disp, K, inv_K, T, H, W, min_depth=0.1, max_depth=100.0):
+    """One (scale, frame) body of generate_images_pred (MD2/trainer.py:481-519):
+    returns (depth [B,1,H,W], sample grid [B,H,W,2], warped colour [B,3,H,W])."""
+    return _WarpView.apply(_c(source), _c(disp), _c(K), _c(inv_K), _c(T), int(H), int(W), float(min_depth),
+                           float(max_depth))
+
+
+def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW):
+    a = N.PasteArgs()
+    n = coeffs.shape[0]
+    if scene.shape[0] not in (1, n) or scene.shape[1] != 3:
+        raise RuntimeError("Batch size doesn't match!")
+    if patch.dim() != 4 or patch.shape[0] != 1 or patch.shape[1] != 3 or tuple(pmask.shape) != (1, 1) + tuple(patch.shape[2:]):
+        raise RuntimeError("eot_paste: patch must be [1,3,PH,PW] and mask [1,1,PH,PW]")
+    if tuple(coeffs.shape) != (n, 8):
+        raise RuntimeError("eot_paste: coeffs must be [N,8]")
+    a.scene, a.patch, a.pmask, a.coeffs = N.ptr(scene), N.ptr(patch), N.ptr(pmask), N.ptr(coeffs)
+    a.scene_bstride = 0 if scene.shape[0] == 1 else scene.shape[1] * scene.shape[2] * scene.shape[3]
+    a.N, a.SH, a.SW = n, scene.shape[2], scene.shape[3]
+    a.PH, a.PW, a.OH, a.OW = patch.shape[2], patch.shape[3], OH, OW
+    a.l_pad, a.t_pad = l_pad, t_pad
+    return a
+
+
+class _EotPaste(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW):
+        lib = N.lib()
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW)
+        adv = torch.empty((a.N, 3, OH, OW), device=scene.device, dtype=torch.float32)
+        mask_out = torch.empty((a.N, 1, OH, OW), device=scene.device, dtype=torch.float32)
+        N.check(lib.dmh_eot_paste_fwd(C.byref(a), N.ptr(adv), N.ptr(mask_out), N.stream()))
+        ctx.save_for_backward(scene, patch, pmask, coeffs)
+        ctx.geo = (l_pad, t_pad, OH, OW)
+        ctx.mark_non_differentiable(mask_out)
+        return adv, mask_out
+
+    @staticmethod
+    def backward(ctx, g_adv, g_mask):
+        scene, patch, pmask, coeffs = ctx.saved_tensors
+        l_pad, t_pad, OH, OW = ctx.geo
+        lib = N.lib()
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW)
+        g_patch = torch.zeros_like(patch)
+        N.check(lib.dmh_eot_paste_bwd(C.byref(a), N.ptr(_c(g_adv)), N.ptr(g_patch), N.stream()))
+        return None, g_patch, None, None, None, None, None, None
+
+
+def eot_paste(scene, patch, pmask, coeffs, l_pad, t_pad, out_size):
+    """Pad -> perspective(patch, mask) -> composite -> Resize, fused (physicalTrans.py:107-166 +
+    phy_obj_atk.py:87-90).  Returns (adv [N,3,OH,OW], mask_out [N,1,OH,OW]); differentiable w.r.t. patch."""
+    return _EotPaste.apply(_c(scene), _c(patch), _c(pmask), _c(coeffs), int(l_pad), int(t_pad), int(out_size[0]),
+                           int(out_size[1]))
+
+
+class _MaskedSqMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, mask):
+        lib = N.lib()
+        n = disp.numel()
+        if mask is not None and mask.numel() != n:
+            raise RuntimeError("masked_sq_mean: mask and disp sizes differ")
+        part = torch.empty(lib.dmh_sq_mean_partials_size(n), device=disp.device, dtype=torch.float32)
+        cost = torch.empty((), device=disp.device, dtype=torch.float32)
+        N.check(lib.dmh_masked_sq_mean_fwd(N.ptr(disp), N.ptr(mask), n, N.ptr(part), N.ptr(cost), N.stream()))
+        ctx.save_for_backward(disp, mask)
+        return cost
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, mask = ctx.saved_tensors
+        lib = N.lib()
+        g_disp = torch.empty_like(disp)
+        N.check(lib.dmh_masked_sq_mean_bwd(N.ptr(disp), N.ptr(mask), disp.numel(), N.ptr(_c(g.to(torch.float32))),
+                                           N.ptr(g_disp), N.stream()))
+        return g_disp, None
+
+
+def masked_sq_mean(disp, mask=None):
+    """mean((disp*mask)^2) == nn.MSELoss()(disp*mask, zeros) (phy_obj_atk.py:94)."""
+    return _MaskedSqMean.apply(_c(disp), None if mask is None else _c(mask))
+
+
+def pgd_linf_step(x, x0, grad, alpha, eps, out=None):
+    """x <- clamp(x0 + clamp(x + alpha*sign(grad) - x0, -eps, eps), 0, 1) (phy_obj_atk.py:98-101)."""
+    x, x0, grad = _c(x.detach()), _c(x0), _c(grad)
+    if x.shape != x0.shape or x.shape != grad.shape:
+        raise RuntimeError("pgd_linf_step: shape mismatch")
+    if out is None:
+        out = torch.empty_like(x)
+    N.check(N.lib().dmh_pgd_linf_step(N.ptr(x), N.ptr(x0), N.ptr(grad), float(alpha), float(eps), N.ptr(out),
+                                      x.numel(), N.stream()))
+    return out
+
+
+class _L0Compose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, obj, pos, neg, l0_clip, finalize):
+        lib = N.lib()
+        Cc, HW = obj.shape[1], obj.shape[2] * obj.shape[3]
+        adv = torch.empty_like(obj)
+        count = torch.zeros(1, device=obj.device, dtype=torch.int32)
+        N.check(lib.dmh_l0_compose_fwd(N.ptr(obj), N.ptr(pos), N.ptr(neg), Cc, HW, l0_clip, int(finalize),
+                                       N.ptr(adv), N.ptr(count), N.stream()))
+        ctx.save_for_backward(obj, pos, neg)
+        ctx.mark_non_differentiable(count)
+        return adv, count
+
+    @staticmethod
+    def backward(ctx, g_adv, g_count):
+        obj, pos, neg = ctx.saved_tensors
+        lib = N.lib()
+        Cc, HW = obj.shape[1], obj.shape[2] * obj.shape[3]
+        g_pos, g_neg = torch.empty_like(pos), torch.empty_like(neg)
+        N.check(lib.dmh_l0_compose_bwd(N.ptr(obj), N.ptr(pos), N.ptr(neg), N.ptr(_c(g_adv)), Cc, HW, N.ptr(g_pos),
+                                       N.ptr(g_neg), 0, N.stream()))
+        return None, g_pos, g_neg, None, None
+
+
+def l0_compose(obj, pos, neg, l0_clip=1.0 / 255.0, finalize=False):
+    """adv = clamp(obj + clamp(pos,0,1) - clamp(neg,0,1), 0, 1) and the L0 count of the thresholded
+    pattern (phy_obj_atk_l0.py:94-99, 43-52; finalize=True applies :143-150).  Returns (adv, count[int32,1])."""
+    if obj.dim() != 4 or obj.shape[0] != 1 or obj.shape != pos.shape or obj.shape != neg.shape:
+        raise RuntimeError("l0_compose: obj/pos/neg must all be [1,C,H,W]")
+    return _L0Compose.apply(_c(obj), _c(pos), _c(neg), float(l0_clip), bool(finalize))
+
+
+class _L0MaskCost(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pos, neg):
+        lib = N.lib()
+        Cc, HW = pos.shape[1], pos.shape[2] * pos.shape[3]
+        part = torch.empty(lib.dmh_l0_mask_partials_size(HW), device=pos.device, dtype=torch.float32)
+        cost = torch.empty((), device=pos.device, dtype=torch.float32)
+        N.check(lib.dmh_l0_mask_cost_fwd(N.ptr(pos), N.ptr(neg), Cc, HW, N.ptr(part), N.ptr(cost), N.stream()))
+        ctx.save_for_backward(pos, neg)
+        return cost
+
+    @staticmethod
+    def backward(ctx, g):
+        pos, neg = ctx.saved_tensors
+        lib = N.lib()
+        Cc, HW = pos.shape[1], pos.shape[2] * pos.shape[3]
+        g_pos, g_neg = torch.empty_like(pos), torch.empty_like(neg)
+        N.check(lib.dmh_l0_mask_cost_bwd(N.ptr(pos), N.ptr(neg), Cc, HW, N.ptr(_c(g.to(torch.float32))), None,
+                                         N.ptr(g_pos), N.ptr(g_neg), 0, N.stream()))
+        return g_pos, g_neg
+
+
+def l0_mask_cost(pos, neg):
+    """mean(max_c(tanh(pos/10)/(2-1e-7)+0.5)) + same for neg (phy_obj_atk_l0.py:130-132)."""
+    if pos.dim() != 4 or pos.shape[0] != 1 or pos.shape != neg.shape:
+        raise RuntimeError("l0_mask_cost: pos/neg must be [1,C,H,W]")
+    return _L0MaskCost.apply(_c(pos), _c(neg))

@@ -1,0 +1,203 @@
+/*
+ * dmh_hip.h -- C ABI of libdmh_hip.so: the MI355X (gfx950) hot path of the
+ * DepthModelHardening adversarial-training loop.
+ *
+ * The reference (Bob-cheng/DepthModelHardening) is pure Python; its seam for this path
+ * is a set of Python call signatures.  Every entry point below
+ * replaces one PyTorch op chain of the reference, cited as file:line relative to the
+ * reference root (MD2 = DepthNetworks/monodepth2, DH = DepthNetworks/depth-hints).
+ * The binding a maintainer would add on the reference side is a ctypes stub -- see
+ * INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C: pointers are DEVICE pointers to fp32, NCHW, contiguous; sizes are ints.
+ *    No torch types.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - the library allocates nothing, retains nothing, never synchronises; every call only
+ *    enqueues kernels on `stream` (safe under hipGraph capture).
+ *  - return value: DMH_OK or an error code; dmh_last_error() gives the message of the
+ *    calling thread's last failure.  Shape errors are caught on the host BEFORE launch.
+ */
+#ifndef DMH_HIP_H
+#define DMH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMH_OK 0
+#define DMH_EINVAL 1  /* bad argument (null pointer, unsupported shape) */
+#define DMH_ELAUNCH 2 /* hipLaunch / runtime error                      */
+
+#define DMH_MAX_SCALES 4
+#define DMH_MAX_FRAMES 4
+
+#define DMH_VARIANT_MD2 0 /* MD2/trainer.py:647-660  min over {identity, reprojection}, mean over all pixels */
+#define DMH_VARIANT_DH 1  /* DH/trainer.py:557-590,700-708  argmin mask, masked sum / mask count            */
+
+#define DMH_NOISE_NONE 0   /* no tie-break term                                                     */
+#define DMH_NOISE_TENSOR 1 /* caller passes the already-scaled term (randn*1e-5, MD2/trainer.py:642-645) */
+#define DMH_NOISE_PHILOX 2 /* N(0,1)*1e-5 generated in-kernel from (seed, offset): no HBM traffic    */
+
+/* Slots of the `fin` vector written by dmh_loss_finalize (floats). */
+#define DMH_FIN_LOSS 0       /* sum_s loss_s / NS                         MD2/trainer.py:670 */
+#define DMH_FIN_LOSS_S 1     /* [4] loss/{s}                              MD2/trainer.py:668 */
+#define DMH_FIN_REPROJ_S 5   /* [4] mean(to_optimise) | DH reproj_loss/{s}                   */
+#define DMH_FIN_COUNT_S 9    /* [4] number of pixels where reprojection was selected         */
+#define DMH_FIN_SMOOTH_S 13  /* [4] get_smooth_loss(norm_disp, color)     MD2/trainer.py:664 */
+#define DMH_FIN_SIZE 20
+
+const char* dmh_version(void);
+const char* dmh_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * K1  fused photometric loss: bilinear-upsample(disp_s) -> disp_to_depth -> BackprojectDepth
+ *     -> Project3D -> grid_sample(border, align_corners=True) -> SSIM(3x3, reflect) + L1
+ *     -> identity term -> per-pixel min / argmin mask -> block partial sums,
+ *     for all scales in ONE launch (target/source tiles are read once).
+ * Replaces: MD2/trainer.py:472-523 (generate_images_pred), :525-537
+ *           (compute_reprojection_loss), :589-660 (compute_losses body),
+ *           MD2/layers.py:16-25,139-198,223-253; DH/trainer.py:638-708.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dmh_photo_args {
+    const float* target;                 /* [B,3,H,W] inputs[("color",0,0)]                        */
+    const float* source[DMH_MAX_FRAMES]; /* [B,3,H,W] inputs[("color",f,0)], f = frame_ids[1:]     */
+    const float* T[DMH_MAX_FRAMES];      /* [B,4,4]   stereo_T or cam_T_cam                        */
+    const float* K;                      /* [B,4,4]   inputs[("K",0)]                              */
+    const float* inv_K;                  /* [B,4,4]   inputs[("inv_K",0)]                          */
+    const float* disp[DMH_MAX_SCALES];   /* [B,1,Hs,Ws] outputs[("disp",s)]                        */
+    int Hs[DMH_MAX_SCALES], Ws[DMH_MAX_SCALES];
+    int B, H, W;
+    int num_frames;                      /* 1..DMH_MAX_FRAMES                                      */
+    int num_scales;                      /* 1..DMH_MAX_SCALES                                      */
+    float min_depth, max_depth;          /* MD2/options.py:69-76                                   */
+    int variant;                         /* DMH_VARIANT_*                                          */
+    int automask;                        /* 0 = --disable_automasking                              */
+    int no_ssim;                         /* 1 = --no_ssim                                          */
+    int noise_mode;                      /* DMH_NOISE_*                                            */
+    const float* noise[DMH_MAX_SCALES];  /* TENSOR mode: [B,NF,H,W], NF = num_frames (MD2) or 1 (DH) */
+    uint64_t seed, offset;               /* PHILOX mode                                            */
+} dmh_photo_args;
+
+/* number of floats the photometric partial-sum workspace needs */
+int64_t dmh_photo_partials_size(int B, int H, int W, int num_scales);
+
+/* Forward.  sel[s]   : out [B,H,W] float, 0 = identity chosen, 1+f = reprojection of frame f chosen
+ *                      (== outputs["identity_selection/s"] for one source frame, MD2/trainer.py:656-658)
+ *           to_opt[s]: out [B,H,W] per-pixel selected loss, or NULL
+ *           partials : out, dmh_photo_partials_size floats                                      */
+int dmh_photo_loss_fwd(const dmh_photo_args* a, float* const sel[DMH_MAX_SCALES],
+                       float* const to_opt[DMH_MAX_SCALES], float* partials, void* stream);
+
+/* Backward (recompute).  gvec: [DMH_FIN_SIZE] upstream gradient of the fin vector; fin: the
+ * finalized forward vector.  g_up[s]: out [B,H,W] gradient w.r.t. the UPSAMPLED disparity of
+ * scale s (for Hs==H it IS the gradient of disp[s]).                                           */
+int dmh_photo_loss_bwd(const dmh_photo_args* a, const float* const sel[DMH_MAX_SCALES],
+                       const float* gvec, const float* fin, float* const g_up[DMH_MAX_SCALES],
+                       void* stream);
+
+/* Adjoint of F.interpolate(disp,[H,W],bilinear,align_corners=False) (MD2/trainer.py:481-482):
+ * g_disp [B,1,Hs,Ws] (+)= gather(g_up [B,H,W]).  accumulate != 0 adds to g_disp.             */
+int dmh_upsample_bilinear_adjoint(const float* g_up, float* g_disp, int B, int H, int W, int Hs, int Ws,
+                                  int accumulate, void* stream);
+
+/* Materialise generate_images_pred's tensors for one (scale, frame) (MD2/trainer.py:481-519):
+ * depth [B,1,H,W], sample [B,H,W,2], color [B,3,H,W]; any output may be NULL.                */
+int dmh_warp_view_fwd(const float* source, const float* disp, const float* K, const float* inv_K,
+                      const float* T, int B, int H, int W, int Hs, int Ws, float min_depth,
+                      float max_depth, float* depth, float* sample, float* color, void* stream);
+
+/* Backward of dmh_warp_view_fwd w.r.t. the upsampled disparity given grad_color [B,3,H,W]
+ * (and optionally grad_depth [B,1,H,W], may be NULL): g_up [B,H,W].                           */
+int dmh_warp_view_bwd(const float* source, const float* disp, const float* K, const float* inv_K,
+                      const float* T, int B, int H, int W, int Hs, int Ws, float min_depth,
+                      float max_depth, const float* grad_color, const float* grad_depth, float* g_up,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K2  edge-aware smoothness on the mean-normalised disparity, all scales in one launch.
+ * Replaces: MD2/trainer.py:662-666 + MD2/layers.py:207-220.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dmh_smooth_args {
+    const float* disp[DMH_MAX_SCALES];  /* [B,1,Hs,Ws] outputs[("disp",s)]   */
+    const float* color[DMH_MAX_SCALES]; /* [B,3,Hs,Ws] inputs[("color",0,s)] */
+    int Hs[DMH_MAX_SCALES], Ws[DMH_MAX_SCALES];
+    int B, num_scales;
+} dmh_smooth_args;
+
+int64_t dmh_smooth_partials_size(const dmh_smooth_args* a);
+int dmh_smooth_loss_fwd(const dmh_smooth_args* a, float* partials, void* stream);
+/* g_disp[s] [B,1,Hs,Ws]; accumulate != 0 adds.  sstats from dmh_loss_finalize. */
+int dmh_smooth_loss_bwd(const dmh_smooth_args* a, const float* gvec, const float* sstats,
+                        float smooth_wt, float* const g_disp[DMH_MAX_SCALES], int accumulate, void* stream);
+
+/* Deterministic final reduction of K1+K2 partials:  fin[DMH_FIN_SIZE], sstats[NS][B][2] =
+ * (mean_disp_b, R_b).  loss_s = reproj_s + smooth_wt * smooth_s / 2^s  (MD2/trainer.py:660-668). */
+int dmh_loss_finalize(const float* photo_partials, const float* smooth_partials, int B, int H, int W,
+                      const dmh_smooth_args* sm, int variant, float smooth_wt, float* fin, float* sstats,
+                      void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K3  EOT paste: Pad -> perspective warp of patch and mask -> composite -> Resize, fused.
+ * Replaces: physicalTrans.py:107-166 (padding_img, project) +
+ *           torchattacks/attacks/phy_obj_atk.py:87-90 (composite + 2x Resize).
+ * coeffs [N,8]: torchvision-0.8.2 perspective coefficients per sample (host computes them from
+ * the integer pixel quads, physicalTrans.py:62-81).  scene_bstride = 0 broadcasts one scene.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dmh_paste_args {
+    const float* scene; /* [N or 1,3,SH,SW] */
+    int64_t scene_bstride;
+    const float* patch; /* [1,3,PH,PW] */
+    const float* pmask; /* [1,1,PH,PW] */
+    const float* coeffs; /* [N,8] */
+    int N, SH, SW, PH, PW, OH, OW;
+    int l_pad, t_pad; /* physicalTrans.py:110-113 */
+} dmh_paste_args;
+
+/* adv [N,3,OH,OW], mask_out [N,1,OH,OW] (either may be NULL) */
+int dmh_eot_paste_fwd(const dmh_paste_args* a, float* adv, float* mask_out, void* stream);
+/* g_patch [1,3,PH,PW] must be zeroed by the caller; accumulated with float atomics. */
+int dmh_eot_paste_bwd(const dmh_paste_args* a, const float* g_adv, float* g_patch, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K4  PGD-L_inf update  x <- clamp(x0 + clamp(x + alpha*sign(g) - x0, -eps, eps), 0, 1)
+ * Replaces: phy_obj_atk.py:98-101, pgd_depth.py:76-78.  out may alias x.
+ * ---------------------------------------------------------------------------------- */
+int dmh_pgd_linf_step(const float* x, const float* x0, const float* g, float alpha, float eps, float* out,
+                      int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K5  L0 attack pieces (phy_obj_atk_l0.py).
+ * compose (:94-99,:43-52): adv = clamp(obj + clamp(pos,0,1) - clamp(neg,0,1), 0, 1);
+ *   l0_count (int32, zeroed by caller) += #pixels whose thresholded pattern is non-zero.
+ *   finalize != 0 applies the final thresholding of :143-150 to the composed patch too.
+ * ---------------------------------------------------------------------------------- */
+int dmh_l0_compose_fwd(const float* obj, const float* pos, const float* neg, int C, int HW, float l0_clip,
+                       int finalize, float* adv, int32_t* l0_count, void* stream);
+int dmh_l0_compose_bwd(const float* obj, const float* pos, const float* neg, const float* g_adv, int C, int HW,
+                       float* g_pos, float* g_neg, int accumulate, void* stream);
+/* mask cost (:130-132): mean_hw max_c(tanh(p/10)/(2-1e-7)+0.5) for pos and neg; cost: float[1] out.
+ * partials: 2*nblk floats (dmh_l0_mask_partials_size). */
+int64_t dmh_l0_mask_partials_size(int HW);
+int dmh_l0_mask_cost_fwd(const float* pos, const float* neg, int C, int HW, float* partials, float* cost,
+                         void* stream);
+/* g_pos/g_neg (+)= gscale[0]*weight[0] * d cost/d p ; gscale, weight: device scalars */
+int dmh_l0_mask_cost_bwd(const float* pos, const float* neg, int C, int HW, const float* gscale,
+                         const float* weight, float* g_pos, float* g_neg, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * K6  masked squared mean  cost = mean((disp*mask)^2)  (MSELoss against zeros,
+ *     phy_obj_atk.py:94, phy_obj_atk_l0.py:127).  mask may be NULL (pgd_depth.py:68).
+ * ---------------------------------------------------------------------------------- */
+int64_t dmh_sq_mean_partials_size(int64_t n);
+int dmh_masked_sq_mean_fwd(const float* disp, const float* mask, int64_t n, float* partials, float* cost,
+                           void* stream);
+/* g_disp = gscale[0] * 2 * disp * mask^2 / n */
+int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, const float* gscale, float* g_disp,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMH_HIP_H */

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Kernel-level micro-benchmark of the loss path at BASELINE config-2 shape (B=32, 320x1024).
+
+Times each C-ABI launch with HIP events on the current stream and prints algorithmic GB/s
+(SURVEY.md section 8d byte counts).  Development tool; bench.py is the judged entry point.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+import torch.nn.functional as F
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from depthmodelhardening_amd import _native as N  # noqa: E402
+from depthmodelhardening_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--B", type=int, default=32)
+    ap.add_argument("--H", type=int, default=320)
+    ap.add_argument("--W", type=int, default=1024)
+    ap.add_argument("--iters", type=int, default=20)
+    a = ap.parse_args()
+    B, H, W = a.B, a.H, a.W
+    dev = torch.device("cuda")
+    g = torch.Generator(device=dev).manual_seed(1234)
+    left = F.avg_pool2d(torch.rand(B, 3, H + 4, W + 4, device=dev, generator=g), 5, 1).contiguous()
+    right = torch.roll(left, 8, 3).contiguous()
+    colors = [left if s == 0 else F.avg_pool2d(left, 2 ** s).contiguous() for s in range(4)]
+    K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device=dev)
+    inv_K = torch.linalg.pinv(K)
+    K, inv_K = K.repeat(B, 1, 1).contiguous(), inv_K.repeat(B, 1, 1).contiguous()
+    T = torch.eye(4, device=dev).repeat(B, 1, 1)
+    T[:, 0, 3] = -0.1
+    disps = [(0.02 + 0.1 * F.avg_pool2d(torch.rand(B, 1, (H >> s) + 8, (W >> s) + 8, device=dev, generator=g), 9, 1))
+             .contiguous().requires_grad_(True) for s in range(4)]
+    lib = N.lib()
+    res = {}
+
+    cfg = dict(F=1, NS=4, min_depth=0.1, max_depth=100.0, variant="md2", automask=True, no_ssim=False,
+               smooth_wt=1e-3, want_to_opt=False, noise_mode=N.NOISE_PHILOX, seed=1, offset=0)
+    pa = ops._photo_args(cfg, left, [right], [T], K, inv_K, [d.detach() for d in disps], ())
+    sm = ops._smooth_args([d.detach() for d in disps], colors)
+    sel = [torch.empty(B, H, W, device=dev) for _ in range(4)]
+    pp = torch.empty(lib.dmh_photo_partials_size(B, H, W, 4), device=dev)
+    sp = torch.empty(lib.dmh_smooth_partials_size(C.byref(sm)), device=dev)
+    fin = torch.empty(N.FIN_SIZE, device=dev)
+    sst = torch.empty(4, B, 2, device=dev)
+    gvec = torch.zeros(N.FIN_SIZE, device=dev)
+    gvec[0] = 1.0
+    g_up = [torch.empty(B, H, W, device=dev) for _ in range(4)]
+    g_disp = [g_up[0].view(B, 1, H, W)] + [torch.empty_like(d) for d in disps[1:]]
+    st = N.stream()
+    selp, nullp, gupp, gdp = N.ptr_array(sel), N.ptr_array([None] * 4), N.ptr_array(g_up), N.ptr_array(g_disp)
+
+    HW = H * W
+    bytes_fused_fwd = B * (24 * HW + sum(4 * (HW >> (2 * s)) for s in range(4)))           # two images once + disp pyramid
+    bytes_byscale_fwd = B * sum(24 * HW + 4 * (HW >> (2 * s)) for s in range(4))            # SURVEY 8d "unfused" figure
+    res["photo_fwd_ms"] = timeit(lambda: N.check(lib.dmh_photo_loss_fwd(C.byref(pa), selp, nullp, N.ptr(pp), st)), a.iters)
+    res["smooth_fwd_ms"] = timeit(lambda: N.check(lib.dmh_smooth_loss_fwd(C.byref(sm), N.ptr(sp), st)), a.iters)
+    res["finalize_ms"] = timeit(lambda: N.check(lib.dmh_loss_finalize(N.ptr(pp), N.ptr(sp), B, H, W, C.byref(sm), 0, 1e-3,
+                                                                       N.ptr(fin), N.ptr(sst), st)), a.iters)
+    res["photo_bwd_ms"] = timeit(lambda: N.check(lib.dmh_photo_loss_bwd(C.byref(pa), selp, N.ptr(gvec), N.ptr(fin), gupp, st)), a.iters)
+
+    def adj():
+        for s in range(1, 4):
+            N.check(lib.dmh_upsample_bilinear_adjoint(N.ptr(g_up[s]), N.ptr(g_disp[s]), B, H, W, H >> s, W >> s, 0, st))
+    res["upsample_adjoint_ms"] = timeit(adj, a.iters)
+    res["smooth_bwd_ms"] = timeit(lambda: N.check(lib.dmh_smooth_loss_bwd(C.byref(sm), N.ptr(gvec), N.ptr(sst), 1e-3, gdp, 1, st)), a.iters)
+    res["photo_fwd_GBps_fused_bytes"] = bytes_fused_fwd / res["photo_fwd_ms"] / 1e6
+    res["photo_fwd_GBps_byscale_bytes"] = bytes_byscale_fwd / res["photo_fwd_ms"] / 1e6
+    res["photo_bwd_GBps_byscale_bytes"] = (bytes_byscale_fwd + B * 4 * HW * 4) / res["photo_bwd_ms"] / 1e6
+
+    def full():
+        for d in disps:
+            d.grad = None
+        o = ops.photometric_smooth_loss(left, [right], [T], K, inv_K, disps, colors, noise="philox")
+        o.fin[0].backward()
+    res["loss_fwd_bwd_python_ms"] = timeit(full, a.iters)
+    res["loss_value"] = float(fin[0])
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
