@@ -15,7 +15,8 @@ VARIANT_MD2, VARIANT_DH = 0, 1
 NOISE_NONE, NOISE_TENSOR, NOISE_PHILOX = 0, 1, 2
 FIN_LOSS, FIN_LOSS_S, FIN_REPROJ_S, FIN_COUNT_S, FIN_SMOOTH_S, FIN_SIZE = 0, 1, 5, 9, 13, 20
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libdmh_hip.so")
+LIB_PATH = os.environ.get("DMH_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
+                                                        "libdmh_hip.so")
 
 _fp = C.c_void_p
 

@@ -30,6 +30,14 @@ constexpr int B_HW = TW + 4, B_HH = TH + 4, B_LD = B_HW + 1, B_PLANE = B_HH * B_
 
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 
+// min waves per SIMD requested from the register allocator (tuning knobs)
+#ifndef DMH_FWD_WAVES
+#define DMH_FWD_WAVES 2
+#endif
+#ifndef DMH_BWD_WAVES
+#define DMH_BWD_WAVES 2
+#endif
+
 struct Cam {
     float ik[9];   // inv_K[:3,:3]           MD2/layers.py:164
     float P[12];   // (K @ T)[:3,:]          MD2/layers.py:188
@@ -141,12 +149,26 @@ __device__ __forceinline__ float tap_sample(const float* __restrict__ img, const
     return img[t.o00] * t.w00 + img[t.o01] * t.w01 + img[t.o10] * t.w10 + img[t.o11] * t.w11;
 }
 
+// SSIM window statistics with every factor scaled by 81 (mu = s/9): SSIM_n/SSIM_d is unchanged,
+// the five divisions by 9 disappear and one division is left (MD2/layers.py:243-253).
+struct SsimTerms {
+    float A1, A2, B1, B2;  // 81*(2 mu_x mu_y + C1), 81*(2 sigma_xy + C2), 81*(mu_x^2+mu_y^2+C1), 81*(sigma_x+sigma_y+C2)
+};
+
+__device__ __forceinline__ SsimTerms ssim_terms(float sx, float sy, float sxx, float syy, float sxy) {
+    const float sxsy = sx * sy, sx2 = sx * sx, sy2 = sy * sy;
+    SsimTerms t;
+    t.A1 = 2.f * sxsy + 81.f * C1;
+    t.A2 = 2.f * (9.f * sxy - sxsy) + 81.f * C2;
+    t.B1 = sx2 + sy2 + 81.f * C1;
+    t.B2 = (9.f * (sxx + syy) - sx2 - sy2) + 81.f * C2;
+    return t;
+}
+
 __device__ __forceinline__ float ssim_val(float sx, float sy, float sxx, float syy, float sxy) {
-    const float mux = sx / 9.f, muy = sy / 9.f;
-    const float sgx = sxx / 9.f - mux * mux, sgy = syy / 9.f - muy * muy, sgxy = sxy / 9.f - mux * muy;
-    const float n = (2.f * mux * muy + C1) * (2.f * sgxy + C2);
-    const float d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
-    return fminf(fmaxf((1.f - n / d) / 2.f, 0.f), 1.f);
+    const SsimTerms t = ssim_terms(sx, sy, sxx, syy, sxy);
+    const float r = __fdividef(t.A1 * t.A2, t.B1 * t.B2);
+    return fminf(fmaxf((1.f - r) * 0.5f, 0.f), 1.f);
 }
 
 // compute_reprojection_loss (MD2/trainer.py:525-537) for the thread's 4 vertically adjacent pixels.
@@ -232,7 +254,7 @@ __device__ __forceinline__ void decode_block(const KArgs& k, int& tx0, int& ty0,
 
 // ------------------------------------------------------------------------------------------------ forward
 template <int NF>
-__global__ __launch_bounds__(NT) void photo_fwd_kernel(const KArgs k) {
+__global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArgs k) {
     __shared__ float s_tgt[3 * F_PLANE];
     __shared__ float s_buf[3 * F_PLANE];
     __shared__ Cam s_cam[DMH_MAX_FRAMES];
@@ -366,7 +388,7 @@ __device__ __forceinline__ float warp_pixel_bwd(const float* __restrict__ src, c
 }
 
 template <int NF>
-__global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
+__global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArgs k) {
     __shared__ float s_tgt[3 * B_PLANE];
     __shared__ float s_wrp[3 * B_PLANE];
     __shared__ float s_cf[3 * F_PLANE];  // a0, ax, ay coefficient fields on the halo-1 tile
@@ -427,18 +449,17 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
                                 syy += yv * yv;
                                 sxy += xv * yv;
                             }
-                        const float mux = sx / 9.f, muy = sy / 9.f;
-                        const float sgx = sxx / 9.f - mux * mux, sgy = syy / 9.f - muy * muy;
-                        const float sgxy = sxy / 9.f - mux * muy;
-                        const float A1 = 2.f * mux * muy + C1, A2 = 2.f * sgxy + C2;
-                        const float B1 = mux * mux + muy * muy + C1, B2 = sgx + sgy + C2;
-                        const float d = B1 * B2, rr_ = (A1 * A2) / d;
-                        const float v = (1.f - rr_) / 2.f;
+                        // d v/d x_q = a0 + ay*y_q + ax*x_q with v = clamp((1 - n/d)/2); in the 81-scaled terms
+                        //   a0 = -G (s_y (A2-A1) - r s_x (B2-B1)) / d',  ay = -9 G A1 / d',  ax = 9 G r B1 / d'
+                        const SsimTerms t = ssim_terms(sx, sy, sxx, syy, sxy);
+                        const float invd = 1.0f / (t.B1 * t.B2);
+                        const float rr_ = (t.A1 * t.A2) * invd;
+                        const float v = (1.f - rr_) * 0.5f;
                         if (v >= 0.f && v <= 1.f) {  // clamp passes gradient on the closed interval
-                            const float gs = up * (0.85f / 3.f) / (9.f * d);
-                            a0 = -gs * (muy * (A2 - A1) - rr_ * mux * (B2 - B1));
-                            cay = -gs * A1;
-                            cax = gs * rr_ * B1;
+                            const float gs = up * (0.85f / 3.f) * invd;
+                            a0 = -gs * (sy * (t.A2 - t.A1) - rr_ * sx * (t.B2 - t.B1));
+                            cay = -9.f * gs * t.A1;
+                            cax = 9.f * gs * rr_ * t.B1;
                         }
                     }
                     s_cf[0 * F_PLANE + r * F_LD + col] = a0;

@@ -13,17 +13,14 @@ from . import _native as N
 
 LossOut = namedtuple("LossOut", ["fin", "sel", "to_opt"])
 
-_philox_state = {"seed": None, "offset": 0}
-
-
 def _philox(device, count):
-    """(seed, offset) for the in-kernel tie-break noise; follows torch.manual_seed."""
+    """(seed, offset) for the in-kernel tie-break noise, drawn from torch's CUDA generator state so
+    that torch.manual_seed() makes runs reproducible; the generator offset is advanced past the
+    ``count`` counters this call consumes."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    seed = torch.cuda.default_generators[idx].initial_seed()
-    if _philox_state["seed"] != seed:
-        _philox_state["seed"], _philox_state["offset"] = seed, 0
-    off = _philox_state["offset"]
-    _philox_state["offset"] = off + count
+    gen = torch.cuda.default_generators[idx]
+    seed, off = gen.initial_seed(), gen.get_offset()
+    gen.set_offset(off + ((count + 3) // 4) * 4)
     return seed & 0xFFFFFFFFFFFFFFFF, off
 
 

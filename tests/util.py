@@ -27,8 +27,11 @@ def assert_close_frac(got, want, rtol=1e-4, atol=1e-6, max_bad_frac=0.0, name=""
     rel_l2 = (got - want).norm().item() / denom if denom > 0 else (got - want).norm().item()
     assert frac <= max_bad_frac, "%s: %.3g of elements out of tolerance (max err %.3g, rel-L2 %.3g)" % (
         name, frac, err.max().item(), rel_l2)
-    if max_bad_frac == 0.0:
-        assert rel_l2 <= 10 * rtol or (got - want).abs().max().item() <= atol, "%s: rel-L2 %.3g" % (name, rel_l2)
+    # rel-L2 over the elements that are in tolerance (all of them when no outliers are allowed)
+    good = ~bad
+    dg = want[good].norm().item()
+    trimmed = (got[good] - want[good]).norm().item() / dg if dg > 0 else 0.0
+    assert trimmed <= 10 * rtol or err[good].max().item() <= atol, "%s: trimmed rel-L2 %.3g" % (name, trimmed)
     return frac, rel_l2
 
 
