@@ -13,6 +13,7 @@ MAX_SCALES = 4
 MAX_FRAMES = 4
 VARIANT_MD2, VARIANT_DH = 0, 1
 NOISE_NONE, NOISE_TENSOR, NOISE_PHILOX = 0, 1, 2
+PASTE_COMPOSITE, PASTE_WARP_ONLY = 0, 1
 FIN_LOSS, FIN_LOSS_S, FIN_REPROJ_S, FIN_COUNT_S, FIN_SMOOTH_S, FIN_SIZE = 0, 1, 5, 9, 13, 20
 
 LIB_PATH = os.environ.get("DMH_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
@@ -38,7 +39,7 @@ class SmoothArgs(C.Structure):
 class PasteArgs(C.Structure):
     _fields_ = [("scene", _fp), ("scene_bstride", C.c_int64), ("patch", _fp), ("pmask", _fp), ("coeffs", _fp),
                 ("N", C.c_int), ("SH", C.c_int), ("SW", C.c_int), ("PH", C.c_int), ("PW", C.c_int),
-                ("OH", C.c_int), ("OW", C.c_int), ("l_pad", C.c_int), ("t_pad", C.c_int)]
+                ("OH", C.c_int), ("OW", C.c_int), ("l_pad", C.c_int), ("t_pad", C.c_int), ("mode", C.c_int)]
 
 
 _PtrArr = _fp * MAX_SCALES

@@ -103,7 +103,8 @@ __global__ __launch_bounds__(NT) void paste_fwd_kernel(const dmh_paste_args a, f
     const Homog m = load_homog(a.coeffs + n * 8, a.SW, a.SH);
     const RTap r = resize_tap(oy, ox, a.SH, a.SW, a.OH, a.OW);
     const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW;
-    const float* sc = a.scene + (size_t)n * a.scene_bstride;
+    const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
+    const float* sc = warp_only ? nullptr : a.scene + (size_t)n * a.scene_bstride;
     const int Ys[2] = {r.y0, r.y1}, Xs[2] = {r.x0, r.x1};
     float comp[2][2][3], mm[2][2];
 #pragma unroll
@@ -118,10 +119,9 @@ __global__ __launch_bounds__(NT) void paste_fwd_kernel(const dmh_paste_args a, f
             mm[j][i] = mk;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float s = sc[c * shw + so];
                 float o = 0.f;
                 if (t.any) o = patch_sample(a.patch + c * phw, t, a.PW, a.PH);
-                comp[j][i][c] = s * (1.f - mk) + o * mk;  // phy_obj_atk.py:88
+                comp[j][i][c] = warp_only ? o : sc[c * shw + so] * (1.f - mk) + o * mk;  // phy_obj_atk.py:88
             }
         }
     const float hy = 1.f - r.ly, hx = 1.f - r.lx;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, c
             if (w == 0.f) continue;
             const PTap t = patch_tap(m, Xs[i], Ys[j], a.l_pad, a.t_pad, a.PW, a.PH);
             if (!t.any) continue;
-            const float mk = patch_sample(a.pmask, t, a.PW, a.PH);
+            const float mk = a.mode == DMH_PASTE_WARP_ONLY ? 1.f : patch_sample(a.pmask, t, a.PW, a.PH);
             if (mk == 0.f) continue;
             if (!loaded) {
 #pragma unroll
@@ -181,7 +181,8 @@ __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, c
 
 int check_paste(const dmh_paste_args* a) {
     DMH_REQUIRE(a != nullptr, "args is null");
-    DMH_REQUIRE(a->scene && a->patch && a->pmask && a->coeffs, "null input");
+    DMH_REQUIRE(a->mode == DMH_PASTE_COMPOSITE || a->mode == DMH_PASTE_WARP_ONLY, "bad mode");
+    DMH_REQUIRE((a->scene || a->mode == DMH_PASTE_WARP_ONLY) && a->patch && a->pmask && a->coeffs, "null input");
     DMH_REQUIRE(a->N > 0 && a->SH >= 2 && a->SW >= 2 && a->OH > 0 && a->OW > 0, "bad sizes");
     DMH_REQUIRE(a->PH > 0 && a->PW > 0 && a->l_pad >= 0 && a->t_pad >= 0, "bad patch geometry");
     DMH_REQUIRE(a->l_pad + a->PW <= a->SW && a->t_pad + a->PH <= a->SH, "patch does not fit the padded frame");

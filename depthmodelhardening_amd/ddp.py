@@ -1,0 +1,112 @@
+"""Data-parallel gradient exchange: one flat fp32 bucket, one RCCL all-reduce per iteration.
+
+The reference is single-GPU (MD2 README.md:149); this is new work.  One process
+per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI; ``gloo`` on CPU for tests).  Every
+trainable tensor's ``.grad`` is a view into ONE contiguous buffer (57.3 MB for ResNet-18 + decoder), so
+the exchange is a single all-reduce; it is issued on a side stream right after backward and the
+training loop only waits for it before ``optimizer.step()`` -- in the default (throughput) mode that wait
+is placed AFTER the next iteration's attack has been enqueued, so the collective overlaps the attack.
+xGMI is point-to-point (7 links x ~153 GB/s): a ring moves 2*(N-1)/N * 57.3 MB per GPU ~ 0.65 ms at
+N=8 -- latency-, not bandwidth-bound, hence one bucket rather than many.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(device_type="cuda"):
+    """Initialise from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*).  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if device_type == "cuda":
+        torch.cuda.set_device(local)
+        device = torch.device("cuda", local)
+    else:
+        device = torch.device("cpu")
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = "nccl" if device_type == "cuda" else "gloo"
+        kw = {"device_id": device} if device_type == "cuda" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, device
+
+
+class GradBucket(object):
+    """Flat gradient bucket over the parameters that can receive a gradient.
+
+    ``params``: iterable of tensors (requires_grad).  Parameters that never get a gradient (the encoder's
+    unused ``fc``, MD2/trainer.py:85) should be excluded by the caller.
+    """
+
+    def __init__(self, params, world_size=None, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise RuntimeError("GradBucket: no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)  # autograd accumulates in place into the view
+            off += n
+        self.group = group
+        self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
+        self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
+        self._work = None
+        self._event = None
+
+    def zero(self):
+        self.flat.zero_()
+
+    def start_all_reduce(self):
+        """Enqueue sum-all-reduce + 1/N of the bucket; returns immediately."""
+        if self.world <= 1:
+            return
+        if self.stream is not None:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work.wait()           # orders the side stream after the collective (no host block)
+                self.flat.div_(self.world)
+                self._event = torch.cuda.Event()
+                self._event.record(self.stream)
+        else:
+            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def finish_all_reduce(self):
+        """Make the averaged gradients visible to the current stream (call before optimizer.step())."""
+        if self.world <= 1:
+            return
+        if self.stream is not None:
+            if self._event is not None:
+                torch.cuda.current_stream().wait_event(self._event)
+                self._event = None
+        elif self._work is not None:
+            self._work.wait()
+            self.flat.div_(self.world)
+        self._work = None
+
+    def all_reduce(self):
+        self.start_all_reduce()
+        self.finish_all_reduce()
+
+
+def broadcast_parameters(modules, src=0, group=None):
+    """Make every rank start from rank ``src``'s weights and buffers (one flat broadcast per module)."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return
+    for m in modules:
+        tensors = [p.data for p in m.parameters()] + [b.data for b in m.buffers() if b.dtype.is_floating_point]
+        if not tensors:
+            continue
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n

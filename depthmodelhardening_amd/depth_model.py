@@ -1,0 +1,38 @@
+"""The callable the attacks differentiate through (reference ``depth_model.py:10-20,89-161``)."""
+import os
+
+import torch
+import torch.nn
+
+from . import networks
+
+
+class DepthModelWrapper(torch.nn.Module):
+    """encoder -> decoder -> outputs[("disp", 0)]."""
+
+    def __init__(self, encoder, decoder) -> None:
+        super().__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+
+    def forward(self, input_image):
+        return self.decoder(self.encoder(input_image))[("disp", 0)]
+
+
+def import_depth_model(scene_size, model_type='monodepth2', pre_model_path=None):
+    """Build the Monodepth2 ResNet-18 depth model and load ``encoder.pth`` / ``depth.pth`` from
+    ``pre_model_path`` when given (depth_model.py:117-153 filters the encoder dict by key the same way).
+    Without weights on disk the model is randomly initialised (no network in this environment).
+
+    scene_size: (width, height)."""
+    if model_type != 'monodepth2':
+        raise RuntimeError("only the monodepth2 depth model is in scope, got %r" % (model_type,))
+    if tuple(scene_size) not in ((1024, 320),):
+        raise RuntimeError("scene size undefined!")
+    encoder = networks.ResnetEncoder(18, False)
+    decoder = networks.DepthDecoder(num_ch_enc=encoder.num_ch_enc, scales=range(4))
+    if pre_model_path is not None:
+        enc = torch.load(os.path.join(pre_model_path, "encoder.pth"), map_location="cpu")
+        encoder.load_state_dict({k: v for k, v in enc.items() if k in encoder.state_dict()})
+        decoder.load_state_dict(torch.load(os.path.join(pre_model_path, "depth.pth"), map_location="cpu"))
+    return DepthModelWrapper(encoder, decoder)

@@ -1,0 +1,43 @@
+"""U-Net depth decoder of Monodepth2 (MD2/networks/depth_decoder.py:17-65): reflection-padded 3x3
+convs + ELU, nearest x2 upsampling, skip connections, one sigmoid disparity head per scale.
+``self.decoder`` is the ModuleList in the reference's insertion order, so ``depth.pth`` keys match."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..layers import ConvBlock, Conv3x3, upsample
+
+
+class DepthDecoder(nn.Module):
+    def __init__(self, num_ch_enc, scales=range(4), num_output_channels=1, use_skips=True):
+        super().__init__()
+        self.num_output_channels = num_output_channels
+        self.use_skips = use_skips
+        self.upsample_mode = 'nearest'
+        self.scales = scales
+        self.num_ch_enc = num_ch_enc
+        self.num_ch_dec = np.array([16, 32, 64, 128, 256])
+        self.convs = OrderedDict()
+        for i in range(4, -1, -1):
+            cin = self.num_ch_enc[-1] if i == 4 else self.num_ch_dec[i + 1]
+            self.convs[("upconv", i, 0)] = ConvBlock(cin, self.num_ch_dec[i])
+            cin = self.num_ch_dec[i] + (self.num_ch_enc[i - 1] if (use_skips and i > 0) else 0)
+            self.convs[("upconv", i, 1)] = ConvBlock(cin, self.num_ch_dec[i])
+        for s in self.scales:
+            self.convs[("dispconv", s)] = Conv3x3(self.num_ch_dec[s], num_output_channels)
+        self.decoder = nn.ModuleList(list(self.convs.values()))
+        self.sigmoid = nn.Sigmoid()
+
+    def forward(self, input_features):
+        self.outputs = {}
+        x = input_features[-1]
+        for i in range(4, -1, -1):
+            x = upsample(self.convs[("upconv", i, 0)](x))
+            if self.use_skips and i > 0:
+                x = torch.cat([x, input_features[i - 1]], 1)
+            x = self.convs[("upconv", i, 1)](x)
+            if i in self.scales:
+                self.outputs[("disp", i)] = self.sigmoid(self.convs[("dispconv", i)](x))
+        return self.outputs

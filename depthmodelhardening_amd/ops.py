@@ -13,6 +13,35 @@ from . import _native as N
 
 LossOut = namedtuple("LossOut", ["fin", "sel", "to_opt"])
 
+# Optional per-launch HIP-event timing of the K1 kernels (bench.py's roofline figure): a dict
+# name -> list of (start, end) torch.cuda.Event pairs recorded on the launch stream, or None (off).
+_profile = None
+
+
+def enable_profile(on=True):
+    global _profile
+    _profile = {} if on else None
+
+
+def profile_ms():
+    """Average launch duration in ms per instrumented kernel (synchronises)."""
+    if not _profile:
+        return {}
+    torch.cuda.synchronize()
+    return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in _profile.items() if v}
+
+
+def _timed(name, launch):
+    if _profile is None:
+        return launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = launch()
+    e1.record()
+    _profile.setdefault(name, []).append((e0, e1))
+    return rc
+
+
 def _philox(device, count):
     """(seed, offset) for the in-kernel tie-break noise, drawn from torch's CUDA generator state so
     that torch.manual_seed() makes runs reproducible; the generator offset is advanced past the
@@ -104,7 +133,8 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         fin = torch.empty(N.FIN_SIZE, device=dev, dtype=torch.float32)
         sstats = torch.empty((NS, B, 2), device=dev, dtype=torch.float32)
         st = N.stream()
-        N.check(lib.dmh_photo_loss_fwd(C.byref(a), N.ptr_array(sel), N.ptr_array(to_opt), N.ptr(pp), st))
+        selp, optp = N.ptr_array(sel), N.ptr_array(to_opt)
+        N.check(_timed("photo_fwd", lambda: lib.dmh_photo_loss_fwd(C.byref(a), selp, optp, N.ptr(pp), st)))
         N.check(lib.dmh_smooth_loss_fwd(C.byref(sm), N.ptr(sp), st))
         N.check(lib.dmh_loss_finalize(N.ptr(pp), N.ptr(sp), B, H, W, C.byref(sm), a.variant, cfg["smooth_wt"],
                                       N.ptr(fin), N.ptr(sstats), st))
@@ -133,7 +163,8 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         sm = _smooth_args(disps, colors)
         st = N.stream()
         g_up = [torch.empty((B, H, W), device=dev, dtype=torch.float32) for _ in range(NS)]
-        N.check(lib.dmh_photo_loss_bwd(C.byref(a), N.ptr_array(sel), N.ptr(gvec), N.ptr(fin), N.ptr_array(g_up), st))
+        selp, gupp = N.ptr_array(sel), N.ptr_array(g_up)
+        N.check(_timed("photo_bwd", lambda: lib.dmh_photo_loss_bwd(C.byref(a), selp, N.ptr(gvec), N.ptr(fin), gupp, st)))
         g_disp = []
         for s, d in enumerate(disps):
             Hs, Ws = d.shape[2], d.shape[3]
@@ -229,16 +260,18 @@ def warp_view(source, disp, K, inv_K, T, H, W, min_depth=0.1, max_depth=100.0):
                            float(max_depth))
 
 
-def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW):
+def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_COMPOSITE):
     a = N.PasteArgs()
     n = coeffs.shape[0]
+    a.mode = mode
     if scene.shape[0] not in (1, n) or scene.shape[1] != 3:
         raise RuntimeError("Batch size doesn't match!")
     if patch.dim() != 4 or patch.shape[0] != 1 or patch.shape[1] != 3 or tuple(pmask.shape) != (1, 1) + tuple(patch.shape[2:]):
         raise RuntimeError("eot_paste: patch must be [1,3,PH,PW] and mask [1,1,PH,PW]")
     if tuple(coeffs.shape) != (n, 8):
         raise RuntimeError("eot_paste: coeffs must be [N,8]")
-    a.scene, a.patch, a.pmask, a.coeffs = N.ptr(scene), N.ptr(patch), N.ptr(pmask), N.ptr(coeffs)
+    a.scene = N.ptr(scene) if mode == N.PASTE_COMPOSITE else None
+    a.patch, a.pmask, a.coeffs = N.ptr(patch), N.ptr(pmask), N.ptr(coeffs)
     a.scene_bstride = 0 if scene.shape[0] == 1 else scene.shape[1] * scene.shape[2] * scene.shape[3]
     a.N, a.SH, a.SW = n, scene.shape[2], scene.shape[3]
     a.PH, a.PW, a.OH, a.OW = patch.shape[2], patch.shape[3], OH, OW
@@ -248,33 +281,42 @@ def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW):
 
 class _EotPaste(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW):
+    def forward(ctx, scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode):
         lib = N.lib()
-        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW)
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode)
         adv = torch.empty((a.N, 3, OH, OW), device=scene.device, dtype=torch.float32)
         mask_out = torch.empty((a.N, 1, OH, OW), device=scene.device, dtype=torch.float32)
         N.check(lib.dmh_eot_paste_fwd(C.byref(a), N.ptr(adv), N.ptr(mask_out), N.stream()))
         ctx.save_for_backward(scene, patch, pmask, coeffs)
-        ctx.geo = (l_pad, t_pad, OH, OW)
+        ctx.geo = (l_pad, t_pad, OH, OW, mode)
         ctx.mark_non_differentiable(mask_out)
         return adv, mask_out
 
     @staticmethod
     def backward(ctx, g_adv, g_mask):
         scene, patch, pmask, coeffs = ctx.saved_tensors
-        l_pad, t_pad, OH, OW = ctx.geo
+        l_pad, t_pad, OH, OW, mode = ctx.geo
         lib = N.lib()
-        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW)
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode)
         g_patch = torch.zeros_like(patch)
         N.check(lib.dmh_eot_paste_bwd(C.byref(a), N.ptr(_c(g_adv)), N.ptr(g_patch), N.stream()))
-        return None, g_patch, None, None, None, None, None, None
+        return None, g_patch, None, None, None, None, None, None, None
 
 
 def eot_paste(scene, patch, pmask, coeffs, l_pad, t_pad, out_size):
     """Pad -> perspective(patch, mask) -> composite -> Resize, fused (physicalTrans.py:107-166 +
     phy_obj_atk.py:87-90).  Returns (adv [N,3,OH,OW], mask_out [N,1,OH,OW]); differentiable w.r.t. patch."""
     return _EotPaste.apply(_c(scene), _c(patch), _c(pmask), _c(coeffs), int(l_pad), int(t_pad), int(out_size[0]),
-                           int(out_size[1]))
+                           int(out_size[1]), N.PASTE_COMPOSITE)
+
+
+def perspective_warp(patch, pmask, coeffs, l_pad, t_pad, frame_size):
+    """Pad + torchvision-0.8.2 perspective of patch and mask into [N,3,SH,SW] / [N,1,SH,SW] frames
+    (physicalTrans.py:156-165), no compositing; differentiable w.r.t. patch."""
+    SH, SW = int(frame_size[0]), int(frame_size[1])
+    dummy = patch.new_empty((1, 3, SH, SW))   # shape carrier only; never read in warp-only mode
+    return _EotPaste.apply(dummy, _c(patch), _c(pmask), _c(coeffs), int(l_pad), int(t_pad), SH, SW,
+                           N.PASTE_WARP_ONLY)
 
 
 class _MaskedSqMean(torch.autograd.Function):

@@ -1,0 +1,106 @@
+"""PGD-L_inf attack on one shared object patch under expectation over physical transformations.
+
+Same class name, constructor, call signature, return tuple and error behaviour as the reference's
+``torchattacks/attacks/phy_obj_atk.py:13-123``.  The inner loop (:83-101) is re-built on the HIP kernels:
+
+    per step   K3 eot_paste (pad + perspective + composite + resize, one launch for all B samples)
+               -> model (PyTorch/MIOpen) -> K6 masked_sq_mean -> autograd (K6 bwd, model bwd, K3 bwd)
+               -> K4 pgd_linf_step
+
+instead of B x 2 ``perspective`` calls, a composite, two ``Resize`` and five element-wise kernels.
+The (z0, alpha) draws use ``random.sample`` in the reference's order; the per-step homography
+coefficients for the whole attack are computed on the host up front and shipped in ONE H2D copy.
+"""
+from random import sample
+
+import numpy as np
+import torch
+
+from ... import ops
+from ...my_utils import object_dataset_root, ori_H, ori_W
+from ...physicalTrans import PhysicalTrans
+from ..attack import Attack
+
+
+class Phy_obj_atk(Attack):
+    r"""
+    Distance Measure : Linf
+
+    Arguments:
+        model (nn.Module): model to attack.
+        obj_img (1x3xHxW), obj_mask (1x1xHxW): object patch and its paint mask.
+        eps (float): maximum perturbation. (Default: 0.3)
+        alpha (float): step size. (Default: 2/255)
+        steps (int): number of steps. (Default: 40)
+        random_start (bool): using random initialization of delta. (Default: True)
+    """
+
+    def __init__(self, model, obj_img, obj_mask, eps=0.3,
+                 alpha=2 / 255, steps=40, random_start=True, dist_range=list(range(5, 31, 2))):
+        super().__init__("PGD", model)
+        self.obj_img = obj_img
+        self.obj_mask = obj_mask
+        self.eps = eps
+        self.alpha = alpha
+        self.steps = steps
+        self.random_start = random_start
+        self._supported_mode = ['default', 'targeted']
+        self._targeted = True
+        self.scene_size = [320, 1024]
+        self.random_start_noise = None  # test hook: a tensor here replaces the uniform_(-eps, eps) draw
+        conf = {'path': f'{object_dataset_root}/training/calib/003086.txt'}
+        self.phy_trans_adv = PhysicalTrans(self.obj_img.clone(), self.obj_mask, conf, (1, 3, ori_H, ori_W),
+                                           dist_range=dist_range)
+        self.phy_trans_ben = PhysicalTrans(self.obj_img, self.obj_mask, conf, (1, 3, ori_H, ori_W),
+                                           dist_range=dist_range)
+
+    def _coeffs(self, samples):
+        """One device tensor [len(samples), B, 8] for a list of (z0, alpha) sample lists."""
+        host = np.stack([self.phy_trans_ben.coeffs_for(z0, al) for z0, al in samples], 0)
+        return torch.from_numpy(host).to(self.device, non_blocking=True)
+
+    def forward(self, images, batch_size, cfg_path=f'{object_dataset_root}/training/calib/003086.txt', eval=False):
+        r"""
+        images: scene image, 1*3*375*1242 (tiled over the batch) or batch_size*3*375*1242.
+        In eval mode the first object position / angle of the returned scenes is fixed (7 m, 0 deg).
+        """
+        images = images.detach().to(self.device)
+        if images.size()[0] != 1 and images.size()[0] != batch_size:
+            raise RuntimeError('Batch size doesn\'t match!')
+        scene_imgs = images  # a single scene is broadcast inside the kernel (no torch.cat copy)
+
+        obj_img_adv = self.obj_img.clone().detach()
+        if self.random_start:
+            noise = self.random_start_noise
+            if noise is None:
+                noise = torch.empty_like(obj_img_adv).uniform_(-self.eps, self.eps)
+            obj_img_adv = torch.clamp(obj_img_adv + noise.to(self.device), min=0, max=1).detach()
+
+        # every (z0, alpha) draw of the attack, in the reference's order: one project() per step
+        # (physicalTrans.py:150,155), then the two explicit draws for the returned scenes (:108-109)
+        pt = self.phy_trans_ben
+        draws = [pt.draw_samples(batch_size) for _ in range(self.steps)]
+        z0_sample = sample(pt.dist_range, batch_size)
+        alpha_sample = sample(pt.angle_range, batch_size)
+        if eval:
+            z0_sample[0] = 7
+            alpha_sample[0] = 0
+        coeffs = self._coeffs(draws + [(z0_sample, alpha_sample)])
+        l_pad, t_pad = pt.l_pad, pt.t_pad
+        mask = self.obj_mask.to(self.device)
+
+        for s in range(self.steps):
+            obj_img_adv.requires_grad_()
+            adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[s], l_pad, t_pad,
+                                                      self.scene_size)
+            adv_depth = self.model(adv_scenes)
+            cost = -ops.masked_sq_mean(adv_depth, obj_masks_out)  # -MSE(adv_depth * mask, 0)
+            grad = torch.autograd.grad(cost, obj_img_adv, retain_graph=False, create_graph=False)[0]
+            obj_img_adv = ops.pgd_linf_step(obj_img_adv, self.obj_img, grad, self.alpha, self.eps)
+
+        self.phy_trans_adv.reset_img(obj_img_adv, self.obj_mask)
+        with torch.no_grad():
+            adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[-1], l_pad, t_pad,
+                                                      self.scene_size)
+            ben_scenes, _ = ops.eot_paste(scene_imgs, self.obj_img, mask, coeffs[-1], l_pad, t_pad, self.scene_size)
+        return adv_scenes, ben_scenes, obj_masks_out, obj_img_adv

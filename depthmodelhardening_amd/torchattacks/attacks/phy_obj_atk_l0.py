@@ -1,0 +1,140 @@
+"""L0 physical-object attack: two non-negative pattern tensors optimised with Adam under a tanh
+sparsity penalty that an L0-ratio threshold switches on and off.
+
+Same surface as the reference's ``torchattacks/attacks/phy_obj_atk_l0.py:16-174``.  Per iteration:
+K5 l0_compose (pattern clamp/compose + thresholded L0 count, one launch) -> K3 eot_paste -> model ->
+K6 masked_sq_mean + K5 l0_mask_cost -> autograd -> Adam.  The reference reads the L0 ratio on the host
+every iteration (:105-111, a device sync); here the mask weight is selected ON DEVICE and the host only
+looks at the ratio when it can end the loop (stp >= steps).
+"""
+import random
+from random import sample
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ... import ops
+from ...my_utils import object_dataset_root, ori_H, ori_W
+from ...physicalTrans import PhysicalTrans
+from ..attack import Attack
+
+
+class Phy_obj_atk_l0(Attack):
+    r"""
+    Distance Measure : L_0
+    """
+
+    def __init__(self, model, obj_img, obj_mask, adam_lr=0.5, steps=10, mask_wt=0.1, l0_thresh=1 / 10,
+                 dist_range=list(range(5, 31, 2))):
+        super().__init__("PGD", model)
+        self.obj_img = obj_img.clone().detach()
+        self.obj_mask = obj_mask.clone().detach()
+        self.steps = steps
+        self.scene_size = [320, 1024]
+        self.clip_max = 1
+        self.learning_rate = adam_lr
+        self.mask_weight_init = mask_wt
+        self.mask_weight = self.mask_weight_init
+        self.l0_thresh = l0_thresh
+        self.l0_clip = self.clip_max / 255.
+        conf = {'path': f'{object_dataset_root}/training/calib/003086.txt'}
+        self.phy_trans_adv = PhysicalTrans(self.obj_img.clone(), self.obj_mask, conf, (1, 3, ori_H, ori_W),
+                                           dist_range=dist_range)
+        self.phy_trans_ben = PhysicalTrans(self.obj_img, self.obj_mask, conf, (1, 3, ori_H, ori_W),
+                                           dist_range=dist_range)
+        self.trace = None  # set to a list to record (l0, mask_weight, adv_cost, mask_cost) per iteration
+
+    def cal_l0(self):
+        """Number of pixels whose thresholded pattern is non-zero (:43-52), as a device tensor."""
+        _, count = ops.l0_compose(self.obj_img, self.pattern_pos_tensor.detach(), self.pattern_neg_tensor.detach(),
+                                  self.l0_clip)
+        return count[0]
+
+    def forward(self, images, batch_size, cfg_path=f'{object_dataset_root}/training/calib/003086.txt', eval=False,
+                color_jit=False):
+        if color_jit:
+            raise NotImplementedError("color_jit needs torchvision ColorJitter (phy_obj_atk_l0.py:41,124); the "
+                                      "training path never enables it (mono_dataset.py:182)")
+        img_B, img_C, img_H, img_W = images.size()
+        if img_H != ori_H or img_W != ori_W:
+            images = F.interpolate(images, size=[ori_H, ori_W], mode="bilinear", align_corners=False)
+            print("image size inconsistent in l0 attack")
+        images = images.detach().to(self.device)
+        if img_B != 1 and img_B != batch_size:
+            raise RuntimeError('Batch size doesn\'t match!')
+        scene_imgs = images
+
+        # numpy RNG on the host, exactly as the reference (:73-83)
+        pats = []
+        for _ in range(2):
+            init_pattern = np.random.random(self.obj_img.size()) * self.clip_max
+            init_pattern = np.clip(init_pattern, 0.0, self.clip_max) / self.clip_max
+            t = torch.Tensor(init_pattern).to(self.device)
+            t.requires_grad = True
+            pats.append(t)
+        self.pattern_pos_tensor, self.pattern_neg_tensor = pats
+        optimizer = torch.optim.Adam([self.pattern_pos_tensor, self.pattern_neg_tensor], lr=self.learning_rate,
+                                     betas=(0.5, 0.9))
+
+        pt = self.phy_trans_ben
+        max_iter = self.steps * 2
+        # All (z0, alpha) draws up front -> one H2D copy of the homographies.  The reference only consumes
+        # a project() draw for iterations it actually runs, so the RNG state after each iteration's draws
+        # is kept and restored if the loop ends early: later draws then match the reference draw for draw.
+        draws, rng_states = [], [random.getstate()]
+        for _ in range(max_iter):
+            draws.append(pt.draw_samples(batch_size))
+            rng_states.append(random.getstate())
+        coeffs_host = np.stack([pt.coeffs_for(z0, al) for z0, al in draws], 0)
+        coeffs = torch.from_numpy(coeffs_host).to(self.device, non_blocking=True)
+        l_pad, t_pad = pt.l_pad, pt.t_pad
+        mask = self.obj_mask.to(self.device)
+        thresh = torch.tensor(float(self.l0_thresh), device=self.device)
+        w_on = torch.tensor(float(self.mask_weight_init), device=self.device)
+        w_off = torch.zeros((), device=self.device)
+        l0_norm_init = None
+        mw = w_on
+        ran = 0
+        for stp in range(max_iter):
+            obj_img_adv, l0_norm = ops.l0_compose(self.obj_img, self.pattern_pos_tensor, self.pattern_neg_tensor,
+                                                  self.l0_clip)
+            if stp == 0:
+                l0_norm_init = l0_norm
+            below = (l0_norm.float() / l0_norm_init.float())[0] <= thresh
+            if stp >= self.steps and bool(below):  # the only host read of the ratio (:106-109)
+                mw = w_off
+                break
+            mw = torch.where(below, w_off, w_on)
+            adv_scenes, adv_obj_mask = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[stp], l_pad, t_pad,
+                                                     self.scene_size)
+            adv_depth = self.model(adv_scenes)
+            adv_cost = ops.masked_sq_mean(adv_depth, adv_obj_mask)
+            mask_cost = ops.l0_mask_cost(self.pattern_pos_tensor, self.pattern_neg_tensor)
+            total_cost = adv_cost + mw * mask_cost
+            # same update as zero_grad(); total_cost.backward(); step() (:136-138), but only the two
+            # pattern tensors get gradients: the reference's backward() also fills (and later discards)
+            # weight gradients of the attacked model -- a third of the conv backward work
+            g_pos, g_neg = torch.autograd.grad(total_cost, [self.pattern_pos_tensor, self.pattern_neg_tensor])
+            self.pattern_pos_tensor.grad, self.pattern_neg_tensor.grad = g_pos, g_neg
+            optimizer.step()
+            ran += 1
+            if self.trace is not None:
+                self.trace.append((int(l0_norm), float(mw), float(adv_cost), float(mask_cost)))
+        random.setstate(rng_states[ran])
+
+        with torch.no_grad():
+            obj_img_adv, _ = ops.l0_compose(self.obj_img, self.pattern_pos_tensor.detach(),
+                                            self.pattern_neg_tensor.detach(), self.l0_clip, finalize=True)
+        self.phy_trans_adv.reset_img(obj_img_adv, self.obj_mask)
+        z0_sample = sample(pt.dist_range, batch_size)
+        alpha_sample = sample(pt.angle_range, batch_size)
+        if eval:
+            z0_sample[0] = 6.1
+            alpha_sample[0] = 0
+        cf = torch.from_numpy(pt.coeffs_for(z0_sample, alpha_sample)).to(self.device)
+        with torch.no_grad():
+            adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, cf, l_pad, t_pad, self.scene_size)
+            ben_scenes, _ = ops.eot_paste(scene_imgs, self.obj_img, mask, cf, l_pad, t_pad, self.scene_size)
+        self.mask_weight = float(mw)
+        return adv_scenes, ben_scenes, obj_masks_out, obj_img_adv

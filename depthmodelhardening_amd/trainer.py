@@ -1,0 +1,321 @@
+"""Adversarial-training Trainer: the reference's ``MD2/trainer.py`` surface on the HIP hot path.
+
+Same method names and dict contracts as the reference:
+
+  generate_images_pred(inputs, outputs)      MD2/trainer.py:472-523
+  compute_reprojection_loss(pred, target)    MD2/trainer.py:525-537
+  compute_losses(inputs, outputs) -> dict    MD2/trainer.py:539-674  (loss, loss/{s}, sup_loss, contras_loss;
+                                             writes outputs["identity_selection/{s}"])
+  process_batch / run_epoch / train / set_train / set_eval / save_model / load_model / save_opts
+
+What changed underneath: compute_losses is ONE fused HIP loss (K1 + K2 + finalise) over all scales instead
+of ~300 eager kernels; the attack (dataset.update_adv_obj) runs on K3/K4/K5/K6; gradients are exchanged by a
+single RCCL all-reduce of a flat bucket on a side stream (ddp.GradBucket) that overlaps the next
+iteration's attack unless --sync_attack asks for the reference's strict order.
+"""
+import json
+import os
+import time
+
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+
+from . import _native as N
+from . import networks, ops
+from .contrastive import SimSiam
+from .datasets import SyntheticKITTIDataset, make_object
+from .ddp import GradBucket, broadcast_parameters
+from .depth_model import DepthModelWrapper, import_depth_model
+from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth
+from .my_utils import ori_H, ori_W
+
+
+class Trainer:
+    def __init__(self, options, rank=0, world_size=1, device=None):
+        self.opt = options
+        self.rank, self.world_size = rank, world_size
+        self.log_path = os.path.join(self.opt.log_dir, self.opt.model_name)
+        assert self.opt.height % 32 == 0, "'height' must be a multiple of 32"
+        assert self.opt.width % 32 == 0, "'width' must be a multiple of 32"
+        self.models = {}
+        self.parameters_to_train = []
+        self.device = device if device is not None else torch.device("cpu" if self.opt.no_cuda else "cuda")
+        self.num_scales = len(self.opt.scales)
+        self.num_input_frames = len(self.opt.frame_ids)
+        assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
+        self.use_pose_net = not (self.opt.use_stereo and self.opt.frame_ids == [0])
+        if self.opt.use_stereo:
+            self.opt.frame_ids.append("s")
+        if self.use_pose_net:
+            raise NotImplementedError("pose networks (monocular frames -1/+1) are outside the hot-path scope; "
+                                      "train with --frame_ids 0 --use_stereo as the paper's command does "
+                                      "(reference README.md:87-91)")
+        for flag in ("v1_multiscale", "avg_reprojection", "predictive_mask", "gt_depth"):
+            if getattr(self.opt, flag):
+                raise NotImplementedError("--%s is not supported by the fused photometric kernel" % flag)
+
+        if self.opt.fine_tune:
+            m = import_depth_model((1024, 320), pre_model_path=self.opt.load_weights_folder)
+            self.models["encoder"], self.models["depth"] = m.encoder, m.decoder
+        else:
+            self.models["encoder"] = networks.ResnetEncoder(self.opt.num_layers, self.opt.weights_init == "pretrained")
+            self.models["depth"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales)
+        self.models["encoder"].to(self.device)
+        self.models["depth"].to(self.device)
+        self.parameters_to_train += list(self.models["encoder"].parameters())
+        self.parameters_to_train += list(self.models["depth"].parameters())
+        self.models["DepthModelWrapper"] = DepthModelWrapper(self.models["encoder"], self.models["depth"]).to(self.device)
+
+        if self.opt.adv_train and self.opt.supervised_adv:
+            self.gt_model = import_depth_model((1024, 320)).to(self.device)   # frozen teacher, trainer.py:93-95
+            for p in self.gt_model.parameters():
+                p.requires_grad_(False)
+            self.gt_model.eval()
+        if self.opt.contrastive_learning:
+            self.models["contrastive_learning"] = SimSiam().to(self.device)
+            self.parameters_to_train += list(self.models["contrastive_learning"].parameters())
+
+        if self.world_size > 1:
+            broadcast_parameters(list(self.models.values()) + ([self.gt_model] if hasattr(self, "gt_model") else []))
+
+        self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate)
+        self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
+        # the encoder's ImageNet ``fc`` is in parameters_to_train (trainer.py:85) but never gets a gradient:
+        # it is left out of the all-reduce bucket
+        fc_ids = {id(p) for p in self.models["encoder"].encoder.fc.parameters()}
+        self.bucket = GradBucket([p for p in self.parameters_to_train if id(p) not in fc_ids], self.world_size)
+
+        if self.opt.load_weights_folder is not None and not self.opt.fine_tune:
+            self.load_model()
+
+        # data
+        if self.opt.dataset != "synthetic":
+            raise NotImplementedError("KITTI file loaders are outside the hot-path scope (SURVEY.md section 2, rows "
+                                      "12-13); use --dataset synthetic")
+        self.dataset = SyntheticKITTIDataset(self.opt.height, self.opt.width, self.opt.frame_ids, 4,
+                                             self.opt.synthetic_len, self.device, seed=self.opt.seed + rank)
+        self.num_total_steps = len(self.dataset) // self.opt.batch_size * self.opt.num_epochs
+
+        if self.opt.adv_train:
+            obj_tensor, mask_tensor = make_object(self.device)
+            common = {"batch_size": self.opt.atk_batch_size,
+                      "load_ben_color": self.opt.supervised_adv or self.opt.contrastive_learning,
+                      "color_aug": self.opt.contrastive_learning, "half_no_synthesis": self.opt.half_no_synthesis}
+            if self.opt.norm_type == "l_inf":   # MD2/trainer.py:199-211
+                args = dict(common, norm_type="l_inf", epsilon=self.opt.atk_eps, alpha=self.opt.atk_alpha,
+                            step=self.opt.atk_steps, epoch=20, adv_type='object')
+            else:                               # MD2/trainer.py:212-223
+                args = dict(common, norm_type="l_0", step=self.opt.atk_steps, adam_lr=self.opt.atk_adam_lr,
+                            mask_wt=self.opt.atk_mask_wt, l0_thresh=self.opt.atk_l0_thresh)
+            self.dataset.set_adv_train(self.models["DepthModelWrapper"], obj_tensor, mask_tensor, args)
+            self.adv_args = args
+            self.dataset.update_adv_obj(self.dataset.next_scenes(args["batch_size"]))   # trainer.py:231-233
+
+        if not self.opt.no_ssim:
+            self.ssim = SSIM().to(self.device)
+        self.backproject_depth, self.project_3d = {}, {}
+        for scale in self.opt.scales:
+            h, w = self.opt.height // (2 ** scale), self.opt.width // (2 ** scale)
+            self.backproject_depth[scale] = BackprojectDepth(self.opt.batch_size, h, w).to(self.device)
+            self.project_3d[scale] = Project3D(self.opt.batch_size, h, w).to(self.device)
+        self.timings = {}
+        if self.rank == 0:
+            self.save_opts()
+
+    # ------------------------------------------------------------------ mode switches
+    def set_train(self):
+        for m in self.models.values():
+            m.train()
+
+    def set_eval(self):
+        for m in self.models.values():
+            m.eval()
+
+    # ------------------------------------------------------------------ training loop
+    def train(self):
+        self.epoch = 0
+        self.step = 0
+        self.start_time = time.time()
+        for self.epoch in range(self.opt.num_epochs):
+            self.run_epoch()
+            if (self.epoch + 1) % self.opt.save_frequency == 0 and self.rank == 0:
+                self.save_model()
+            if self.opt.max_steps and self.step >= self.opt.max_steps:
+                break
+
+    def train_step(self):
+        """One iteration of run_epoch's loop body (MD2/trainer.py:297-315): attack -> forward -> loss ->
+        backward -> gradient all-reduce -> Adam.  Returns the losses dict."""
+        overlap = self.world_size > 1 and not self.opt.sync_attack
+        if overlap:
+            # the previous iteration left its all-reduce in flight: enqueue this iteration's attack first
+            # (it reads weights one optimiser step old), then apply the averaged gradients
+            if self.opt.adv_train:
+                self.dataset.update_adv_obj(self.dataset.next_scenes(self.adv_args["batch_size"]))
+            self._apply_pending_update()
+        else:
+            self._apply_pending_update()
+            if self.opt.adv_train:
+                self.dataset.update_adv_obj(self.dataset.next_scenes(self.adv_args["batch_size"]))
+        inputs = self.dataset.next_batch(self.opt.batch_size)
+        outputs, losses = self.process_batch(inputs)
+        self.bucket.zero()                       # model_optimizer.zero_grad()
+        losses["loss"].backward()
+        self.bucket.start_all_reduce()
+        self._pending = True
+        if not overlap:
+            self._apply_pending_update()
+        return losses
+
+    def _apply_pending_update(self):
+        if getattr(self, "_pending", False):
+            self.bucket.finish_all_reduce()
+            self.model_optimizer.step()
+            self._pending = False
+
+    def run_epoch(self):
+        self.set_train()
+        steps = len(self.dataset) // self.opt.batch_size
+        for batch_idx in range(steps):
+            before_op_time = time.time()
+            losses = self.train_step()
+            early_phase = batch_idx % self.opt.log_frequency == 0 and self.step < 2000
+            late_phase = self.step % 2000 == 0
+            if (early_phase or late_phase) and self.rank == 0:
+                self.log_time(batch_idx, time.time() - before_op_time, losses["loss"].detach().cpu())
+            self.step += 1
+            if self.opt.max_steps and self.step >= self.opt.max_steps:
+                break
+        self._apply_pending_update()
+        self.model_lr_scheduler.step()
+
+    def process_batch(self, inputs):
+        """Pass a minibatch through the network and generate images and losses (MD2/trainer.py:335-375)."""
+        for key, ipt in inputs.items():
+            inputs[key] = ipt.to(self.device)
+        features = self.models["encoder"](inputs["color_aug", 0, 0])
+        outputs = self.models["depth"](features)
+        outputs["middle_features_aug"] = features
+        if self.opt.contrastive_learning:
+            outputs["middle_features_ben"] = self.models["encoder"](inputs["color_ben", 0, 0])
+        self.generate_images_pred(inputs, outputs)
+        losses = self.compute_losses(inputs, outputs)
+        return outputs, losses
+
+    # ------------------------------------------------------------------ the hot path
+    def _frame_T(self, inputs, outputs, frame_id):
+        return inputs["stereo_T"] if frame_id == "s" else outputs[("cam_T_cam", 0, frame_id)]
+
+    def generate_images_pred(self, inputs, outputs):
+        """Generate the warped (reprojected) color images for a minibatch.
+
+        The fused loss kernel re-derives the warp on chip and never reads these tensors, so by default only
+        the free aliases (``color_identity``) are written; --materialize_warps also writes
+        ("depth",0,s), ("sample",f,s), ("color",f,s) through the stand-alone warp kernel (differentiable)."""
+        for scale in self.opt.scales:
+            for frame_id in self.opt.frame_ids[1:]:
+                if self.opt.materialize_warps:
+                    depth, sample, color = ops.warp_view(
+                        inputs[("color", frame_id, 0)], outputs[("disp", scale)], inputs[("K", 0)],
+                        inputs[("inv_K", 0)], self._frame_T(inputs, outputs, frame_id), self.opt.height,
+                        self.opt.width, self.opt.min_depth, self.opt.max_depth)
+                    outputs[("depth", 0, scale)] = depth
+                    outputs[("sample", frame_id, scale)] = sample
+                    outputs[("color", frame_id, scale)] = color
+                if not self.opt.disable_automasking:
+                    outputs[("color_identity", frame_id, scale)] = inputs[("color", frame_id, 0)]
+
+    def compute_reprojection_loss(self, pred, target):
+        """Reprojection loss between a batch of predicted and target images (stand-alone surface)."""
+        l1_loss = torch.abs(target - pred).mean(1, True)
+        if self.opt.no_ssim:
+            return l1_loss
+        return 0.85 * self.ssim(pred, target).mean(1, True) + 0.15 * l1_loss
+
+    def compute_losses(self, inputs, outputs):
+        """Compute the reprojection and smoothness losses for a minibatch."""
+        losses = {}
+        total_loss = 0
+        if self.opt.adv_train and self.opt.supervised_adv:
+            disp = outputs[("disp", 0)]
+            with torch.no_grad():
+                disp_gt = self.gt_model(inputs[("color_ben", 0, 0)])
+            loss_sup = ops.masked_sq_mean(disp_gt - disp, None)     # MSELoss(disp_gt, disp), trainer.py:559
+            losses["sup_loss"] = loss_sup
+            total_loss = total_loss + loss_sup
+        if self.opt.adv_train and self.opt.contrastive_learning:
+            wt = 1 if self.opt.loss_variant == "md2" else 0.1       # MD2/trainer.py:571 vs DH/trainer.py:617
+            contras_loss = self.models['contrastive_learning'](outputs["middle_features_aug"],
+                                                               outputs["middle_features_ben"]) * wt
+            losses["contras_loss"] = contras_loss
+            total_loss = total_loss + contras_loss
+        if self.opt.adv_train and self.opt.no_original_train:
+            losses["loss"] = total_loss
+            return losses
+
+        frames = self.opt.frame_ids[1:]
+        out = ops.photometric_smooth_loss(
+            inputs[("color", 0, 0)], [inputs[("color", f, 0)] for f in frames],
+            [self._frame_T(inputs, outputs, f) for f in frames], inputs[("K", 0)], inputs[("inv_K", 0)],
+            [outputs[("disp", s)] for s in self.opt.scales], [inputs[("color", 0, s)] for s in self.opt.scales],
+            min_depth=self.opt.min_depth, max_depth=self.opt.max_depth, variant=self.opt.loss_variant,
+            automask=not self.opt.disable_automasking, no_ssim=self.opt.no_ssim,
+            smooth_wt=self.opt.disparity_smoothness, noise="philox")
+        for i, scale in enumerate(self.opt.scales):
+            losses["loss/{}".format(scale)] = out.fin[N.FIN_LOSS_S + i]
+            if self.opt.loss_variant == "dh":
+                losses["reproj_loss/{}".format(scale)] = out.fin[N.FIN_REPROJ_S + i]
+            if not self.opt.disable_automasking:
+                sel = out.sel[i]
+                if len(frames) > 1 or self.opt.loss_variant == "dh":
+                    sel = (sel > 0).float()
+                    if self.opt.loss_variant == "dh":
+                        sel = 1 - sel                                 # DH/trainer.py:703
+                outputs["identity_selection/{}".format(scale)] = sel
+        total_loss = total_loss + out.fin[N.FIN_LOSS]
+        losses["loss"] = total_loss
+        return losses
+
+    # ------------------------------------------------------------------ logging / checkpoints
+    def log_time(self, batch_idx, duration, loss):
+        samples_per_sec = self.opt.batch_size * self.world_size / duration
+        time_sofar = time.time() - self.start_time if hasattr(self, "start_time") else 0.0
+        print("epoch {:>3} | batch {:>6} | examples/s: {:5.1f} | loss: {:.5f} | time elapsed: {:.0f}s".format(
+            getattr(self, "epoch", 0), batch_idx, samples_per_sec, float(loss), time_sofar), flush=True)
+
+    def save_opts(self):
+        models_dir = os.path.join(self.log_path, "models")
+        os.makedirs(models_dir, exist_ok=True)
+        with open(os.path.join(models_dir, 'opt.json'), 'w') as f:
+            json.dump({k: v for k, v in self.opt.__dict__.items()}, f, indent=2, default=str)
+
+    def save_model(self):
+        """weights_{epoch}/{model}.pth state_dicts (+ height/width/use_stereo in the encoder) and adam.pth --
+        the reference's on-disk format (MD2/trainer.py:765-785), written by rank 0 only."""
+        save_folder = os.path.join(self.log_path, "models", "weights_{}".format(self.epoch))
+        os.makedirs(save_folder, exist_ok=True)
+        for model_name, model in self.models.items():
+            to_save = model.state_dict()
+            if model_name == 'encoder':
+                to_save['height'] = self.opt.height
+                to_save['width'] = self.opt.width
+                to_save['use_stereo'] = self.opt.use_stereo
+            torch.save(to_save, os.path.join(save_folder, "{}.pth".format(model_name)))
+        torch.save(self.model_optimizer.state_dict(), os.path.join(save_folder, "adam.pth"))
+
+    def load_model(self):
+        """MD2/trainer.py:787-812: load the listed models (filtering unknown keys) and the Adam state."""
+        folder = os.path.expanduser(self.opt.load_weights_folder)
+        assert os.path.isdir(folder), "Cannot find folder {}".format(folder)
+        for n in self.opt.models_to_load:
+            path = os.path.join(folder, "{}.pth".format(n))
+            if n not in self.models or not os.path.isfile(path):
+                continue
+            model_dict = self.models[n].state_dict()
+            pretrained = torch.load(path, map_location="cpu")
+            model_dict.update({k: v for k, v in pretrained.items() if k in model_dict})
+            self.models[n].load_state_dict(model_dict)
+        adam = os.path.join(folder, "adam.pth")
+        if os.path.isfile(adam):
+            self.model_optimizer.load_state_dict(torch.load(adam, map_location="cpu"))

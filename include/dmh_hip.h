@@ -145,6 +145,9 @@ int dmh_loss_finalize(const float* photo_partials, const float* smooth_partials,
  * coeffs [N,8]: torchvision-0.8.2 perspective coefficients per sample (host computes them from
  * the integer pixel quads, physicalTrans.py:62-81).  scene_bstride = 0 broadcasts one scene.
  * ---------------------------------------------------------------------------------- */
+#define DMH_PASTE_COMPOSITE 0 /* adv = resize(scene*(1-m) + obj*m), mask_out = resize(m)   phy_obj_atk.py:88-90 */
+#define DMH_PASTE_WARP_ONLY 1 /* adv = resize(obj), mask_out = resize(m); scene ignored    physicalTrans.py:156-165 */
+
 typedef struct dmh_paste_args {
     const float* scene; /* [N or 1,3,SH,SW] */
     int64_t scene_bstride;
@@ -153,6 +156,7 @@ typedef struct dmh_paste_args {
     const float* coeffs; /* [N,8] */
     int N, SH, SW, PH, PW, OH, OW;
     int l_pad, t_pad; /* physicalTrans.py:110-113 */
+    int mode;         /* DMH_PASTE_COMPOSITE or DMH_PASTE_WARP_ONLY */
 } dmh_paste_args;
 
 /* adv [N,3,OH,OW], mask_out [N,1,OH,OW] (either may be NULL) */
