@@ -1,0 +1,106 @@
+"""Host-side logic of the product (no GPU): geometry, coefficient solve, RNG draw order, options, isolation."""
+import os
+import random
+import re
+
+import numpy as np
+import torch
+
+from depthmodelhardening_amd import my_utils
+from depthmodelhardening_amd.options import MonodepthOptions
+from depthmodelhardening_amd.physicalTrans import PhysicalTrans, get_perspective_coeffs, read_calib_P2
+from oracle import attack_ref, synth, tv082
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_quads_match_reference_golden(golden):
+    g = golden("geometry")
+    obj, mask = synth.make_object()
+    pt = PhysicalTrans(obj, mask, {"path": None}, (1, 3, 375, 1242), dist_range=my_utils.train_dist_range)
+    assert pt.calib_source == "builtin:003086"
+    assert np.array_equal(np.array(pt.pos_obj_img_start, dtype=np.int32), g["start"])
+    adv_K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    adv_K[0, :] *= 1242
+    adv_K[1, :] *= 375
+    for i, z0 in enumerate(pt.dist_range):
+        for j, al in enumerate(pt.angle_range):
+            assert np.array_equal(pt.objPosOnImage(z0, al), g["quads"][i, j])
+            assert np.array_equal(pt.objPosOnImage(z0, al, adv_K), g["quads_K"][i, j])
+
+
+def test_calib_file_and_coeffs(tmp_path):
+    p = tmp_path / "003086.txt"
+    p.write_text(synth.KITTI_CALIB_TEXT)
+    assert np.allclose(read_calib_P2(str(p)), my_utils.KITTI_003086_P2)
+    obj, mask = synth.make_object()
+    pt = PhysicalTrans(obj, mask, {"path": str(p)}, (1, 3, 375, 1242))
+    assert pt.calib_source == str(p)
+    ref = attack_ref.PhysicalTransRef(obj, mask)
+    T = np.eye(4, dtype=np.float32)
+    T[0, 3] = -0.54
+    c = pt.coeffs_for([5.0, 9.4], [-30, 15])
+    for i, (z0, al) in enumerate([(5.0, -30), (9.4, 15)]):
+        want = tv082.get_perspective_coeffs([list(map(float, q)) for q in ref.pos_obj_img_start],
+                                            [list(map(float, q)) for q in ref.obj_pos_on_image(z0, al)])
+        assert np.allclose(c[i], np.array(want, dtype=np.float32), rtol=0, atol=0)
+    assert np.array_equal(pt._objPosOnImage_w_trans(T, 6.0, 10), ref.obj_pos_on_image(6.0, 10, None, T))
+    # identity quad -> identity homography
+    start = [[float(v) for v in q] for q in pt.pos_obj_img_start]
+    assert np.allclose(get_perspective_coeffs(start, start), [1, 0, 0, 0, 1, 0, 0, 0], atol=1e-6)
+    try:
+        PhysicalTrans(obj, mask, {"path": None}, (1, 3, 320, 1024))
+        assert False
+    except AssertionError:
+        pass
+
+
+def test_sample_draw_order_matches_reference_semantics():
+    obj, mask = synth.make_object()
+    pt = PhysicalTrans(obj, mask, {"path": None}, (1, 3, 375, 1242), dist_range=my_utils.train_dist_range)
+    random.seed(3)
+    z0, al = pt.draw_samples(12)
+    random.seed(3)
+    assert z0 == random.sample(pt.dist_range, 12) and al == random.sample(pt.angle_range, 12)
+    assert len(set(al)) == 12      # without replacement: at most 13 samples (SURVEY a-10)
+    try:
+        pt.draw_samples(14)
+        assert False, "14 angles cannot be drawn without replacement"
+    except ValueError:
+        pass
+
+
+def test_options_keep_reference_flags_and_defaults():
+    o = MonodepthOptions().parse([])
+    assert (o.height, o.width, o.batch_size, o.learning_rate, o.num_epochs) == (192, 640, 12, 1e-4, 20)
+    assert o.frame_ids == [0, -1, 1] and o.scales == [0, 1, 2, 3] and o.disparity_smoothness == 1e-3
+    assert (o.min_depth, o.max_depth, o.num_workers, o.log_frequency) == (0.1, 100.0, 12, 250)
+    assert (o.atk_steps, o.atk_eps, o.atk_alpha, o.atk_batch_size) == (10, 0.1, 0.02, 12)   # MD2/trainer.py:199-211
+    assert (o.atk_adam_lr, o.atk_mask_wt, o.atk_l0_thresh) == (0.5, 0.06, 0.1)               # MD2/trainer.py:212-223
+    p = MonodepthOptions().parse("--frame_ids 0 --use_stereo --split eigen_full --png --width 1024 --height 320 "
+                                 "--learning_rate 1e-5 --adv_train --norm_type l_0 --contrastive_learning "
+                                 "--supervised_adv --batch_size 32 --num_workers 8".split())
+    assert p.adv_train and p.norm_type == "l_0" and p.contrastive_learning and p.supervised_adv and p.width == 1024
+
+
+def test_constants():
+    assert (my_utils.ori_H, my_utils.ori_W) == (375, 1242)
+    assert len(my_utils.train_dist_range) == 25 and abs(my_utils.train_dist_range[-1] - 9.8) < 1e-9
+
+
+def test_cpu_tensors_are_rejected_not_silently_computed():
+    from depthmodelhardening_amd import ops
+    x = torch.rand(4)
+    try:
+        ops.pgd_linf_step(x, x, x, 0.1, 0.1)
+        assert False
+    except RuntimeError as e:
+        assert "no CPU path" in str(e)
+
+
+def test_product_never_imports_the_oracle():
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b", re.M)
+    for root, _, files in os.walk(os.path.join(REPO, "depthmodelhardening_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                assert not pat.search(open(os.path.join(root, f)).read()), f
