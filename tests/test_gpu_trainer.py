@@ -78,7 +78,8 @@ def test_adversarial_train_steps(tmp_path, norm_type):
                                           "encoder.pth"]
     enc = torch.load(os.path.join(folder, "encoder.pth"))
     assert enc["height"] == 64 and enc["width"] == 192 and enc["use_stereo"] is True
-    tr2 = _trainer(tmp_path, ["--load_weights_folder", folder])
+    tr2 = _trainer(tmp_path, ["--adv_train", "--norm_type", norm_type, "--supervised_adv", "--contrastive_learning",
+                              "--load_weights_folder", folder])
     for a, b in zip(tr.models["depth"].parameters(), tr2.models["depth"].parameters()):
         assert torch.equal(a, b)
 
