@@ -91,12 +91,16 @@ struct Proj {
     float depth;
 };
 
-// disp_to_depth -> BackprojectDepth -> Project3D -> grid normalise/un-normalise, op order of the reference
+// disp_to_depth -> BackprojectDepth -> Project3D -> grid normalise/un-normalise, op order of the reference.
+// FAST (the fused loss kernels): reciprocals by rcp + one Newton step instead of IEEE divides, and the sampling
+// coordinate is the projected pixel itself instead of the reference's x/(W-1) -> (.-0.5)*2 -> ((.+1)/2)*(W-1)
+// round trip (an identity up to ~1.5 ulp of the coordinate, 6e-5 px at x~500, which both sides carry anyway).
+template <bool FAST>
 __device__ __forceinline__ Proj project(const Cam& c, float disp, int x, int y, int H, int W, float min_disp,
                                         float dmul) {
     Proj p;
     const float sd = min_disp + dmul * disp;
-    p.depth = 1.0f / sd;
+    p.depth = FAST ? fast_rcp(sd) : 1.0f / sd;
     const float fx = (float)x, fy = (float)y;
     const float rx = c.ik[0] * fx + c.ik[1] * fy + c.ik[2];
     const float ry = c.ik[3] * fx + c.ik[4] * fy + c.ik[5];
@@ -109,12 +113,20 @@ __device__ __forceinline__ Proj project(const Cam& c, float disp, int x, int y, 
     p.ay = c.P[4] * rx + c.P[5] * ry + c.P[6] * rz;
     p.az = c.P[8] * rx + c.P[9] * ry + c.P[10] * rz;
     p.den = Z + 1e-7f;
-    p.px = X / p.den;
-    p.py = Y / p.den;
-    const float gx = (p.px / (float)(W - 1) - 0.5f) * 2.f;  // MD2/layers.py:195-197
-    const float gy = (p.py / (float)(H - 1) - 0.5f) * 2.f;
-    p.ix = ((gx + 1.f) / 2.f) * (float)(W - 1);             // grid_sampler_unnormalize, align_corners=True
-    p.iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    if (FAST) {
+        const float rden = fast_rcp(p.den);
+        p.px = X * rden;
+        p.py = Y * rden;
+        p.ix = p.px;
+        p.iy = p.py;
+    } else {
+        p.px = X / p.den;
+        p.py = Y / p.den;
+        const float gx = (p.px / (float)(W - 1) - 0.5f) * 2.f;  // MD2/layers.py:195-197
+        const float gy = (p.py / (float)(H - 1) - 0.5f) * 2.f;
+        p.ix = ((gx + 1.f) / 2.f) * (float)(W - 1);             // grid_sampler_unnormalize, align_corners=True
+        p.iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
+    }
     return p;
 }
 
@@ -167,7 +179,7 @@ __device__ __forceinline__ SsimTerms ssim_terms(float sx, float sy, float sxx, f
 
 __device__ __forceinline__ float ssim_val(float sx, float sy, float sxx, float syy, float sxy) {
     const SsimTerms t = ssim_terms(sx, sy, sxx, syy, sxy);
-    const float r = __fdividef(t.A1 * t.A2, t.B1 * t.B2);
+    const float r = (t.A1 * t.A2) * __builtin_amdgcn_rcpf(t.B1 * t.B2);  // 1-ulp reciprocal: << the SSIM conditioning noise
     return fminf(fmaxf((1.f - r) * 0.5f, 0.f), 1.f);
 }
 
@@ -203,7 +215,7 @@ __device__ __forceinline__ void reproj4(const float* sp, const float* st, int ro
     }
 #pragma unroll
     for (int k = 0; k < PXT; ++k)
-        out[k] = no_ssim ? l1[k] / 3.f : 0.85f * (ss[k] / 3.f) + 0.15f * (l1[k] / 3.f);
+        out[k] = no_ssim ? l1[k] * (1.f / 3.f) : (0.85f / 3.f) * ss[k] + (0.15f / 3.f) * l1[k];
 }
 
 // Copy an image tile with halo HALO into LDS planes [3][HH][LD]; out-of-image slots use the
@@ -230,7 +242,7 @@ __device__ __forceinline__ void warp_tile(float* s, const float* __restrict__ sr
         const int r = i / HW_, col = i - r * HW_;
         const int gy = reflect_idx(y0 - HALO + r, H), gx = reflect_idx(x0 - HALO + col, W);
         const float d = disp_at(disp, Hs, Ws, rh, rw, same, gy, gx);
-        const Proj p = project(cam, d, gx, gy, H, W, min_disp, dmul);
+        const Proj p = project<true>(cam, d, gx, gy, H, W, min_disp, dmul);
         const Tap t = make_tap(p.ix, p.iy, H, W);
         s[0 * PLANE + r * LD + col] = tap_sample(src, t);
         s[1 * PLANE + r * LD + col] = tap_sample(src + H * W, t);
@@ -289,7 +301,7 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
         }
     }
 
-    const Philox rng(a.seed);
+    const Philox<7> rng(a.seed);
     for (int s = 0; s < a.num_scales; ++s) {
         float best[PXT];
         int bestf[PXT];
@@ -332,9 +344,11 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                     if (a.noise_mode == DMH_NOISE_TENSOR) {
                         nz = a.noise[s][(((size_t)b * nf + fi) * H + qy) * W + qx];
                     } else if (a.noise_mode == DMH_NOISE_PHILOX) {
-                        const uint64_t ctr = a.offset + ((((uint64_t)s * a.B + b) * nf + fi) * H + qy) * W + qx;
+                        // one Philox call serves a vertical pixel pair: words (x,y) -> even row, (z,w) -> odd row
+                        const uint64_t ctr =
+                            a.offset + ((((uint64_t)s * a.B + b) * nf + fi) * H + (qy0 + (i & ~1))) * W + qx;
                         const uint4 r = rng(ctr, 0x646d68ull);
-                        nz = normal_from_bits(r.x, r.y) * 0.00001f;
+                        nz = ((i & 1) ? normal_from_bits(r.z, r.w) : normal_from_bits(r.x, r.y)) * 0.00001f;
                     }
                     // MD2: noise per identity channel, then min over channels (trainer.py:642-654);
                     // DH : min over frames first, one noise plane (DH/trainer.py:671,687-690)
@@ -366,10 +380,11 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
 
 // ------------------------------------------------------------------------------------------------ backward
 // gradient of one warped pixel back to the up-sampled disparity, given d loss / d warped (3 channels)
+template <bool FAST>
 __device__ __forceinline__ float warp_pixel_bwd(const float* __restrict__ src, const Cam& cam, float d, int x, int y,
                                                 int H, int W, float min_disp, float dmul, float g0, float g1,
                                                 float g2) {
-    const Proj p = project(cam, d, x, y, H, W, min_disp, dmul);
+    const Proj p = project<FAST>(cam, d, x, y, H, W, min_disp, dmul);
     const Tap t = make_tap(p.ix, p.iy, H, W);
     float gix = 0.f, giy = 0.f;
     const float gc[3] = {g0, g1, g2};
@@ -383,7 +398,7 @@ __device__ __forceinline__ float warp_pixel_bwd(const float* __restrict__ src, c
     // clip_coordinates_set_grad: zero outside the open interval (0, size-1)
     if (!(p.ix > 0.f && p.ix < (float)(W - 1))) gix = 0.f;
     if (!(p.iy > 0.f && p.iy < (float)(H - 1))) giy = 0.f;
-    const float g_depth = (gix * (p.ax - p.px * p.az) + giy * (p.ay - p.py * p.az)) / p.den;
+    const float g_depth = (gix * (p.ax - p.px * p.az) + giy * (p.ay - p.py * p.az)) * (FAST ? fast_rcp(p.den) : 1.0f / p.den);
     return g_depth * (-(p.depth * p.depth)) * dmul;
 }
 
@@ -452,7 +467,7 @@ __global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArg
                         // d v/d x_q = a0 + ay*y_q + ax*x_q with v = clamp((1 - n/d)/2); in the 81-scaled terms
                         //   a0 = -G (s_y (A2-A1) - r s_x (B2-B1)) / d',  ay = -9 G A1 / d',  ax = 9 G r B1 / d'
                         const SsimTerms t = ssim_terms(sx, sy, sxx, syy, sxy);
-                        const float invd = 1.0f / (t.B1 * t.B2);
+                        const float invd = fast_rcp(t.B1 * t.B2);
                         const float rr_ = (t.A1 * t.A2) * invd;
                         const float v = (1.f - rr_) * 0.5f;
                         if (v >= 0.f && v <= 1.f) {  // clamp passes gradient on the closed interval
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArg
                 const int qy = qy0 + i;
                 if (qx < W && qy < H) {
                     const float d = disp_at(disp, a.Hs[s], a.Ws[s], rh, rw, same, qy, qx);
-                    acc[i] += warp_pixel_bwd(src, s_cam[f], d, qx, qy, H, W, k.min_disp, k.dmul, gw[0][i], gw[1][i],
+                    acc[i] += warp_pixel_bwd<true>(src, s_cam[f], d, qx, qy, H, W, k.min_disp, k.dmul, gw[0][i], gw[1][i],
                                              gw[2][i]);
                 }
             }
@@ -565,7 +580,7 @@ __global__ __launch_bounds__(NT) void warp_view_fwd_kernel(const float* __restri
     const bool same = (Hs == H && Ws == W);
     const float d = disp_at(disp_all + (size_t)b * Hs * Ws, Hs, Ws, (float)Hs / (float)H, (float)Ws / (float)W, same,
                             y, x);
-    const Proj p = project(s_cam, d, x, y, H, W, min_disp, dmul);
+    const Proj p = project<false>(s_cam, d, x, y, H, W, min_disp, dmul);
     const size_t pix = (size_t)b * H * W + idx;
     if (depth) depth[pix] = p.depth;
     if (sample) {
@@ -606,7 +621,7 @@ __global__ __launch_bounds__(NT) void warp_view_bwd_kernel(const float* __restri
         g1 = grad_color[((size_t)b * 3 + 1) * hw + idx];
         g2 = grad_color[((size_t)b * 3 + 2) * hw + idx];
     }
-    float g = warp_pixel_bwd(source + (size_t)b * 3 * hw, s_cam, d, x, y, H, W, min_disp, dmul, g0, g1, g2);
+    float g = warp_pixel_bwd<false>(source + (size_t)b * 3 * hw, s_cam, d, x, y, H, W, min_disp, dmul, g0, g1, g2);
     if (grad_depth) {
         const float sd = min_disp + dmul * d;
         g += grad_depth[(size_t)b * hw + idx] * (-1.0f / (sd * sd)) * dmul;
