@@ -99,4 +99,14 @@ __device__ __forceinline__ float normal_from_bits(uint32_t u0, uint32_t u1) {
     return sqrtf(-2.0f * __logf(a)) * __cosf(6.283185307179586f * b);
 }
 
+// two uniform 32-bit words -> two independent N(0,1) samples (both Box-Muller branches)
+__device__ __forceinline__ float2 normal_pair_from_bits(uint32_t u0, uint32_t u1) {
+    const float a = ((float)u0 + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
+    const float b = (float)u1 * 2.3283064365386963e-10f;           // [0,1)
+    const float rad = sqrtf(-2.0f * __logf(a));
+    float sn, cs;
+    __sincosf(6.283185307179586f * b, &sn, &cs);
+    return make_float2(rad * cs, rad * sn);
+}
+
 }  // namespace dmh

@@ -41,7 +41,17 @@ constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 struct Cam {
     float ik[9];   // inv_K[:3,:3]           MD2/layers.py:164
     float P[12];   // (K @ T)[:3,:]          MD2/layers.py:188
+    float A[9];    // P[:, :3] @ inv_K[:3,:3]: d(X,Y,Z)/d depth is affine in the pixel coordinates (fast path)
 };
+
+// second stage of load_cam (after a barrier): A = P[:, :3] @ ik
+__device__ __forceinline__ void compose_cam(Cam* cam, int t) {
+    if (t < 9) {
+        const int i = t / 3, j = t % 3;
+        cam->A[t] = cam->P[i * 4 + 0] * cam->ik[0 * 3 + j] + cam->P[i * 4 + 1] * cam->ik[1 * 3 + j] +
+                    cam->P[i * 4 + 2] * cam->ik[2 * 3 + j];
+    }
+}
 
 struct KArgs {
     dmh_photo_args a;
@@ -102,6 +112,18 @@ __device__ __forceinline__ Proj project(const Cam& c, float disp, int x, int y, 
     const float sd = min_disp + dmul * disp;
     p.depth = FAST ? fast_rcp(sd) : 1.0f / sd;
     const float fx = (float)x, fy = (float)y;
+    if (FAST) {
+        p.ax = c.A[0] * fx + c.A[1] * fy + c.A[2];
+        p.ay = c.A[3] * fx + c.A[4] * fy + c.A[5];
+        p.az = c.A[6] * fx + c.A[7] * fy + c.A[8];
+        p.den = (p.depth * p.az + c.P[11]) + 1e-7f;
+        const float rden = fast_rcp(p.den);
+        p.px = (p.depth * p.ax + c.P[3]) * rden;
+        p.py = (p.depth * p.ay + c.P[7]) * rden;
+        p.ix = p.px;
+        p.iy = p.py;
+        return p;
+    }
     const float rx = c.ik[0] * fx + c.ik[1] * fy + c.ik[2];
     const float ry = c.ik[3] * fx + c.ik[4] * fy + c.ik[5];
     const float rz = c.ik[6] * fx + c.ik[7] * fy + c.ik[8];
@@ -113,25 +135,17 @@ __device__ __forceinline__ Proj project(const Cam& c, float disp, int x, int y, 
     p.ay = c.P[4] * rx + c.P[5] * ry + c.P[6] * rz;
     p.az = c.P[8] * rx + c.P[9] * ry + c.P[10] * rz;
     p.den = Z + 1e-7f;
-    if (FAST) {
-        const float rden = fast_rcp(p.den);
-        p.px = X * rden;
-        p.py = Y * rden;
-        p.ix = p.px;
-        p.iy = p.py;
-    } else {
-        p.px = X / p.den;
-        p.py = Y / p.den;
-        const float gx = (p.px / (float)(W - 1) - 0.5f) * 2.f;  // MD2/layers.py:195-197
-        const float gy = (p.py / (float)(H - 1) - 0.5f) * 2.f;
-        p.ix = ((gx + 1.f) / 2.f) * (float)(W - 1);             // grid_sampler_unnormalize, align_corners=True
-        p.iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
-    }
+    p.px = X / p.den;
+    p.py = Y / p.den;
+    const float gx = (p.px / (float)(W - 1) - 0.5f) * 2.f;  // MD2/layers.py:195-197
+    const float gy = (p.py / (float)(H - 1) - 0.5f) * 2.f;
+    p.ix = ((gx + 1.f) / 2.f) * (float)(W - 1);             // grid_sampler_unnormalize, align_corners=True
+    p.iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
     return p;
 }
 
 struct Tap {
-    int o00, o01, o10, o11;
+    unsigned o00, o01, o10, o11;  // unsigned 32-bit offsets: scalar base + 32-bit VGPR offset addressing
     float w00, w01, w10, w11, fx, fy;
 };
 
@@ -150,10 +164,10 @@ __device__ __forceinline__ Tap make_tap(float ix, float iy, int H, int W) {
     t.w01 = t.fx * gy;
     t.w10 = gx * t.fy;
     t.w11 = t.fx * t.fy;
-    t.o00 = y0 * W + x0;
-    t.o01 = y0 * W + x1;
-    t.o10 = y1 * W + x0;
-    t.o11 = y1 * W + x1;
+    t.o00 = (unsigned)(y0 * W + x0);
+    t.o01 = (unsigned)(y0 * W + x1);
+    t.o10 = (unsigned)(y1 * W + x0);
+    t.o11 = (unsigned)(y1 * W + x1);
     return t;
 }
 
@@ -282,6 +296,8 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
 
     if (tid < 21 * F) load_cam(&s_cam[tid / 21], a.K, a.inv_K, a.T[tid / 21], b, tid % 21);
     load_tile<1, F_HW, F_HH, F_LD, F_PLANE>(s_tgt, a.target + img_off, H, W, x0, y0);
+    __syncthreads();
+    if (tid < 9 * F) compose_cam(&s_cam[tid / 9], tid % 9);
 
     const int qx = x0 + tx;
     const int qy0 = y0 + tg * PXT;
@@ -344,11 +360,11 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                     if (a.noise_mode == DMH_NOISE_TENSOR) {
                         nz = a.noise[s][(((size_t)b * nf + fi) * H + qy) * W + qx];
                     } else if (a.noise_mode == DMH_NOISE_PHILOX) {
-                        // one Philox call serves a vertical pixel pair: words (x,y) -> even row, (z,w) -> odd row
-                        const uint64_t ctr =
-                            a.offset + ((((uint64_t)s * a.B + b) * nf + fi) * H + (qy0 + (i & ~1))) * W + qx;
+                        // one Philox call serves the thread's 4 pixels: two Box-Muller pairs (cos, sin) each
+                        const uint64_t ctr = a.offset + ((((uint64_t)s * a.B + b) * nf + fi) * H + qy0) * W + qx;
                         const uint4 r = rng(ctr, 0x646d68ull);
-                        nz = ((i & 1) ? normal_from_bits(r.z, r.w) : normal_from_bits(r.x, r.y)) * 0.00001f;
+                        const float2 n01 = normal_pair_from_bits(r.x, r.y), n23 = normal_pair_from_bits(r.z, r.w);
+                        nz = (i == 0 ? n01.x : i == 1 ? n01.y : i == 2 ? n23.x : n23.y) * 0.00001f;
                     }
                     // MD2: noise per identity channel, then min over channels (trainer.py:642-654);
                     // DH : min over frames first, one noise plane (DH/trainer.py:671,687-690)
@@ -419,6 +435,8 @@ __global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArg
 
     if (tid < 21 * F) load_cam(&s_cam[tid / 21], a.K, a.inv_K, a.T[tid / 21], b, tid % 21);
     load_tile<2, B_HW, B_HH, B_LD, B_PLANE>(s_tgt, a.target + img_off, H, W, x0, y0);
+    __syncthreads();
+    if (tid < 9 * F) compose_cam(&s_cam[tid / 9], tid % 9);
 
     const int qx = x0 + tx, qy0 = y0 + tg * PXT;
     const float mxl = (qx == 1) ? 2.f : 1.f, mxr = (qx == W - 2) ? 2.f : 1.f;  // reflection-pad adjoint
