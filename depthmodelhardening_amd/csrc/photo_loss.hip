@@ -252,6 +252,9 @@ __device__ __forceinline__ void warp_tile(float* s, const float* __restrict__ sr
                                           float dmul) {
     const bool same = (Hs == H && Ws == W);
     const float rh = (float)Hs / (float)H, rw = (float)Ws / (float)W;
+#ifdef DMH_WARP_UNROLL
+#pragma unroll
+#endif
     for (int i = threadIdx.x; i < HH_ * HW_; i += NT) {
         const int r = i / HW_, col = i - r * HW_;
         const int gy = reflect_idx(y0 - HALO + r, H), gx = reflect_idx(x0 - HALO + col, W);
