@@ -37,13 +37,31 @@ def k1_bytes(B, H, W, scales=4):
     return fwd, bwd
 
 
+def usable_cores():
+    """Cores this process may actually use: affinity mask and cgroup CPU quota, not the host's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    # a GPU box hands each GPU a 16-core share even where nproc reports the whole host (256): more threads than
+    # that only oversubscribe (measured: 400 s instead of 20 s for the same sample)
+    return max(1, min(n, int(os.environ.get("DMH_CPU_THREADS", "16"))))
+
+
 def cpu_baseline(height, width, atk_steps, batch):
     """The CPU oracle (oracle/, plain PyTorch) on a bounded sample of the same iteration, extrapolated
     linearly: attack time ~ PGD steps, train-step time ~ batch."""
     from depthmodelhardening_amd.depth_model import import_depth_model
     from oracle import train_step_ref
     torch.manual_seed(0)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     model = import_depth_model((1024, 320))
     s_steps, s_batch, s_ba = 1, 2, 12
@@ -104,7 +122,7 @@ def main():
 
     def heartbeat():
         while not stop_hb.wait(60.0):
-            print("[bench %.0fs] ... still running (MIOpen compiles kernels on first use)" %
+            print("[bench %.0fs] ... still running (first step: MIOpen builds its kernels; last: CPU baseline)" %
                   (time.perf_counter() - t_start), file=sys.stderr, flush=True)
     if rank == 0:
         threading.Thread(target=heartbeat, daemon=True).start()

@@ -171,8 +171,53 @@ __device__ __forceinline__ Tap make_tap(float ix, float iy, int H, int W) {
     return t;
 }
 
+// Gather through a buffer resource: one 128-bit descriptor in SGPRs per source image, 32-bit byte offsets in
+// VGPRs and the colour-plane offset in an SGPR -- no 64-bit address arithmetic per load (guide T8).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    // the pointer is the same in every lane (derived from blockIdx); tell the compiler so
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
+__device__ __forceinline__ float tap_sample_buf(rsrc_t rs, unsigned plane_bytes, const Tap& t) {
+#ifdef DMH_ABLATE_GATHER
+    return (float)t.o00 * t.w00 + (float)t.o01 * t.w01 + (float)t.o10 * t.w10 + (float)t.o11 * t.w11;
+#else
+    const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o00 * 4u, plane_bytes, 0));
+    const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o01 * 4u, plane_bytes, 0));
+    const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o10 * 4u, plane_bytes, 0));
+    const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o11 * 4u, plane_bytes, 0));
+    return v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
+#endif
+}
+
+__device__ __forceinline__ float ld_buf(rsrc_t rs, unsigned elem) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, elem * 4u, 0, 0));
+}
+
+// disp_at through a buffer resource (same arithmetic)
+__device__ __forceinline__ float disp_at_buf(rsrc_t rd, int Hs, int Ws, float rh, float rw, bool same, int y, int x) {
+    if (same) return ld_buf(rd, (unsigned)(y * Ws + x));
+    const float sy = fmaxf(rh * ((float)y + 0.5f) - 0.5f, 0.f);
+    const float sx = fmaxf(rw * ((float)x + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, x0 = (int)sx;
+    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    const float v00 = ld_buf(rd, (unsigned)(y0 * Ws + x0)), v01 = ld_buf(rd, (unsigned)(y0 * Ws + x1));
+    const float v10 = ld_buf(rd, (unsigned)(y1 * Ws + x0)), v11 = ld_buf(rd, (unsigned)(y1 * Ws + x1));
+    return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+}
+
 __device__ __forceinline__ float tap_sample(const float* __restrict__ img, const Tap& t) {
+#ifdef DMH_ABLATE_GATHER  // timing-only build: no gather loads (results are wrong)
+    return (float)t.o00 * t.w00 + (float)t.o01 * t.w01 + (float)t.o10 * t.w10 + (float)t.o11 * t.w11;
+#else
     return img[t.o00] * t.w00 + img[t.o01] * t.w01 + img[t.o10] * t.w10 + img[t.o11] * t.w11;
+#endif
 }
 
 // SSIM window statistics with every factor scaled by 81 (mu = s/9): SSIM_n/SSIM_d is unchanged,
@@ -252,18 +297,18 @@ __device__ __forceinline__ void warp_tile(float* s, const float* __restrict__ sr
                                           float dmul) {
     const bool same = (Hs == H && Ws == W);
     const float rh = (float)Hs / (float)H, rw = (float)Ws / (float)W;
-#ifdef DMH_WARP_UNROLL
-#pragma unroll
-#endif
+    const unsigned plane = (unsigned)(H * W) * 4u;
+    const rsrc_t rs = make_rsrc(src, 3u * plane);
+    const rsrc_t rd = make_rsrc(disp, (unsigned)(Hs * Ws) * 4u);
     for (int i = threadIdx.x; i < HH_ * HW_; i += NT) {
         const int r = i / HW_, col = i - r * HW_;
         const int gy = reflect_idx(y0 - HALO + r, H), gx = reflect_idx(x0 - HALO + col, W);
-        const float d = disp_at(disp, Hs, Ws, rh, rw, same, gy, gx);
+        const float d = disp_at_buf(rd, Hs, Ws, rh, rw, same, gy, gx);
         const Proj p = project<true>(cam, d, gx, gy, H, W, min_disp, dmul);
         const Tap t = make_tap(p.ix, p.iy, H, W);
-        s[0 * PLANE + r * LD + col] = tap_sample(src, t);
-        s[1 * PLANE + r * LD + col] = tap_sample(src + H * W, t);
-        s[2 * PLANE + r * LD + col] = tap_sample(src + 2 * H * W, t);
+        s[0 * PLANE + r * LD + col] = tap_sample_buf(rs, 0u, t);
+        s[1 * PLANE + r * LD + col] = tap_sample_buf(rs, plane, t);
+        s[2 * PLANE + r * LD + col] = tap_sample_buf(rs, 2u * plane, t);
     }
 }
 
@@ -321,7 +366,10 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
     }
 
     const Philox<7> rng(a.seed);
-    for (int s = 0; s < a.num_scales; ++s) {
+    float acc1[DMH_MAX_SCALES], acc2[DMH_MAX_SCALES];
+#pragma unroll
+    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
+        if (s >= a.num_scales) break;
         float best[PXT];
         int bestf[PXT];
 #pragma unroll
@@ -388,8 +436,15 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
             s1 += val;
             s2 += chosen ? 1.f : 0.f;
         }
-        const float t1 = block_sum<NT>(s1, s_red);
-        const float t2 = block_sum<NT>(s2, s_red);
+        acc1[s] = s1;
+        acc2[s] = s2;
+    }
+    // one reduction for all scales at the end (keeps the scale loop free of extra barriers)
+#pragma unroll
+    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
+        if (s >= a.num_scales) break;
+        const float t1 = block_sum<NT>(acc1[s], s_red);
+        const float t2 = block_sum<NT>(acc2[s], s_red);
         if (tid == 0) {
             k.partials[((size_t)s * k.nblk + blk) * 2 + 0] = t1;
             k.partials[((size_t)s * k.nblk + blk) * 2 + 1] = t2;
@@ -418,6 +473,30 @@ __device__ __forceinline__ float warp_pixel_bwd(const float* __restrict__ src, c
     if (!(p.ix > 0.f && p.ix < (float)(W - 1))) gix = 0.f;
     if (!(p.iy > 0.f && p.iy < (float)(H - 1))) giy = 0.f;
     const float g_depth = (gix * (p.ax - p.px * p.az) + giy * (p.ay - p.py * p.az)) * (FAST ? fast_rcp(p.den) : 1.0f / p.den);
+    return g_depth * (-(p.depth * p.depth)) * dmul;
+}
+
+// fused-kernel version of warp_pixel_bwd: buffer-resource gathers, fast projection
+__device__ __forceinline__ float warp_pixel_bwd_buf(rsrc_t rs, unsigned plane, const Cam& cam, float d, int x, int y,
+                                                    int H, int W, float min_disp, float dmul, float g0, float g1,
+                                                    float g2) {
+    const Proj p = project<true>(cam, d, x, y, H, W, min_disp, dmul);
+    const Tap t = make_tap(p.ix, p.iy, H, W);
+    float gix = 0.f, giy = 0.f;
+    const float gc[3] = {g0, g1, g2};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned po = plane * (unsigned)c;
+        const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o00 * 4u, po, 0));
+        const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o01 * 4u, po, 0));
+        const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o10 * 4u, po, 0));
+        const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o11 * 4u, po, 0));
+        gix += gc[c] * ((v01 - v00) * (1.f - t.fy) + (v11 - v10) * t.fy);
+        giy += gc[c] * ((v10 - v00) * (1.f - t.fx) + (v11 - v01) * t.fx);
+    }
+    if (!(p.ix > 0.f && p.ix < (float)(W - 1))) gix = 0.f;
+    if (!(p.iy > 0.f && p.iy < (float)(H - 1))) giy = 0.f;
+    const float g_depth = (gix * (p.ax - p.px * p.az) + giy * (p.ay - p.py * p.az)) * fast_rcp(p.den);
     return g_depth * (-(p.depth * p.depth)) * dmul;
 }
 
@@ -532,13 +611,16 @@ __global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArg
                 __syncthreads();
             }
             // (3) chain through the bilinear gather, the projective divide and disp_to_depth
+            const unsigned plane = (unsigned)(H * W) * 4u;
+            const rsrc_t rs = make_rsrc(src, 3u * plane);
+            const rsrc_t rd = make_rsrc(disp, (unsigned)(a.Hs[s] * a.Ws[s]) * 4u);
 #pragma unroll
             for (int i = 0; i < PXT; ++i) {
                 const int qy = qy0 + i;
                 if (qx < W && qy < H) {
-                    const float d = disp_at(disp, a.Hs[s], a.Ws[s], rh, rw, same, qy, qx);
-                    acc[i] += warp_pixel_bwd<true>(src, s_cam[f], d, qx, qy, H, W, k.min_disp, k.dmul, gw[0][i], gw[1][i],
-                                             gw[2][i]);
+                    const float d = disp_at_buf(rd, a.Hs[s], a.Ws[s], rh, rw, same, qy, qx);
+                    acc[i] += warp_pixel_bwd_buf(rs, plane, s_cam[f], d, qx, qy, H, W, k.min_disp, k.dmul, gw[0][i],
+                                                 gw[1][i], gw[2][i]);
                 }
             }
         }

@@ -90,3 +90,20 @@ def test_unsupported_configurations_fail_loudly(tmp_path):
     with pytest.raises(NotImplementedError):
         Trainer(MonodepthOptions().parse(["--dataset", "synthetic", "--log_dir", str(tmp_path)]),
                 device=torch.device("cuda"))   # default frame_ids [0,-1,1] needs the pose network
+
+
+@pytest.mark.parametrize("adv_type", ["object", "image"])
+def test_simple_adv_training_loop(adv_type):
+    """simple_adv_training.py:96-155 / physical_adv_training.py:66-116 harness: two iterations run and learn."""
+    from depthmodelhardening_amd import simple_adv_training as sat
+    args = sat.getCLIOptions(["-at", adv_type, "-lp", "t", "-bs", "2", "-s", "2", "--max_steps", "2",
+                              "-eps", "0.05" if adv_type == "object" else "0.03"])
+    sat.setup_seed(args["random_seed"])
+    dev = torch.device("cuda")
+    from oracle.synth import TinyDepthNet
+    model = TinyDepthNet(seed=5).to(dev).eval()
+    import copy
+    rob = copy.deepcopy(model)
+    w0 = rob.c3.weight.detach().clone()
+    sat.do_adv_training(rob, model, args, dev)
+    assert not torch.equal(rob.c3.weight, w0)

@@ -37,6 +37,9 @@ def main():
     ap.add_argument("--H", type=int, default=320)
     ap.add_argument("--W", type=int, default=1024)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--no_ssim", type=int, default=0)
+    ap.add_argument("--noise", type=int, default=2)
+    ap.add_argument("--scales", type=int, default=4)
     a = ap.parse_args()
     B, H, W = a.B, a.H, a.W
     dev = torch.device("cuda")
@@ -54,8 +57,8 @@ def main():
     lib = N.lib()
     res = {}
 
-    cfg = dict(F=1, NS=4, min_depth=0.1, max_depth=100.0, variant="md2", automask=True, no_ssim=False,
-               smooth_wt=1e-3, want_to_opt=False, noise_mode=N.NOISE_PHILOX, seed=1, offset=0)
+    cfg = dict(F=1, NS=4, min_depth=0.1, max_depth=100.0, variant="md2", automask=True, no_ssim=bool(a.no_ssim),
+               smooth_wt=1e-3, want_to_opt=False, noise_mode=a.noise, seed=1, offset=0)
     pa = ops._photo_args(cfg, left, [right], [T], K, inv_K, [d.detach() for d in disps], ())
     sm = ops._smooth_args([d.detach() for d in disps], colors)
     sel = [torch.empty(B, H, W, device=dev) for _ in range(4)]
