@@ -38,6 +38,7 @@ constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 #define DMH_BWD_WAVES 2
 #endif
 
+
 struct Cam {
     float ik[9];   // inv_K[:3,:3]           MD2/layers.py:164
     float P[12];   // (K @ T)[:3,:]          MD2/layers.py:188
@@ -523,7 +524,9 @@ __global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArg
     const int qx = x0 + tx, qy0 = y0 + tg * PXT;
     const float mxl = (qx == 1) ? 2.f : 1.f, mxr = (qx == W - 2) ? 2.f : 1.f;  // reflection-pad adjoint
 
-    for (int s = 0; s < a.num_scales; ++s) {
+#pragma unroll
+    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
+        if (s >= a.num_scales) break;
         float up = k.gvec[DMH_FIN_LOSS] / (float)a.num_scales + k.gvec[DMH_FIN_LOSS_S + s] +
                    k.gvec[DMH_FIN_REPROJ_S + s];
         up *= (a.variant == DMH_VARIANT_MD2) ? 1.0f / ((float)a.B * (float)H * (float)W)
