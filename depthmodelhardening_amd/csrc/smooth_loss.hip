@@ -134,56 +134,77 @@ struct FArgs {
     float* sstats;
 };
 
+constexpr int NTF = 1024;  // the finalise kernel is one workgroup: make it as wide as the hardware allows
+
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
     __syncthreads();
     red[threadIdx.x] = v;
     __syncthreads();
-    for (int o = NT / 2; o > 0; o >>= 1) {
+    for (int o = NTF / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
     return red[0];
 }
 
-__global__ __launch_bounds__(NT) void finalize_kernel(const FArgs k) {
-    __shared__ double s_red[NT];
+__global__ __launch_bounds__(NTF) void finalize_kernel(const FArgs k) {
+    __shared__ double s_red[NTF];
     __shared__ double s_sm[DMH_MAX_SCALES];
     const int NS = k.sm.num_scales, B = k.B, tid = threadIdx.x;
     if (tid < DMH_MAX_SCALES) s_sm[tid] = 0.0;
-    double reproj[DMH_MAX_SCALES], count[DMH_MAX_SCALES];
-    for (int s = 0; s < NS; ++s) {
-        double a1 = 0.0, a2 = 0.0;
-        for (int i = tid; i < k.nblk; i += NT) {
-            a1 += (double)k.photo[((size_t)s * k.nblk + i) * 2 + 0];
-            a2 += (double)k.photo[((size_t)s * k.nblk + i) * 2 + 1];
+    // photometric partials: one strided pass over [NS][nblk] float2, all scales' loads independent and in flight
+    double a1[DMH_MAX_SCALES] = {0, 0, 0, 0}, a2[DMH_MAX_SCALES] = {0, 0, 0, 0};
+    const float2* ph = reinterpret_cast<const float2*>(k.photo);
+    for (int i = tid; i < k.nblk; i += NTF) {
+#pragma unroll
+        for (int s = 0; s < DMH_MAX_SCALES; ++s) {
+            if (s < NS) {
+                const float2 v = ph[(size_t)s * k.nblk + i];
+                a1[s] += (double)v.x;
+                a2[s] += (double)v.y;
+            }
         }
-        const double S1 = block_sum_d(a1, s_red);
-        const double S2 = block_sum_d(a2, s_red);
-        count[s] = S2;
-        reproj[s] = (k.variant == DMH_VARIANT_MD2) ? S1 / ((double)B * k.H * k.W) : S1 / (S2 + 1e-7);
+    }
+    double reproj[DMH_MAX_SCALES], count[DMH_MAX_SCALES];
+#pragma unroll
+    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
+        reproj[s] = count[s] = 0.0;
+        if (s < NS) {
+            const double S1 = block_sum_d(a1[s], s_red);
+            const double S2 = block_sum_d(a2[s], s_red);
+            count[s] = S2;
+            reproj[s] = (k.variant == DMH_VARIANT_MD2) ? S1 / ((double)B * k.H * k.W) : S1 / (S2 + 1e-7);
+        }
     }
     // smoothness: one (scale, image) pair per thread, chunks summed in a fixed order
-    for (int s = 0; s < NS; ++s) {
-        double part = 0.0;
-        for (int b = tid; b < B; b += NT) {
-            const int nc = k.l.nchunk[s];
-            const float* p = k.smooth + ((size_t)k.l.blk_base[s] + (size_t)b * nc) * 3;
-            double sd = 0.0, rx = 0.0, ry = 0.0;
-            for (int c = 0; c < nc; ++c) {
-                sd += (double)p[c * 3 + 0];
-                rx += (double)p[c * 3 + 1];
-                ry += (double)p[c * 3 + 2];
-            }
-            const int Hs = k.sm.Hs[s], Ws = k.sm.Ws[s];
-            const double mean = sd / ((double)Hs * Ws);
-            const double R = rx / ((double)B * Hs * (Ws - 1)) + ry / ((double)B * (Hs - 1) * Ws);
-            k.sstats[(s * B + b) * 2 + 0] = (float)mean;
-            k.sstats[(s * B + b) * 2 + 1] = (float)R;
-            const double den = mean + 1e-7;
-            part += R / (den < 0 ? -den : den);
+    double part[DMH_MAX_SCALES] = {0, 0, 0, 0};
+    for (int p = tid; p < NS * B; p += NTF) {
+        const int s = p / B, b = p - s * B;
+        const int nc = k.l.nchunk[s];
+        const float* q = k.smooth + ((size_t)k.l.blk_base[s] + (size_t)b * nc) * 3;
+        double sd = 0.0, rx = 0.0, ry = 0.0;
+        for (int c = 0; c < nc; ++c) {
+            sd += (double)q[c * 3 + 0];
+            rx += (double)q[c * 3 + 1];
+            ry += (double)q[c * 3 + 2];
         }
-        const double S = block_sum_d(part, s_red);
-        if (tid == 0) s_sm[s] = S;
+        const int Hs = k.sm.Hs[s], Ws = k.sm.Ws[s];
+        const double mean = sd / ((double)Hs * Ws);
+        const double R = rx / ((double)B * Hs * (Ws - 1)) + ry / ((double)B * (Hs - 1) * Ws);
+        k.sstats[(s * B + b) * 2 + 0] = (float)mean;
+        k.sstats[(s * B + b) * 2 + 1] = (float)R;
+        const double den = mean + 1e-7;
+        const double term = R / (den < 0 ? -den : den);
+#pragma unroll
+        for (int j = 0; j < DMH_MAX_SCALES; ++j)
+            if (j == s) part[j] += term;
+    }
+#pragma unroll
+    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
+        if (s < NS) {
+            const double S = block_sum_d(part[s], s_red);
+            if (tid == 0) s_sm[s] = S;
+        }
     }
     __syncthreads();
     if (tid == 0) {
@@ -273,7 +294,7 @@ int dmh_loss_finalize(const float* photo_partials, const float* smooth_partials,
     k.smooth_wt = smooth_wt;
     k.fin = fin;
     k.sstats = sstats;
-    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, k);
+    hipLaunchKernelGGL(finalize_kernel, dim3(1), dim3(NTF), 0, (hipStream_t)stream, k);
     return check_launch("dmh_loss_finalize");
 }
 
