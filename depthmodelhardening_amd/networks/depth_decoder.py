@@ -31,6 +31,27 @@ class DepthDecoder(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, input_features):
+        if input_features[-1].is_cuda and self.use_skips and self.upsample_mode == 'nearest':
+            return self._forward_fused(input_features)
+        return self._forward_reference(input_features)
+
+    def _forward_fused(self, input_features):
+        """Same arithmetic as the reference forward, with the element-wise passes between the convolutions fused
+        into the HIP glue kernels (ops.up_cat_pad / ops.elu_pad) and the convolutions run un-padded on pre-padded
+        tensors.  Identical parameters / state_dict."""
+        from .. import ops
+        self.outputs = {}
+        p = ops.elu_pad(input_features[-1], apply_elu=False)
+        for i in range(4, -1, -1):
+            y = self.convs[("upconv", i, 0)].conv.conv(p)
+            p = ops.up_cat_pad(y, input_features[i - 1] if i > 0 else None)
+            z = self.convs[("upconv", i, 1)].conv.conv(p)
+            p = ops.elu_pad(z)                      # feeds both the next stage and this scale's disparity head
+            if i in self.scales:
+                self.outputs[("disp", i)] = self.sigmoid(self.convs[("dispconv", i)].conv(p))
+        return self.outputs
+
+    def _forward_reference(self, input_features):
         self.outputs = {}
         x = input_features[-1]
         for i in range(4, -1, -1):

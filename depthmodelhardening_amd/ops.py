@@ -418,3 +418,62 @@ def l0_mask_cost(pos, neg):
     if pos.dim() != 4 or pos.shape[0] != 1 or pos.shape != neg.shape:
         raise RuntimeError("l0_mask_cost: pos/neg must be [1,C,H,W]")
     return _L0MaskCost.apply(_c(pos), _c(neg))
+
+
+class _UpCatPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, skip):
+        lib = N.lib()
+        B, C1, h, w = y.shape
+        C2 = 0 if skip is None else skip.shape[1]
+        if skip is not None and tuple(skip.shape) != (B, C2, 2 * h, 2 * w):
+            raise RuntimeError("up_cat_pad: skip must be [B,C2,2h,2w], got %s for y %s" % (tuple(skip.shape), tuple(y.shape)))
+        out = torch.empty((B, C1 + C2, 2 * h + 2, 2 * w + 2), device=y.device, dtype=torch.float32)
+        N.check(lib.dmh_dec_up_cat_pad_fwd(N.ptr(y), N.ptr(skip), B, C1, C2, h, w, N.ptr(out), N.stream()))
+        ctx.save_for_backward(y)
+        ctx.c2 = C2
+        ctx.skip_grad = skip is not None and skip.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (y,) = ctx.saved_tensors
+        lib = N.lib()
+        B, C1, h, w = y.shape
+        g_y = torch.empty_like(y)
+        g_skip = torch.empty((B, ctx.c2, 2 * h, 2 * w), device=y.device, dtype=torch.float32) if ctx.skip_grad else None
+        N.check(lib.dmh_dec_up_cat_pad_bwd(N.ptr(y), N.ptr(_c(g_out)), B, C1, ctx.c2, h, w, N.ptr(g_y), N.ptr(g_skip),
+                                           N.stream()))
+        return g_y, g_skip
+
+
+def up_cat_pad(y, skip=None):
+    """pad1_reflect(cat(up2_nearest(ELU(y)), skip)) in one pass (MD2/networks/depth_decoder.py:54-60 + the
+    ReflectionPad2d of the next Conv3x3)."""
+    return _UpCatPad.apply(_c(y), None if skip is None else _c(skip))
+
+
+class _EluPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, apply_elu):
+        lib = N.lib()
+        B, Cc, H, W = z.shape
+        out = torch.empty((B, Cc, H + 2, W + 2), device=z.device, dtype=torch.float32)
+        N.check(lib.dmh_elu_pad_fwd(N.ptr(z), B, Cc, H, W, int(apply_elu), N.ptr(out), N.stream()))
+        ctx.save_for_backward(z)
+        ctx.apply_elu = int(apply_elu)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (z,) = ctx.saved_tensors
+        lib = N.lib()
+        B, Cc, H, W = z.shape
+        g_z = torch.empty_like(z)
+        N.check(lib.dmh_elu_pad_bwd(N.ptr(z), N.ptr(_c(g_out)), B, Cc, H, W, ctx.apply_elu, N.ptr(g_z), N.stream()))
+        return g_z, None
+
+
+def elu_pad(z, apply_elu=True):
+    """pad1_reflect(ELU(z)) in one pass (apply_elu=False: ReflectionPad2d(1) only)."""
+    return _EluPad.apply(_c(z), bool(apply_elu))

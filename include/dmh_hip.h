@@ -201,6 +201,23 @@ int dmh_masked_sq_mean_fwd(const float* disp, const float* mask, int64_t n, floa
 int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, const float* gscale, float* g_disp,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Decoder glue (SURVEY.md section 8f direction "fuse around the convolutions"): the element-wise passes between
+ * the MIOpen convolutions of the depth decoder, one pass per stage boundary.
+ * Replaces MD2/networks/depth_decoder.py:54-60 (ELU, nearest upsample, torch.cat) + the ReflectionPad2d(1) of the
+ * following Conv3x3 (MD2/layers.py:133-136).
+ *   up_cat_pad: out[B,C1+C2,2h+2,2w+2] = pad1_reflect(cat(up2_nearest(ELU(y[B,C1,h,w])), skip[B,C2,2h,2w]))
+ *   elu_pad   : out[B,C,H+2,W+2]       = pad1_reflect(ELU(z[B,C,H,W]))      (apply_elu = 0: pad only)
+ * skip / g_skip may be NULL when C2 == 0.
+ * ---------------------------------------------------------------------------------- */
+int dmh_dec_up_cat_pad_fwd(const float* y, const float* skip, int B, int C1, int C2, int h, int w, float* out,
+                           void* stream);
+int dmh_dec_up_cat_pad_bwd(const float* y, const float* g_out, int B, int C1, int C2, int h, int w, float* g_y,
+                           float* g_skip, void* stream);
+int dmh_elu_pad_fwd(const float* z, int B, int C, int H, int W, int apply_elu, float* out, void* stream);
+int dmh_elu_pad_bwd(const float* z, const float* g_out, int B, int C, int H, int W, int apply_elu, float* g_z,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

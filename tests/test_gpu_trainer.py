@@ -107,3 +107,54 @@ def test_simple_adv_training_loop(adv_type):
     w0 = rob.c3.weight.detach().clone()
     sat.do_adv_training(rob, model, args, dev)
     assert not torch.equal(rob.c3.weight, w0)
+
+
+def test_fused_decoder_glue_matches_reference_decoder():
+    """ops.up_cat_pad / ops.elu_pad (HIP) + un-padded convs == the reference decoder graph (ELU, upsample, cat,
+    ReflectionPad2d as separate ATen ops), forward values and every gradient."""
+    from depthmodelhardening_amd import networks
+    torch.manual_seed(0)
+    enc = networks.ResnetEncoder(18, False).cuda()
+    dec = networks.DepthDecoder(enc.num_ch_enc, range(4)).cuda()
+    x = torch.rand(2, 3, 64, 96, device="cuda")
+    feats = [f.detach().requires_grad_(True) for f in enc(x)]
+    out_f = dec._forward_fused(feats)
+    loss_f = sum((out_f[("disp", s)] ** 2).mean() * (s + 1) for s in range(4))
+    g_f = torch.autograd.grad(loss_f, feats + list(dec.parameters()))
+    out_r = dec._forward_reference(feats)
+    loss_r = sum((out_r[("disp", s)] ** 2).mean() * (s + 1) for s in range(4))
+    g_r = torch.autograd.grad(loss_r, feats + list(dec.parameters()))
+    for s in range(4):
+        assert_close_frac(out_f[("disp", s)], out_r[("disp", s)], rtol=1e-5, atol=1e-6, name="disp%d" % s)
+    for a, b in zip(g_f, g_r):
+        assert_close_frac(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()) + 1e-12, name="decoder grad")
+    assert dec(feats).keys() == out_r.keys()
+
+
+def test_glue_ops_small_shapes():
+    from depthmodelhardening_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for (B, C1, C2, h, w) in [(1, 2, 0, 2, 3), (2, 3, 2, 1, 2), (1, 1, 1, 5, 4)]:
+        y = (torch.rand(B, C1, h, w, device="cuda", generator=g) - 0.5).requires_grad_(True)
+        skip = torch.rand(B, C2, 2 * h, 2 * w, device="cuda", generator=g).requires_grad_(True) if C2 else None
+        got = ops.up_cat_pad(y, skip)
+        ref = F.interpolate(F.elu(y), scale_factor=2, mode="nearest")
+        if C2:
+            ref = torch.cat([ref, skip], 1)
+        ref = F.pad(ref, [1, 1, 1, 1], mode="reflect")
+        w8 = torch.rand(got.shape, device="cuda", generator=g)
+        ins = [y] + ([skip] if C2 else [])
+        ga = torch.autograd.grad((got * w8).sum(), ins)
+        gb = torch.autograd.grad((ref * w8).sum(), ins)
+        torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
+        for a, b in zip(ga, gb):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+    z = (torch.rand(2, 3, 4, 5, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    for elu in (True, False):
+        got = ops.elu_pad(z, elu)
+        ref = F.pad(F.elu(z) if elu else z, [1, 1, 1, 1], mode="reflect")
+        w8 = torch.rand(got.shape, device="cuda", generator=g)
+        torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
+        torch.testing.assert_close(torch.autograd.grad((got * w8).sum(), z)[0],
+                                   torch.autograd.grad((ref * w8).sum(), z)[0], rtol=1e-5, atol=1e-6)
