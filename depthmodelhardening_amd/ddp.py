@@ -21,6 +21,7 @@ def init_distributed(device_type="cuda"):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if device_type == "cuda":
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
         device = torch.device("cuda", local)
     else:
@@ -28,8 +29,9 @@ def init_distributed(device_type="cuda"):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = "nccl" if device_type == "cuda" else "gloo"
-        kw = {"device_id": device} if device_type == "cuda" else {}
+        # nccl (= RCCL on ROCm) for GPUs; DMH_DIST_BACKEND=gloo lets several ranks share ONE GPU in tests
+        backend = os.environ.get("DMH_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
+        kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, device
 
