@@ -25,6 +25,10 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290
 
+# HBM bytes per launch measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
+# MI355X_MICROARCH.md section HBM) for the profiled shape; see profiles/README.md.  Keyed by (B, H, W).
+MEASURED_TRAFFIC = {(32, 320, 1024): {"photo_fwd": 482.6e6, "photo_bwd": 641.5e6, "source": "profiles/r01_k1k2_pmc.csv"}}
+
 
 def k1_bytes(B, H, W, scales=4):
     """Algorithmic HBM bytes of the fused K1 launches (all-scales-fused variant):
@@ -168,8 +172,12 @@ def main():
         if dom:
             kname, nbytes = names[dom]
             achieved = nbytes / (kms[dom] * 1e-3) / 1e9
+            meas = MEASURED_TRAFFIC.get((a.batch_size, a.height, a.width), {})
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": meas.get(dom),
+                    "traffic_source": meas.get("source"),
+                    "note": "all-scales-fused kernel: traffic == algorithmic bytes (no re-reads); it is bound by VALU issue "
+                            "and dependent-load latency, not by HBM (profiles/README.md)",
                     "avg_ms": round(kms[dom], 4), "algorithmic_bytes": nbytes,
                     "others": {names[k][0]: {"avg_ms": round(v, 4), "GB/s": round(names[k][1] / (v * 1e-3) / 1e9, 1)}
                                for k, v in kms.items() if k != dom}}
