@@ -82,7 +82,7 @@ def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
     f = fin.detach().cpu()
     # md2's mean(min(.)) is continuous in the inputs: 2e-5.  dh's masked-sum / mask-count jumps by
     # (value - mean)/count whenever an fp32 near-tie flips the argmin, so small images get 2e-4.
-    srtol = 2e-5 if variant == "md2" else 2e-4
+    srtol = 2e-5 if variant == "md2" else max(2e-4, 2.0 / (B * H * W))
     assert abs(f[N.FIN_LOSS].item() - losses["loss"].item()) <= srtol * abs(losses["loss"].item())
     for s in range(4):
         ref = losses["loss/%d" % s].item()
