@@ -292,3 +292,91 @@ int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, cons
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------- K8
+// Masked depth-error metrics of evaluate_attacks (MD2/evaluate_depth.py:57-99,193-197): disparity -> depth
+// (disp_to_depth on |disp|, x5.4 stereo scale, clamp to [1e-3, 80]) and the eight sums, in one pass.
+namespace {
+
+constexpr int NQ = 9;  // mask, a1, a2, a3, abs_err, sq_err, log_sq_err, abs_rel, sq_rel
+
+__global__ __launch_bounds__(NT) void depth_err_kernel(const float* __restrict__ dgt, const float* __restrict__ dpr,
+                                                       const float* __restrict__ mask, int64_t n, float min_disp,
+                                                       float dmul, float scale, float lo, float hi,
+                                                       float* __restrict__ partials) {
+    __shared__ float s_red[NT / WAVE];
+    float acc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+        const float gt = clampf(scale / (min_disp + dmul * fabsf(dgt[i])), lo, hi);
+        const float pr = clampf(scale / (min_disp + dmul * fabsf(dpr[i])), lo, hi);
+        const float m = mask ? mask[i] : 1.f;
+        const float th = fmaxf(gt / pr, pr / gt), d = gt - pr, ld = logf(gt) - logf(pr);
+        acc[0] += m;
+        acc[1] += th < 1.25f ? m : 0.f;
+        acc[2] += th < 1.25f * 1.25f ? m : 0.f;
+        acc[3] += th < 1.25f * 1.25f * 1.25f ? m : 0.f;
+        acc[4] += fabsf(d) * m;
+        acc[5] += d * d * m;
+        acc[6] += ld * ld * m;
+        acc[7] += fabsf(d) / gt * m;
+        acc[8] += d * d / gt * m;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float t = block_sum<NT>(acc[q], s_red);
+        if (threadIdx.x == 0) partials[blockIdx.x * NQ + q] = t;
+    }
+}
+
+__global__ __launch_bounds__(NT) void depth_err_finalize_kernel(const float* __restrict__ partials, int nblk,
+                                                                float* __restrict__ out) {
+    __shared__ double s_red[NT];
+    double tot[NQ];
+    for (int q = 0; q < NQ; ++q) {
+        double a = 0.0;
+        for (int i = threadIdx.x; i < nblk; i += NT) a += (double)partials[i * NQ + q];
+        __syncthreads();
+        s_red[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = NT / 2; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+            __syncthreads();
+        }
+        tot[q] = s_red[0];
+    }
+    if (threadIdx.x == 0) {
+        const double t = tot[0];
+        out[0] = (float)(tot[4] / t);        // abs_err
+        out[1] = (float)(tot[7] / t);        // abs_rel
+        out[2] = (float)(tot[8] / t);        // sq_rel
+        out[3] = (float)sqrt(tot[5] / t);    // rmse
+        out[4] = (float)sqrt(tot[6] / t);    // rmse_log
+        out[5] = (float)(tot[1] / t);        // a1
+        out[6] = (float)(tot[2] / t);        // a2
+        out[7] = (float)(tot[3] / t);        // a3
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dmh_depth_errors_partials_size(int64_t n) { return (int64_t)red_blocks(n) * NQ; }
+
+int dmh_masked_depth_errors(const float* disp_gt, const float* disp_pred, const float* mask, int64_t n,
+                            float min_depth, float max_depth, float scale, float clamp_lo, float clamp_hi,
+                            float* partials, float* out8, void* stream) {
+    DMH_REQUIRE(disp_gt && disp_pred && partials && out8 && n > 0, "null pointer or n <= 0");
+    DMH_REQUIRE(min_depth > 0.f && max_depth > min_depth && clamp_lo > 0.f && clamp_hi > clamp_lo, "bad ranges");
+    const double mn = 1.0 / (double)max_depth, mx = 1.0 / (double)min_depth;
+    const int nb = red_blocks(n);
+    hipLaunchKernelGGL(depth_err_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, disp_gt, disp_pred, mask, n,
+                       (float)mn, (float)(mx - mn), scale, clamp_lo, clamp_hi, partials);
+    hipLaunchKernelGGL(depth_err_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partials, nb, out8);
+    return check_launch("dmh_masked_depth_errors");
+}
+
+}  // extern "C"

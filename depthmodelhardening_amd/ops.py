@@ -477,3 +477,20 @@ class _EluPad(torch.autograd.Function):
 def elu_pad(z, apply_elu=True):
     """pad1_reflect(ELU(z)) in one pass (apply_elu=False: ReflectionPad2d(1) only)."""
     return _EluPad.apply(_c(z), bool(apply_elu))
+
+
+def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,
+                        clamp_hi=80.0):
+    """The eight attack-evaluation metrics of MD2/evaluate_depth.py:57-99 computed from two disparity maps in one
+    pass on the device: returns a tensor [abs_err, abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3]."""
+    lib = N.lib()
+    disp_gt, disp_pred = _c(disp_gt.detach()), _c(disp_pred.detach())
+    n = disp_gt.numel()
+    if disp_pred.numel() != n or (mask is not None and mask.numel() != n):
+        raise RuntimeError("masked_depth_errors: size mismatch")
+    part = torch.empty(lib.dmh_depth_errors_partials_size(n), device=disp_gt.device, dtype=torch.float32)
+    out = torch.empty(8, device=disp_gt.device, dtype=torch.float32)
+    N.check(lib.dmh_masked_depth_errors(N.ptr(disp_gt), N.ptr(disp_pred), N.ptr(None if mask is None else _c(mask)), n,
+                                        min_depth, max_depth, scale, clamp_lo, clamp_hi, N.ptr(part), N.ptr(out),
+                                        N.stream()))
+    return out

@@ -120,6 +120,7 @@ class Trainer:
             self.backproject_depth[scale] = BackprojectDepth(self.opt.batch_size, h, w).to(self.device)
             self.project_3d[scale] = Project3D(self.opt.batch_size, h, w).to(self.device)
         self.timings = {}
+        self.val_eval_count = 10   # evaluate_attacks(..., eval_count=10), MD2/trainer.py:465
         if self.rank == 0:
             self.save_opts()
 
@@ -184,11 +185,29 @@ class Trainer:
             late_phase = self.step % 2000 == 0
             if (early_phase or late_phase) and self.rank == 0:
                 self.log_time(batch_idx, time.time() - before_op_time, losses["loss"].detach().cpu())
+                if self.opt.adv_train and self.val_eval_count > 0:
+                    self._apply_pending_update()
+                    self.val()
             self.step += 1
             if self.opt.max_steps and self.step >= self.opt.max_steps:
                 break
         self._apply_pending_update()
         self.model_lr_scheduler.step()
+
+    def val(self):
+        """Validate on a single minibatch, then evaluate the model under attack (MD2/trainer.py:435-470: an L0 attack
+        with 10 steps on 8 scenes, 10 batches).  The reference prints and discards the numbers; they are returned."""
+        self.set_eval()
+        with torch.no_grad():
+            inputs = self.dataset.next_batch(self.opt.batch_size)
+            self.process_batch(inputs)
+        eval_args = {"norm_type": "l_0", "step": self.opt.atk_steps, "adam_lr": 0.5, "mask_wt": 0.06, "l0_thresh": 0.1,
+                     "batch_size": 8}
+        from .evaluate_depth import evaluate_attacks
+        errors = evaluate_attacks(self.models['DepthModelWrapper'], eval_args, eval_count=self.val_eval_count,
+                                  scene_source=self.dataset.next_scenes)
+        self.set_train()
+        return errors
 
     def process_batch(self, inputs):
         """Pass a minibatch through the network and generate images and losses (MD2/trainer.py:335-375)."""

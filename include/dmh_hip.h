@@ -202,6 +202,16 @@ int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, cons
                            void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K8  attack-evaluation metrics of Trainer.val -> evaluate_attacks (MD2/evaluate_depth.py:57-99,193-197):
+ *     depth = clamp(5.4 / (min_disp + (max_disp-min_disp)*|disp|), 1e-3, 80) for both disparities, then the
+ *     (mask-weighted) abs_err, abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 -> out8.  mask may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int64_t dmh_depth_errors_partials_size(int64_t n);
+int dmh_masked_depth_errors(const float* disp_gt, const float* disp_pred, const float* mask, int64_t n,
+                            float min_depth, float max_depth, float scale, float clamp_lo, float clamp_hi,
+                            float* partials, float* out8, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Decoder glue (SURVEY.md section 8f direction "fuse around the convolutions"): the element-wise passes between
  * the MIOpen convolutions of the depth decoder, one pass per stage boundary.
  * Replaces MD2/networks/depth_decoder.py:54-60 (ELU, nearest upsample, torch.cat) + the ReflectionPad2d(1) of the

@@ -158,3 +158,11 @@ def test_glue_ops_small_shapes():
         torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
         torch.testing.assert_close(torch.autograd.grad((got * w8).sum(), z)[0],
                                    torch.autograd.grad((ref * w8).sum(), z)[0], rtol=1e-5, atol=1e-6)
+
+
+def test_trainer_val_reports_attack_metrics(tmp_path):
+    tr = _trainer(tmp_path, ["--adv_train", "--atk_steps", "1"])
+    tr.val_eval_count = 1
+    err = tr.val()
+    assert err.shape == (8,) and torch.isfinite(torch.from_numpy(err)).all()
+    assert tr.models["encoder"].training
