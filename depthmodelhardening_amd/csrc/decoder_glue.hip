@@ -39,80 +39,113 @@ __device__ __forceinline__ float fold2d(const float* __restrict__ gp, int Y, int
     return acc;
 }
 
+// Index scheme: blockIdx.y = plane (b * C + c); blockIdx.x * NT + threadIdx.x = PAIR of horizontally adjacent
+// elements inside the plane.  Row widths are even (2w, 2w+2, W+2 with W even), so a pair never straddles rows and
+// its 8-byte store is aligned: half the store instructions, one 32-bit division per pair.
+template <bool VEC2>
 __global__ __launch_bounds__(NT) void up_cat_pad_fwd_kernel(const float* __restrict__ y, const float* __restrict__ skip,
-                                                            int C1, int C2, int h, int w, float* __restrict__ out,
-                                                            int64_t total) {
+                                                            int C1, int C2, int h, int w, float* __restrict__ out) {
     const int H = 2 * h, W = 2 * w, PH = H + 2, PW = W + 2, C = C1 + C2;
-    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NT) {
-        const int px = (int)(idx % PW);
-        const int py = (int)((idx / PW) % PH);
-        const int c = (int)((idx / ((int64_t)PW * PH)) % C);
-        const int b = (int)(idx / ((int64_t)PW * PH * C));
-        const int Y = reflect_idx(py - 1, H), X = reflect_idx(px - 1, W);
-        float v;
-        if (c < C1)
-            v = elu_f(y[(((int64_t)b * C1 + c) * h + (Y >> 1)) * w + (X >> 1)]);
-        else
-            v = skip[(((int64_t)b * C2 + (c - C1)) * H + Y) * W + X];
-        out[idx] = v;
+    const int idx = (blockIdx.x * NT + threadIdx.x) * 2;   // PW is even
+    if (idx >= PH * PW) return;
+    const int plane = blockIdx.y, b = plane / C, c = plane - b * C;
+    const int py = idx / PW, px = idx - py * PW;
+    const int Y = reflect_idx(py - 1, H);
+    const int X0 = reflect_idx(px - 1, W), X1 = reflect_idx(px, W);
+    float v0, v1;
+    if (c < C1) {
+        const float* row = y + ((size_t)(b * C1 + c) * h + (Y >> 1)) * w;
+        v0 = elu_f(row[X0 >> 1]);
+        v1 = elu_f(row[X1 >> 1]);
+    } else {
+        const float* row = skip + ((size_t)(b * C2 + (c - C1)) * H + Y) * W;
+        v0 = row[X0];
+        v1 = row[X1];
     }
+    *reinterpret_cast<float2*>(out + (size_t)plane * PH * PW + idx) = make_float2(v0, v1);
 }
 
+// grid.y = B*C1 planes of g_y followed by B*C2 planes of g_skip; grid.x covers the larger (skip-resolution) plane
+template <bool VEC2>
 __global__ __launch_bounds__(NT) void up_cat_pad_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g_out,
-                                                            int C1, int C2, int h, int w, float* __restrict__ g_y,
-                                                            float* __restrict__ g_skip, int64_t n_y, int64_t n_skip) {
+                                                            int B, int C1, int C2, int h, int w,
+                                                            float* __restrict__ g_y, float* __restrict__ g_skip) {
     const int H = 2 * h, W = 2 * w, C = C1 + C2;
-    const int64_t plane = (int64_t)(H + 2) * (W + 2);
-    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < n_y + n_skip; idx += (int64_t)gridDim.x * NT) {
-        if (idx < n_y) {
-            const int j = (int)(idx % w);
-            const int i = (int)((idx / w) % h);
-            const int c = (int)((idx / ((int64_t)w * h)) % C1);
-            const int b = (int)(idx / ((int64_t)w * h * C1));
-            const float* gp = g_out + ((int64_t)b * C + c) * plane;
-            const float acc = fold2d(gp, 2 * i, 2 * j, H, W) + fold2d(gp, 2 * i, 2 * j + 1, H, W) +
-                              fold2d(gp, 2 * i + 1, 2 * j, H, W) + fold2d(gp, 2 * i + 1, 2 * j + 1, H, W);
-            g_y[idx] = acc * elu_grad(y[idx]);
-        } else if (g_skip) {
-            const int64_t k = idx - n_y;
-            const int X = (int)(k % W);
-            const int Y = (int)((k / W) % H);
-            const int c = (int)((k / ((int64_t)W * H)) % C2);
-            const int b = (int)(k / ((int64_t)W * H * C2));
-            g_skip[k] = fold2d(g_out + ((int64_t)b * C + C1 + c) * plane, Y, X, H, W);
-        }
+    const size_t pplane = (size_t)(H + 2) * (W + 2);
+    const int t = blockIdx.x * NT + threadIdx.x;
+    const int plane = blockIdx.y;
+    if (plane < B * C1) {
+        if (t >= h * w) return;
+        const int b = plane / C1, c = plane - b * C1;
+        const int i = t / w, j = t - i * w;
+        const float* gp = g_out + (size_t)(b * C + c) * pplane;
+        const float acc = fold2d(gp, 2 * i, 2 * j, H, W) + fold2d(gp, 2 * i, 2 * j + 1, H, W) +
+                          fold2d(gp, 2 * i + 1, 2 * j, H, W) + fold2d(gp, 2 * i + 1, 2 * j + 1, H, W);
+        const size_t o = (size_t)plane * h * w + t;
+        g_y[o] = acc * elu_grad(y[o]);
+    } else {
+        const int idx = t * 2;   // W = 2w is even
+        if (idx >= H * W) return;
+        const int q = plane - B * C1, b = q / C2, c = q - b * C2;
+        const int Y = idx / W, X = idx - Y * W;
+        const float* gp = g_out + (size_t)(b * C + C1 + c) * pplane;
+        *reinterpret_cast<float2*>(g_skip + (size_t)q * H * W + idx) =
+            make_float2(fold2d(gp, Y, X, H, W), fold2d(gp, Y, X + 1, H, W));
     }
 }
 
-__global__ __launch_bounds__(NT) void elu_pad_fwd_kernel(const float* __restrict__ z, int C, int H, int W, int apply_elu,
-                                                         float* __restrict__ out, int64_t total) {
+template <bool VEC2>
+__global__ __launch_bounds__(NT) void elu_pad_fwd_kernel(const float* __restrict__ z, int H, int W, int apply_elu,
+                                                         float* __restrict__ out) {
     const int PH = H + 2, PW = W + 2;
-    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NT) {
-        const int px = (int)(idx % PW);
-        const int py = (int)((idx / PW) % PH);
-        const int64_t bc = idx / ((int64_t)PW * PH);
-        const float v = z[(bc * H + reflect_idx(py - 1, H)) * W + reflect_idx(px - 1, W)];
-        out[idx] = apply_elu ? elu_f(v) : v;
+    const float* zp = z + (size_t)blockIdx.y * H * W;
+    float* op = out + (size_t)blockIdx.y * PH * PW;
+    if (VEC2) {
+        const int idx = (blockIdx.x * NT + threadIdx.x) * 2;
+        if (idx >= PH * PW) return;
+        const int py = idx / PW, px = idx - py * PW;
+        const float* row = zp + (size_t)reflect_idx(py - 1, H) * W;
+        float v0 = row[reflect_idx(px - 1, W)], v1 = row[reflect_idx(px, W)];
+        if (apply_elu) {
+            v0 = elu_f(v0);
+            v1 = elu_f(v1);
+        }
+        *reinterpret_cast<float2*>(op + idx) = make_float2(v0, v1);
+    } else {
+        const int idx = blockIdx.x * NT + threadIdx.x;
+        if (idx >= PH * PW) return;
+        const int py = idx / PW, px = idx - py * PW;
+        const float v = zp[(size_t)reflect_idx(py - 1, H) * W + reflect_idx(px - 1, W)];
+        op[idx] = apply_elu ? elu_f(v) : v;
     }
 }
 
+template <bool VEC2>
 __global__ __launch_bounds__(NT) void elu_pad_bwd_kernel(const float* __restrict__ z, const float* __restrict__ g_out,
-                                                         int H, int W, int apply_elu, float* __restrict__ g_z,
-                                                         int64_t total) {
-    const int64_t plane = (int64_t)(H + 2) * (W + 2);
-    for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * NT) {
-        const int X = (int)(idx % W);
-        const int Y = (int)((idx / W) % H);
-        const int64_t bc = idx / ((int64_t)W * H);
-        const float g = fold2d(g_out + bc * plane, Y, X, H, W);
-        g_z[idx] = apply_elu ? g * elu_grad(z[idx]) : g;
+                                                         int H, int W, int apply_elu, float* __restrict__ g_z) {
+    const float* gp = g_out + (size_t)blockIdx.y * (H + 2) * (W + 2);
+    const size_t base = (size_t)blockIdx.y * H * W;
+    if (VEC2) {
+        const int idx = (blockIdx.x * NT + threadIdx.x) * 2;
+        if (idx >= H * W) return;
+        const int Y = idx / W, X = idx - Y * W;
+        float g0 = fold2d(gp, Y, X, H, W), g1 = fold2d(gp, Y, X + 1, H, W);
+        if (apply_elu) {
+            const float2 zz = *reinterpret_cast<const float2*>(z + base + idx);
+            g0 *= elu_grad(zz.x);
+            g1 *= elu_grad(zz.y);
+        }
+        *reinterpret_cast<float2*>(g_z + base + idx) = make_float2(g0, g1);
+    } else {
+        const int idx = blockIdx.x * NT + threadIdx.x;
+        if (idx >= H * W) return;
+        const int Y = idx / W, X = idx - Y * W;
+        const float g = fold2d(gp, Y, X, H, W);
+        g_z[base + idx] = apply_elu ? g * elu_grad(z[base + idx]) : g;
     }
 }
 
-inline int grid_for(int64_t n) {
-    const int64_t b = (n + NT - 1) / NT;
-    return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
-}
+inline unsigned blocks_for(int n) { return (unsigned)((n + NT - 1) / NT); }
 
 }  // namespace
 
@@ -122,9 +155,9 @@ int dmh_dec_up_cat_pad_fwd(const float* y, const float* skip, int B, int C1, int
                            void* stream) {
     DMH_REQUIRE(y && out && (skip || C2 == 0), "null pointer");
     DMH_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && h >= 1 && w >= 1, "bad sizes");
-    const int64_t total = (int64_t)B * (C1 + C2) * (2 * h + 2) * (2 * w + 2);
-    hipLaunchKernelGGL(up_cat_pad_fwd_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, y, skip, C1, C2, h,
-                       w, out, total);
+    DMH_REQUIRE((int64_t)B * (C1 + C2) <= 65535 && (int64_t)(2 * h + 2) * (2 * w + 2) < (1 << 30), "tensor too large");
+    hipLaunchKernelGGL(up_cat_pad_fwd_kernel<true>, dim3(blocks_for((h + 1) * (2 * w + 2)), B * (C1 + C2)), dim3(NT), 0,
+                       (hipStream_t)stream, y, skip, C1, C2, h, w, out);
     return check_launch("dmh_dec_up_cat_pad_fwd");
 }
 
@@ -132,18 +165,24 @@ int dmh_dec_up_cat_pad_bwd(const float* y, const float* g_out, int B, int C1, in
                            float* g_skip, void* stream) {
     DMH_REQUIRE(y && g_out && g_y, "null pointer");
     DMH_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && h >= 1 && w >= 1, "bad sizes");
-    const int64_t n_y = (int64_t)B * C1 * h * w, n_skip = g_skip ? (int64_t)B * C2 * 4 * h * w : 0;
-    hipLaunchKernelGGL(up_cat_pad_bwd_kernel, dim3(grid_for(n_y + n_skip)), dim3(NT), 0, (hipStream_t)stream, y, g_out,
-                       C1, C2, h, w, g_y, g_skip, n_y, n_skip);
+    const int planes = B * C1 + (g_skip ? B * C2 : 0);
+    DMH_REQUIRE(planes <= 65535 && (int64_t)(2 * h + 2) * (2 * w + 2) < (1 << 30), "tensor too large");
+    const int per_plane = (g_skip && C2 > 0) ? 2 * h * w : h * w;   // threads: one per g_y element / per g_skip pair
+    hipLaunchKernelGGL(up_cat_pad_bwd_kernel<true>, dim3(blocks_for(per_plane), planes), dim3(NT), 0,
+                       (hipStream_t)stream, y, g_out, B, C1, C2, h, w, g_y, g_skip);
     return check_launch("dmh_dec_up_cat_pad_bwd");
 }
 
 int dmh_elu_pad_fwd(const float* z, int B, int C, int H, int W, int apply_elu, float* out, void* stream) {
     DMH_REQUIRE(z && out, "null pointer");
     DMH_REQUIRE(B > 0 && C > 0 && H >= 2 && W >= 2, "bad sizes");
-    const int64_t total = (int64_t)B * C * (H + 2) * (W + 2);
-    hipLaunchKernelGGL(elu_pad_fwd_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, z, C, H, W, apply_elu,
-                       out, total);
+    DMH_REQUIRE((int64_t)B * C <= 65535 && (int64_t)(H + 2) * (W + 2) < (1 << 30), "tensor too large");
+    if ((W & 1) == 0)
+        hipLaunchKernelGGL(elu_pad_fwd_kernel<true>, dim3(blocks_for((H + 2) * (W + 2) / 2), B * C), dim3(NT), 0,
+                           (hipStream_t)stream, z, H, W, apply_elu, out);
+    else
+        hipLaunchKernelGGL(elu_pad_fwd_kernel<false>, dim3(blocks_for((H + 2) * (W + 2)), B * C), dim3(NT), 0,
+                           (hipStream_t)stream, z, H, W, apply_elu, out);
     return check_launch("dmh_elu_pad_fwd");
 }
 
@@ -151,9 +190,13 @@ int dmh_elu_pad_bwd(const float* z, const float* g_out, int B, int C, int H, int
                     void* stream) {
     DMH_REQUIRE(z && g_out && g_z, "null pointer");
     DMH_REQUIRE(B > 0 && C > 0 && H >= 2 && W >= 2, "bad sizes");
-    const int64_t total = (int64_t)B * C * H * W;
-    hipLaunchKernelGGL(elu_pad_bwd_kernel, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream, z, g_out, H, W,
-                       apply_elu, g_z, total);
+    DMH_REQUIRE((int64_t)B * C <= 65535 && (int64_t)(H + 2) * (W + 2) < (1 << 30), "tensor too large");
+    if ((W & 1) == 0)
+        hipLaunchKernelGGL(elu_pad_bwd_kernel<true>, dim3(blocks_for(H * W / 2), B * C), dim3(NT), 0, (hipStream_t)stream,
+                           z, g_out, H, W, apply_elu, g_z);
+    else
+        hipLaunchKernelGGL(elu_pad_bwd_kernel<false>, dim3(blocks_for(H * W), B * C), dim3(NT), 0, (hipStream_t)stream,
+                           z, g_out, H, W, apply_elu, g_z);
     return check_launch("dmh_elu_pad_bwd");
 }
 

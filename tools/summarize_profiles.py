@@ -14,8 +14,9 @@ os.makedirs("profiles", exist_ok=True)
 
 
 def first(pattern):
-    m = glob.glob(pattern)
-    return m[0] if m else None
+    """Newest match (gpurun merges new runs into the same scratch directory next to older ones)."""
+    m = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return m[-1] if m else None
 
 
 ks = first(G + "k1_trace/*/*_kernel_stats.csv")
