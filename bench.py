@@ -88,6 +88,10 @@ def main():
     ap.add_argument("--atk_steps", type=int, default=10)
     ap.add_argument("--norm_type", type=str, default="l_inf", choices=["l_inf", "l_0"])
     ap.add_argument("--sync_attack", action="store_true")
+    # the other BASELINE.json configs (parity/regression cases, not the headline line)
+    ap.add_argument("--supervised_adv", action="store_true")
+    ap.add_argument("--contrastive_learning", action="store_true")
+    ap.add_argument("--loss_variant", type=str, default="md2", choices=["md2", "dh"])
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="also print a per-phase GPU-time breakdown to stderr")
     a = ap.parse_args()
@@ -111,6 +115,11 @@ def main():
             "--log_dir", os.path.join("/tmp", "dmh_bench_%d" % rank), "--synthetic_len", "1000000"]
     if a.sync_attack:
         argv.append("--sync_attack")
+    if a.supervised_adv:
+        argv.append("--supervised_adv")
+    if a.contrastive_learning:
+        argv.append("--contrastive_learning")
+    argv += ["--loss_variant", a.loss_variant]
     opts = MonodepthOptions().parse(argv)
     trainer = Trainer(opts, rank=rank, world_size=world, device=device)
     if int(os.environ.get("DMH_CHANNELS_LAST", "0")):   # experiment knob: NHWC activations for MIOpen
@@ -185,9 +194,12 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "Monodepth2 ResNet18 %dx%d, %d-step PGD-L_inf (%s) on 12 scenes, train batch %d/GPU, "
-                                      "stereo photometric+SSIM+smoothness loss, Adam" % (a.width, a.height, a.atk_steps,
-                                                                                       a.norm_type, a.batch_size),
+               "config": {"workload": "Monodepth2 ResNet18 %dx%d, %d-step %s attack on 12 scenes, train batch %d/GPU, "
+                                      "stereo photometric+SSIM+smoothness loss (%s)%s%s, Adam" % (
+                                          a.width, a.height, a.atk_steps,
+                                          "PGD-L_inf" if a.norm_type == "l_inf" else "L0/Adam", a.batch_size, a.loss_variant,
+                                          " + supervised_adv" if a.supervised_adv else "",
+                                          " + contrastive" if a.contrastive_learning else ""),
                           "global_batch": a.batch_size * world, "parallelism": "dp%d" % world,
                           "attack_overlap": bool(world > 1 and not a.sync_attack), "final_loss": round(loss_val, 6)},
                "roofline": roof}
