@@ -86,6 +86,14 @@ def lib():
     """The loaded library; raises loudly when it has not been built."""
     global _lib
     if _lib is None:
+        if not os.path.exists(LIB_PATH) and "DMH_HIP_LIB" not in os.environ:
+            try:    # fresh checkout on a box with hipcc: build in-tree once (seconds); never fall back to eager ops
+                from .build import build
+                build(verbose=False)
+            except Exception as e:
+                raise RuntimeError("libdmh_hip.so is not built (%s) and building it failed (%s): run `python -m "
+                                   "depthmodelhardening_amd.build`; there is no CPU/eager fallback for the hot path"
+                                   % (LIB_PATH, e))
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libdmh_hip.so is not built (%s): run `python -m depthmodelhardening_amd.build`; "
                                "there is no CPU/eager fallback for the hot path" % LIB_PATH)
