@@ -191,6 +191,7 @@ def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_de
     Returns LossOut(fin, sel, to_opt): fin[FIN_*] is differentiable w.r.t. the disparities.
     """
     F, NS = len(sources), len(disps)
+    N.ptr(target)   # rejects CPU tensors up front ("no CPU path") before any CUDA-only call below
     if not (1 <= F <= N.MAX_FRAMES and 1 <= NS <= N.MAX_SCALES):
         raise RuntimeError("photometric loss supports 1..4 source frames and 1..4 scales")
     if variant not in ("md2", "dh"):
