@@ -161,3 +161,36 @@ def test_evaluate_attacks_runs():
                  {"norm_type": "image", "epsilon": 0.03, "alpha": 2 / 255, "step": 1, "batch_size": 2}):
         err = evaluate_attacks(model, args, eval_count=2)
         assert err.shape == (8,) and np.isfinite(err).all() and 0 <= err[5] <= err[6] <= err[7] <= 1 + 1e-6
+
+
+def test_physicaltrans_project_surface_vs_oracle():
+    """PhysicalTrans.project / project_w_trans (physicalTrans.py:130-196) through K3's warp-only mode, incl. autograd."""
+    from depthmodelhardening_amd.physicalTrans import PhysicalTrans
+    ta, attack_ref, synth, obj, mask = _setup()
+    ref = attack_ref.PhysicalTransRef(obj.clone().requires_grad_(True), mask, dist_range=attack_ref.TRAIN_DIST_RANGE)
+    z0, al = [5.2, 8.8, 9.8], [-30, 0, 25]
+    o_ref, m_ref, _, _ = ref.project(batch_size=3, z0_sample=z0, alpha_sample=al)
+    patch = obj.cuda().requires_grad_(True)
+    pt = PhysicalTrans(patch, mask.cuda(), {"path": None}, (1, 3, 375, 1242), dist_range=list(np.arange(5, 10, 0.2)))
+    o, m, z0_out, al_out = pt.project(batch_size=3, z0_sample=z0, alpha_sample=al)
+    assert o.shape == (3, 3, 375, 1242) and m.shape == (3, 1, 375, 1242) and z0_out == z0 and al_out == al
+    # the patch is white noise (|grad| ~ 1/px): 1e-4 px of fp32 coordinate rounding shows up as ~1e-4 in the sample
+    assert_close_frac(o, o_ref, rtol=1e-4, atol=2e-4, max_bad_frac=1e-5, name="projected patch")
+    assert_close_frac(m, m_ref, rtol=1e-4, atol=2e-4, max_bad_frac=1e-5, name="projected mask")
+    w8 = torch.rand(o.shape, generator=torch.Generator().manual_seed(2))
+    (o * w8.cuda()).sum().backward()
+    (o_ref * w8).sum().backward()
+    assert_close_frac(patch.grad, ref.obj_img.grad, rtol=1e-3, atol=1e-4 * float(ref.obj_img.grad.abs().max()),
+                      max_bad_frac=1e-4, name="d project / d patch")
+    # stereo twin with Monodepth2 intrinsics and the 0.54 m baseline (mono_dataset.py:112-117,160-165)
+    K = np.array([[0.58 * 1242, 0, 0.5 * 1242, 0], [0, 1.92 * 375, 0.5 * 375, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    T = np.eye(4, dtype=np.float32)
+    T[0, 3] = -0.54
+    o2, m2 = pt.project_w_trans(T, z0, al, K=K)
+    o2_ref, m2_ref, _, _ = ref.project(batch_size=3, z0_sample=z0, alpha_sample=al, K=K, T=T)
+    assert_close_frac(o2, o2_ref, rtol=1e-4, atol=2e-4, max_bad_frac=1e-5, name="project_w_trans")
+    assert_close_frac(m2, m2_ref, rtol=1e-4, atol=2e-4, max_bad_frac=1e-5, name="project_w_trans mask")
+    random.seed(9)
+    _, _, zs, als = pt.project(batch_size=12)
+    random.seed(9)
+    assert zs == random.sample(pt.dist_range, 12) and als == random.sample(pt.angle_range, 12)
