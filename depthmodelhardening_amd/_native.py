@@ -75,6 +75,10 @@ _SIGNATURES = {
     "dmh_dec_up_cat_pad_bwd": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp, _fp]),
     "dmh_elu_pad_fwd": (C.c_int, [_fp] + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_elu_pad_bwd": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp]),
+    "dmh_bn_act_fwd": (C.c_int, [_fp] * 4 + [C.c_int] * 4 + [_fp, _fp]),
+    "dmh_bn_act_bwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp, _fp, _fp]),
+    "dmh_stem_bn_relu_pool_fwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp] * 4),
+    "dmh_stem_bn_relu_pool_bwd": (C.c_int, [_fp] * 5 + [C.c_int] * 4 + [_fp, _fp]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))
@@ -112,14 +116,14 @@ def check(rc):
 
 
 def ptr(t):
-    """Device pointer of a contiguous fp32 (or int32) CUDA tensor; None -> NULL."""
+    """Device pointer of a contiguous fp32 (or int32 / uint8 index) CUDA tensor; None -> NULL."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("libdmh_hip ops need CUDA (ROCm) tensors; got device %s -- there is no CPU path" % t.device)
     if not t.is_contiguous():
         raise RuntimeError("libdmh_hip ops need contiguous tensors")
-    if t.dtype not in (torch.float32, torch.int32):
+    if t.dtype not in (torch.float32, torch.int32, torch.uint8):
         raise RuntimeError("libdmh_hip ops compute in fp32; got %s" % t.dtype)
     return C.c_void_p(t.data_ptr())
 

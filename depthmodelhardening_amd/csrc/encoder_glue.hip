@@ -1,0 +1,259 @@
+// Encoder glue (K9) -- the element-wise passes between the MIOpen convolutions of the ResNet encoder while the
+// model is in eval() mode, i.e. inside every PGD / L0 attack step (10 of the 11 forward+backward passes of one
+// adversarial-training step; the attack bracket torchattacks/attack.py:165-182 switches the model to eval).
+//
+// Reference: MD2/networks/resnet_encoder.py:85-98 runs torchvision's ResNet: conv -> BatchNorm2d -> ReLU
+// (-> MaxPool2d 3x3/2 in the stem) and, per BasicBlock, conv -> bn -> relu -> conv -> bn -> (+identity) -> relu, each
+// as its own full-tensor pass (BN-inference, clamp, add, max-pool + their four backward kernels).  With running
+// statistics BatchNorm is the per-channel affine  x * scale[c] + shift[c]
+// (scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale), so each group is ONE pass:
+//
+//   bn_act        : out = act( x * scale[c] + shift[c] (+ residual) )               act = ReLU or identity
+//   stem          : feat = ReLU(x * scale[c] + shift[c]);  pooled = maxpool3x3/2(feat);  argmax (0..8) kept as u8
+//
+// Backward kernels are gathers (the max-pool adjoint looks its <= 4 covering windows up through the stored argmax):
+// deterministic, no atomics.  Pure HBM streaming, 16-byte accesses where the row length allows.
+#include "common.hpp"
+
+#include <cmath>
+
+using namespace dmh;
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float relu_f(float v) { return v > 0.f ? v : 0.f; }
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_act_fwd_vec(const float4* __restrict__ x, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, const float4* __restrict__ res,
+                                                     unsigned C, unsigned hw4, unsigned total4, float4* __restrict__ out) {
+    const unsigned i = blockIdx.x * NT + threadIdx.x;
+    if (i >= total4) return;
+    const unsigned c = (i / hw4) % C;
+    const float s = scale[c], b = shift[c];
+    const float4 v = x[i];
+    float4 r = make_float4(fmaf(v.x, s, b), fmaf(v.y, s, b), fmaf(v.z, s, b), fmaf(v.w, s, b));
+    if (RES) {
+        const float4 q = res[i];
+        r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+    }
+    if (RELU) r = make_float4(relu_f(r.x), relu_f(r.y), relu_f(r.z), relu_f(r.w));
+    out[i] = r;
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_act_fwd_scalar(const float* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, const float* __restrict__ res,
+                                                        unsigned C, unsigned hw, unsigned total, float* __restrict__ out) {
+    const unsigned i = blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    const unsigned c = (i / hw) % C;
+    float r = fmaf(x[i], scale[c], shift[c]);
+    if (RES) r += res[i];
+    out[i] = RELU ? relu_f(r) : r;
+}
+
+// g_res = RELU ? g * [out > 0] : g ;   g_x = g_res * scale[c]
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_act_bwd_vec(const float4* __restrict__ out, const float4* __restrict__ g,
+                                                     const float* __restrict__ scale, unsigned C, unsigned hw4,
+                                                     unsigned total4, float4* __restrict__ g_x, float4* __restrict__ g_res) {
+    const unsigned i = blockIdx.x * NT + threadIdx.x;
+    if (i >= total4) return;
+    const float s = scale[(i / hw4) % C];
+    float4 gv = g[i];
+    if (RELU) {
+        const float4 o = out[i];
+        gv = make_float4(o.x > 0.f ? gv.x : 0.f, o.y > 0.f ? gv.y : 0.f, o.z > 0.f ? gv.z : 0.f, o.w > 0.f ? gv.w : 0.f);
+    }
+    if (RES) g_res[i] = gv;
+    g_x[i] = make_float4(gv.x * s, gv.y * s, gv.z * s, gv.w * s);
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_act_bwd_scalar(const float* __restrict__ out, const float* __restrict__ g,
+                                                        const float* __restrict__ scale, unsigned C, unsigned hw,
+                                                        unsigned total, float* __restrict__ g_x, float* __restrict__ g_res) {
+    const unsigned i = blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    float gv = g[i];
+    if (RELU) gv = out[i] > 0.f ? gv : 0.f;
+    if (RES) g_res[i] = gv;
+    g_x[i] = gv * scale[(i / hw) % C];
+}
+
+// Stem.  One thread per pooled output (i, j): it owns the 2x2 quad rows {2i, 2i+1} x cols {2j, 2j+1} of the
+// activation and its 3x3 window rows 2i-1..2i+1, cols 2j-1..2j+1 (H, W even, so only the top/left edges clip).
+// The argmax follows at::native max_pool_forward_nchw: scan ky, kx ascending, replace on strictly greater.
+__global__ __launch_bounds__(NT) void stem_fwd_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int C, int H, int W,
+                                                      float* __restrict__ feat, float* __restrict__ pooled,
+                                                      unsigned char* __restrict__ argmax) {
+    const int PH = H >> 1, PW = W >> 1;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if (t >= PH * PW) return;
+    const int plane = blockIdx.y, c = plane % C;
+    const int i = t / PW, j = t - i * PW;
+    const float s = scale[c], b = shift[c];
+    const float* xp = x + (size_t)plane * H * W;
+    float* fp = feat + (size_t)plane * H * W;
+    float m = -INFINITY;
+    int arg = 4;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int yy = 2 * i - 1 + ky;
+        if (yy < 0) continue;
+        const float* row = xp + (size_t)yy * W + 2 * j;
+        const float2 vc = *reinterpret_cast<const float2*>(row);
+        const float a1 = relu_f(fmaf(vc.x, s, b)), a2 = relu_f(fmaf(vc.y, s, b));
+        if (j > 0) {
+            const float a0 = relu_f(fmaf(row[-1], s, b));
+            if (a0 > m) { m = a0; arg = ky * 3; }
+        }
+        if (a1 > m) { m = a1; arg = ky * 3 + 1; }
+        if (a2 > m) { m = a2; arg = ky * 3 + 2; }
+        if (ky >= 1) *reinterpret_cast<float2*>(fp + (size_t)yy * W + 2 * j) = make_float2(a1, a2);
+    }
+    const size_t o = (size_t)plane * PH * PW + t;
+    pooled[o] = m;
+    argmax[o] = (unsigned char)arg;
+}
+
+// g_x = scale[c] * [feat > 0] * ( g_feat + sum over covering windows whose argmax is this pixel of g_pool )
+__global__ __launch_bounds__(NT) void stem_bwd_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ argmax,
+                                                      const float* __restrict__ g_feat, const float* __restrict__ g_pool,
+                                                      const float* __restrict__ scale, int C, int H, int W,
+                                                      float* __restrict__ g_x) {
+    const int PH = H >> 1, PW = W >> 1;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if (t >= PH * PW) return;
+    const int plane = blockIdx.y, c = plane % C;
+    const int i = t / PW, j = t - i * PW;
+    const size_t base = (size_t)plane * H * W, pbase = (size_t)plane * PH * PW;
+    float acc[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (g_pool) {
+#pragma unroll
+        for (int di = 0; di < 2; ++di) {
+            const int oi = i + di;
+            if (oi >= PH) continue;
+#pragma unroll
+            for (int dj = 0; dj < 2; ++dj) {
+                const int oj = j + dj;
+                if (oj >= PW) continue;
+                const int a = argmax[pbase + (size_t)oi * PW + oj];
+                const int ky = a / 3, kx = a - ky * 3;
+                const int ry = 2 * di - 1 + ky, rx = 2 * dj - 1 + kx;   // position relative to the quad origin
+                if (ry >= 0 && ry < 2 && rx >= 0 && rx < 2) {
+                    const float gp = g_pool[pbase + (size_t)oi * PW + oj];
+                    // compile-time indices keep acc in registers
+                    if (ry == 0 && rx == 0) acc[0][0] += gp;
+                    if (ry == 0 && rx == 1) acc[0][1] += gp;
+                    if (ry == 1 && rx == 0) acc[1][0] += gp;
+                    if (ry == 1 && rx == 1) acc[1][1] += gp;
+                }
+            }
+        }
+    }
+    const float s = scale[c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const size_t o = base + (size_t)(2 * i + r) * W + 2 * j;
+        const float2 f = *reinterpret_cast<const float2*>(feat + o);
+        float g0 = acc[r][0], g1 = acc[r][1];
+        if (g_feat) {
+            const float2 gf = *reinterpret_cast<const float2*>(g_feat + o);
+            g0 += gf.x;
+            g1 += gf.y;
+        }
+        *reinterpret_cast<float2*>(g_x + o) = make_float2(f.x > 0.f ? g0 * s : 0.f, f.y > 0.f ? g1 * s : 0.f);
+    }
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + NT - 1) / NT); }
+
+template <bool RELU, bool RES>
+void launch_fwd(const float* x, const float* scale, const float* shift, const float* res, int C, int HW, int64_t total,
+                float* out, hipStream_t st) {
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL((bn_act_fwd_vec<RELU, RES>), dim3(blocks_for(total / 4)), dim3(NT), 0, st,
+                           reinterpret_cast<const float4*>(x), scale, shift, reinterpret_cast<const float4*>(res),
+                           (unsigned)C, (unsigned)(HW / 4), (unsigned)(total / 4), reinterpret_cast<float4*>(out));
+    else
+        hipLaunchKernelGGL((bn_act_fwd_scalar<RELU, RES>), dim3(blocks_for(total)), dim3(NT), 0, st, x, scale, shift, res,
+                           (unsigned)C, (unsigned)HW, (unsigned)total, out);
+}
+
+template <bool RELU, bool RES>
+void launch_bwd(const float* out, const float* g, const float* scale, int C, int HW, int64_t total, float* g_x,
+                float* g_res, hipStream_t st) {
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL((bn_act_bwd_vec<RELU, RES>), dim3(blocks_for(total / 4)), dim3(NT), 0, st,
+                           reinterpret_cast<const float4*>(out), reinterpret_cast<const float4*>(g), scale, (unsigned)C,
+                           (unsigned)(HW / 4), (unsigned)(total / 4), reinterpret_cast<float4*>(g_x),
+                           reinterpret_cast<float4*>(g_res));
+    else
+        hipLaunchKernelGGL((bn_act_bwd_scalar<RELU, RES>), dim3(blocks_for(total)), dim3(NT), 0, st, out, g, scale,
+                           (unsigned)C, (unsigned)HW, (unsigned)total, g_x, g_res);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmh_bn_act_fwd(const float* x, const float* scale, const float* shift, const float* residual, int B, int C, int HW,
+                   int relu, float* out, void* stream) {
+    DMH_REQUIRE(x && scale && shift && out, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && HW > 0, "bad sizes");
+    const int64_t total = (int64_t)B * C * HW;
+    DMH_REQUIRE(total < ((int64_t)1 << 31), "tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) {
+        if (residual) launch_fwd<true, true>(x, scale, shift, residual, C, HW, total, out, st);
+        else launch_fwd<true, false>(x, scale, shift, nullptr, C, HW, total, out, st);
+    } else {
+        if (residual) launch_fwd<false, true>(x, scale, shift, residual, C, HW, total, out, st);
+        else launch_fwd<false, false>(x, scale, shift, nullptr, C, HW, total, out, st);
+    }
+    return check_launch("dmh_bn_act_fwd");
+}
+
+int dmh_bn_act_bwd(const float* out, const float* g_out, const float* scale, int B, int C, int HW, int relu, float* g_x,
+                   float* g_residual, void* stream) {
+    DMH_REQUIRE(g_out && scale && g_x && (out || !relu), "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && HW > 0, "bad sizes");
+    const int64_t total = (int64_t)B * C * HW;
+    DMH_REQUIRE(total < ((int64_t)1 << 31), "tensor too large");
+    hipStream_t st = (hipStream_t)stream;
+    if (relu) {
+        if (g_residual) launch_bwd<true, true>(out, g_out, scale, C, HW, total, g_x, g_residual, st);
+        else launch_bwd<true, false>(out, g_out, scale, C, HW, total, g_x, nullptr, st);
+    } else {
+        if (g_residual) launch_bwd<false, true>(out, g_out, scale, C, HW, total, g_x, g_residual, st);
+        else launch_bwd<false, false>(out, g_out, scale, C, HW, total, g_x, nullptr, st);
+    }
+    return check_launch("dmh_bn_act_bwd");
+}
+
+int dmh_stem_bn_relu_pool_fwd(const float* x, const float* scale, const float* shift, int B, int C, int H, int W,
+                              float* feat, float* pooled, unsigned char* argmax, void* stream) {
+    DMH_REQUIRE(x && scale && shift && feat && pooled && argmax, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "H and W must be even and >= 2");
+    DMH_REQUIRE((int64_t)B * C <= 65535 && (int64_t)H * W < (1 << 30), "tensor too large");
+    hipLaunchKernelGGL(stem_fwd_kernel, dim3(blocks_for((int64_t)(H / 2) * (W / 2)), B * C), dim3(NT), 0,
+                       (hipStream_t)stream, x, scale, shift, C, H, W, feat, pooled, argmax);
+    return check_launch("dmh_stem_bn_relu_pool_fwd");
+}
+
+int dmh_stem_bn_relu_pool_bwd(const float* feat, const unsigned char* argmax, const float* g_feat, const float* g_pooled,
+                              const float* scale, int B, int C, int H, int W, float* g_x, void* stream) {
+    DMH_REQUIRE(feat && argmax && scale && g_x, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "H and W must be even and >= 2");
+    DMH_REQUIRE((int64_t)B * C <= 65535 && (int64_t)H * W < (1 << 30), "tensor too large");
+    hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks_for((int64_t)(H / 2) * (W / 2)), B * C), dim3(NT), 0,
+                       (hipStream_t)stream, feat, argmax, g_feat, g_pooled, scale, C, H, W, g_x);
+    return check_launch("dmh_stem_bn_relu_pool_bwd");
+}
+
+}  // extern "C"

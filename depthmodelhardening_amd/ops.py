@@ -28,17 +28,25 @@ def profile_ms():
     if not _profile:
         return {}
     torch.cuda.synchronize()
-    return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in _profile.items() if v}
+    return {k: sum(a.elapsed_time(b) for a, b, _ in v) / len(v) for k, v in _profile.items() if v}
 
 
-def _timed(name, launch):
+def profile_bytes():
+    """Per instrumented kernel: (launches, total ms, total algorithmic bytes) -- for kernels whose shape varies."""
+    if not _profile:
+        return {}
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v), sum(n for _, _, n in v)) for k, v in _profile.items() if v}
+
+
+def _timed(name, launch, nbytes=0):
     if _profile is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = launch()
     e1.record()
-    _profile.setdefault(name, []).append((e0, e1))
+    _profile.setdefault(name, []).append((e0, e1, nbytes))
     return rc
 
 
@@ -430,7 +438,9 @@ class _UpCatPad(torch.autograd.Function):
         if skip is not None and tuple(skip.shape) != (B, C2, 2 * h, 2 * w):
             raise RuntimeError("up_cat_pad: skip must be [B,C2,2h,2w], got %s for y %s" % (tuple(skip.shape), tuple(y.shape)))
         out = torch.empty((B, C1 + C2, 2 * h + 2, 2 * w + 2), device=y.device, dtype=torch.float32)
-        N.check(lib.dmh_dec_up_cat_pad_fwd(N.ptr(y), N.ptr(skip), B, C1, C2, h, w, N.ptr(out), N.stream()))
+        nb = 4 * (y.numel() + (0 if skip is None else skip.numel()) + out.numel())
+        N.check(_timed("up_cat_pad_fwd", lambda: lib.dmh_dec_up_cat_pad_fwd(N.ptr(y), N.ptr(skip), B, C1, C2, h, w,
+                                                                           N.ptr(out), N.stream()), nb))
         ctx.save_for_backward(y)
         ctx.c2 = C2
         ctx.skip_grad = skip is not None and skip.requires_grad
@@ -443,8 +453,10 @@ class _UpCatPad(torch.autograd.Function):
         B, C1, h, w = y.shape
         g_y = torch.empty_like(y)
         g_skip = torch.empty((B, ctx.c2, 2 * h, 2 * w), device=y.device, dtype=torch.float32) if ctx.skip_grad else None
-        N.check(lib.dmh_dec_up_cat_pad_bwd(N.ptr(y), N.ptr(_c(g_out)), B, C1, ctx.c2, h, w, N.ptr(g_y), N.ptr(g_skip),
-                                           N.stream()))
+        g_out = _c(g_out)
+        nb = 4 * (2 * y.numel() + g_out.numel() + (0 if g_skip is None else g_skip.numel()))
+        N.check(_timed("up_cat_pad_bwd", lambda: lib.dmh_dec_up_cat_pad_bwd(N.ptr(y), N.ptr(g_out), B, C1, ctx.c2, h, w,
+                                                                           N.ptr(g_y), N.ptr(g_skip), N.stream()), nb))
         return g_y, g_skip
 
 
@@ -460,7 +472,8 @@ class _EluPad(torch.autograd.Function):
         lib = N.lib()
         B, Cc, H, W = z.shape
         out = torch.empty((B, Cc, H + 2, W + 2), device=z.device, dtype=torch.float32)
-        N.check(lib.dmh_elu_pad_fwd(N.ptr(z), B, Cc, H, W, int(apply_elu), N.ptr(out), N.stream()))
+        N.check(_timed("elu_pad_fwd", lambda: lib.dmh_elu_pad_fwd(N.ptr(z), B, Cc, H, W, int(apply_elu), N.ptr(out),
+                                                                 N.stream()), 4 * (z.numel() + out.numel())))
         ctx.save_for_backward(z)
         ctx.apply_elu = int(apply_elu)
         return out
@@ -471,13 +484,101 @@ class _EluPad(torch.autograd.Function):
         lib = N.lib()
         B, Cc, H, W = z.shape
         g_z = torch.empty_like(z)
-        N.check(lib.dmh_elu_pad_bwd(N.ptr(z), N.ptr(_c(g_out)), B, Cc, H, W, ctx.apply_elu, N.ptr(g_z), N.stream()))
+        g_out = _c(g_out)
+        N.check(_timed("elu_pad_bwd", lambda: lib.dmh_elu_pad_bwd(N.ptr(z), N.ptr(g_out), B, Cc, H, W, ctx.apply_elu,
+                                                                 N.ptr(g_z), N.stream()), 4 * (2 * z.numel() + g_out.numel())))
         return g_z, None
 
 
 def elu_pad(z, apply_elu=True):
     """pad1_reflect(ELU(z)) in one pass (apply_elu=False: ReflectionPad2d(1) only)."""
     return _EluPad.apply(_c(z), bool(apply_elu))
+
+
+class _BnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift, residual, relu):
+        lib = N.lib()
+        B, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * Cc)
+        if scale.numel() != Cc or shift.numel() != Cc:
+            raise RuntimeError("bn_act: scale/shift must have %d entries" % Cc)
+        if residual is not None and residual.shape != x.shape:
+            raise RuntimeError("bn_act: residual %s does not match x %s" % (tuple(residual.shape), tuple(x.shape)))
+        out = torch.empty_like(x)
+        nb = 4 * (x.numel() * (2 if residual is None else 3))
+        N.check(_timed("bn_act_fwd", lambda: lib.dmh_bn_act_fwd(N.ptr(x), N.ptr(scale), N.ptr(shift), N.ptr(residual), B,
+                                                               Cc, HW, int(relu), N.ptr(out), N.stream()), nb))
+        ctx.save_for_backward(out if relu else None, scale)
+        ctx.relu = int(relu)
+        ctx.res_grad = residual is not None and residual.requires_grad
+        ctx.x_grad = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        out, scale = ctx.saved_tensors
+        lib = N.lib()
+        g_out = _c(g_out)
+        B, Cc = g_out.shape[0], g_out.shape[1]
+        HW = g_out.numel() // (B * Cc)
+        g_x = torch.empty_like(g_out)
+        g_res = torch.empty_like(g_out) if ctx.res_grad else None
+        nb = 4 * g_out.numel() * (2 + (1 if ctx.relu else 0) + (1 if ctx.res_grad else 0))
+        N.check(_timed("bn_act_bwd", lambda: lib.dmh_bn_act_bwd(N.ptr(out), N.ptr(g_out), N.ptr(scale), B, Cc, HW, ctx.relu,
+                                                               N.ptr(g_x), N.ptr(g_res), N.stream()), nb))
+        return g_x, None, None, g_res, None
+
+
+def bn_act(x, scale, shift, residual=None, relu=True):
+    """act(x * scale[c] + shift[c] (+ residual)) in one pass: BatchNorm2d in eval() mode folded to its per-channel
+    affine, the BasicBlock's identity add and the ReLU (torchvision BasicBlock.forward as used by
+    MD2/networks/resnet_encoder.py:85-98).  No gradient flows to scale/shift (eval-mode statistics and affine
+    parameters are constants of the attack; phy_obj_atk.py:96 differentiates w.r.t. the patch only)."""
+    return _BnAct.apply(_c(x), _c(scale.detach()), _c(shift.detach()), None if residual is None else _c(residual),
+                        bool(relu))
+
+
+class _StemBnReluPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        lib = N.lib()
+        B, Cc, H, W = x.shape
+        feat = torch.empty_like(x)
+        pooled = torch.empty((B, Cc, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        arg = torch.empty((B, Cc, H // 2, W // 2), device=x.device, dtype=torch.uint8)
+        nb = 4 * (2 * x.numel() + pooled.numel()) + arg.numel()
+        N.check(_timed("stem_fwd", lambda: lib.dmh_stem_bn_relu_pool_fwd(N.ptr(x), N.ptr(scale), N.ptr(shift), B, Cc, H, W,
+                                                                        N.ptr(feat), N.ptr(pooled), N.ptr(arg),
+                                                                        N.stream()), nb))
+        ctx.save_for_backward(feat, arg, scale)
+        ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)    # an unused output hands None to backward: the kernel skips that read
+        return feat, pooled, arg
+
+    @staticmethod
+    def backward(ctx, g_feat, g_pooled, _g_arg):
+        feat, arg, scale = ctx.saved_tensors
+        if g_feat is None and g_pooled is None:
+            return None, None, None
+        lib = N.lib()
+        B, Cc, H, W = feat.shape
+        g_feat = None if g_feat is None else _c(g_feat)
+        g_pooled = None if g_pooled is None else _c(g_pooled)
+        g_x = torch.empty_like(feat)
+        nb = 4 * (2 * feat.numel() + (0 if g_feat is None else feat.numel()) +
+                  (0 if g_pooled is None else g_pooled.numel())) + arg.numel()
+        N.check(_timed("stem_bwd", lambda: lib.dmh_stem_bn_relu_pool_bwd(N.ptr(feat), N.ptr(arg), N.ptr(g_feat),
+                                                                        N.ptr(g_pooled), N.ptr(scale), B, Cc, H, W,
+                                                                        N.ptr(g_x), N.stream()), nb))
+        return g_x, None, None
+
+
+def stem_bn_relu_pool(x, scale, shift):
+    """(ReLU(BN_eval(x)), MaxPool2d(3, 2, 1) of it) in one pass -- the encoder stem of
+    MD2/networks/resnet_encoder.py:88-91 (features[0] and the input of layer1).  H and W must be even."""
+    feat, pooled, _ = _StemBnReluPool.apply(_c(x), _c(scale.detach()), _c(shift.detach()))
+    return feat, pooled
 
 
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,

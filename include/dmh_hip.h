@@ -228,6 +228,28 @@ int dmh_elu_pad_fwd(const float* z, int B, int C, int H, int W, int apply_elu, f
 int dmh_elu_pad_bwd(const float* z, const float* g_out, int B, int C, int H, int W, int apply_elu, float* g_z,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K9  encoder glue: the element-wise passes between the MIOpen convolutions of the ResNet encoder while the model
+ *     is in eval() mode (every attack step: torchattacks/attack.py:165-182 brackets the attack with model.eval()).
+ *     Replaces, in MD2/networks/resnet_encoder.py:85-98 / torchvision BasicBlock.forward, the chains
+ *     BatchNorm2d(eval) -> [+ identity] -> ReLU and, in the stem, BatchNorm2d(eval) -> ReLU -> MaxPool2d(3, 2, 1).
+ *     scale[c] = weight / sqrt(running_var + eps), shift[c] = bias - running_mean * scale (computed by the caller).
+ *   bn_act : out[B,C,HW] = act(x * scale[c] + shift[c] (+ residual)),  act = ReLU when relu != 0.  residual may be NULL.
+ *            bwd: g_residual = relu ? g_out * [out > 0] : g_out (written when non-NULL);  g_x = g_residual * scale[c].
+ *            `out` may be NULL in the backward when relu == 0.
+ *   stem   : feat[B,C,H,W] = ReLU(x * scale[c] + shift[c]); pooled[B,C,H/2,W/2] = maxpool3x3/2/1(feat);
+ *            argmax[B,C,H/2,W/2] (u8, ky*3+kx, first maximum in scan order as ATen's max_pool2d).  H, W even.
+ *            bwd: g_x = scale[c] * [feat > 0] * (g_feat + maxpool_adjoint(g_pooled));  either gradient may be NULL.
+ * ---------------------------------------------------------------------------------- */
+int dmh_bn_act_fwd(const float* x, const float* scale, const float* shift, const float* residual, int B, int C, int HW,
+                   int relu, float* out, void* stream);
+int dmh_bn_act_bwd(const float* out, const float* g_out, const float* scale, int B, int C, int HW, int relu, float* g_x,
+                   float* g_residual, void* stream);
+int dmh_stem_bn_relu_pool_fwd(const float* x, const float* scale, const float* shift, int B, int C, int H, int W,
+                              float* feat, float* pooled, unsigned char* argmax, void* stream);
+int dmh_stem_bn_relu_pool_bwd(const float* feat, const unsigned char* argmax, const float* g_feat, const float* g_pooled,
+                              const float* scale, int B, int C, int H, int W, float* g_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

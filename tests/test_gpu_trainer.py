@@ -160,6 +160,102 @@ def test_glue_ops_small_shapes():
                                    torch.autograd.grad((ref * w8).sum(), z)[0], rtol=1e-5, atol=1e-6)
 
 
+def test_encoder_glue_ops_vs_aten():
+    """ops.bn_act / ops.stem_bn_relu_pool (HIP, K9) == BatchNorm2d(eval) -> (+identity) -> ReLU (-> MaxPool2d(3,2,1))
+    as the separate ATen ops torchvision's ResNet runs (MD2/networks/resnet_encoder.py:85-98)."""
+    from depthmodelhardening_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(3)
+    rnd = lambda *s: torch.rand(*s, device="cuda", generator=g)    # noqa: E731
+    for (B, C, H, W) in [(2, 5, 4, 8), (1, 3, 3, 5), (3, 64, 20, 64), (1, 1, 1, 1)]:
+        x = (rnd(B, C, H, W) - 0.5).requires_grad_(True)
+        res = (rnd(B, C, H, W) - 0.5).requires_grad_(True)
+        w, b, mu, var = rnd(C) + 0.5, rnd(C) - 0.5, rnd(C) - 0.5, rnd(C) + 0.1
+        scale = w / torch.sqrt(var + 1e-5)
+        shift = b - mu * scale
+        w8 = rnd(B, C, H, W)
+        for relu in (True, False):
+            for use_res in (True, False):
+                got = ops.bn_act(x, scale, shift, res if use_res else None, relu)
+                ref = F.batch_norm(x, mu, var, w, b, False, 0.0, 1e-5)
+                ref = ref + res if use_res else ref
+                ref = F.relu(ref) if relu else ref
+                # x*scale+shift vs (x-mean)*invstd*w+b: a few ulp of the largest term
+                torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6)
+                ins = [x, res] if use_res else [x]
+                ga = torch.autograd.grad((got * w8).sum(), ins, retain_graph=True)
+                # the ReLU mask is taken from each path's own output: compare where the reference is off the kink
+                off_kink = ((ref.abs() > 1e-5) | (not relu)).float()
+                gb = torch.autograd.grad((ref * w8 * off_kink).sum(), ins)
+                ga_k = torch.autograd.grad((got * w8 * off_kink).sum(), ins)
+                for a, bb in zip(ga_k, gb):
+                    torch.testing.assert_close(a, bb, rtol=1e-5, atol=1e-6)
+                assert all(torch.isfinite(a).all() for a in ga)
+    for (B, C, H, W) in [(2, 3, 4, 6), (1, 2, 2, 2), (2, 64, 32, 48), (1, 4, 10, 2)]:
+        x = (rnd(B, C, H, W) - 0.4).requires_grad_(True)
+        w, b, mu, var = rnd(C) + 0.5, rnd(C) - 0.5, rnd(C) - 0.5, rnd(C) + 0.1
+        scale = w / torch.sqrt(var + 1e-5)
+        shift = b - mu * scale
+        feat, pooled = ops.stem_bn_relu_pool(x, scale, shift)
+        rfeat = F.relu(F.batch_norm(x, mu, var, w, b, False, 0.0, 1e-5))
+        rpool = F.max_pool2d(rfeat, 3, 2, 1)
+        torch.testing.assert_close(feat, rfeat, rtol=1e-5, atol=2e-6)
+        torch.testing.assert_close(pooled, rpool, rtol=1e-5, atol=2e-6)
+        # gradients: feed the HIP path's own activation through ATen's ReLU-mask/max-pool adjoint so that both sides
+        # see bit-identical maxima (argmax ties at 0 are killed by the ReLU mask on both sides)
+        wf, wp = rnd(B, C, H, W), rnd(B, C, H // 2, W // 2)
+        for use_f, use_p in [(True, True), (False, True), (True, False)]:
+            cost = (feat * wf).sum() * float(use_f) if use_f else 0.0
+            cost = cost + ((pooled * wp).sum() if use_p else 0.0)
+            got = torch.autograd.grad(cost, x, retain_graph=True)[0]
+            fd = feat.detach().requires_grad_(True)
+            rc = ((fd * wf).sum() if use_f else 0.0) + ((F.max_pool2d(fd, 3, 2, 1) * wp).sum() if use_p else 0.0)
+            g_feat = torch.autograd.grad(rc, fd)[0]
+            want = g_feat * (feat.detach() > 0).float() * scale.view(1, -1, 1, 1)
+            torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="even"):
+        ops.stem_bn_relu_pool(rnd(1, 2, 3, 4), torch.ones(2, device="cuda"), torch.zeros(2, device="cuda"))
+    with pytest.raises(RuntimeError, match="entries"):
+        ops.bn_act(rnd(1, 2, 3, 4), torch.ones(3, device="cuda"), torch.zeros(3, device="cuda"))
+
+
+@pytest.mark.parametrize("num_layers", [18, 50])
+def test_fused_eval_encoder_matches_module_path(num_layers):
+    """ResnetEncoder in eval(): fused K9 path == the module path (BatchNorm2d/ReLU/MaxPool2d as ATen ops), features and
+    the gradient w.r.t. the input image (what the attacks differentiate); train() keeps the module path."""
+    from depthmodelhardening_amd import networks
+    torch.manual_seed(0)
+    enc = networks.ResnetEncoder(num_layers, False).cuda()
+    with torch.no_grad():                       # non-trivial running statistics and affine parameters
+        for m in enc.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.uniform_(-0.2, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.uniform_(-0.2, 0.2)
+    enc.eval()
+    x = torch.rand(2, 3, 64, 96, device="cuda").requires_grad_(True)
+    wts = None
+    res = {}
+    for fused in (True, False):
+        enc.encoder.fuse_eval_bn = fused
+        feats = enc(x)
+        if wts is None:
+            wts = [torch.rand_like(f) for f in feats]
+        cost = sum((f * w).mean() for f, w in zip(feats, wts))
+        res[fused] = ([f.detach() for f in feats], torch.autograd.grad(cost, x)[0])
+    for a, b in zip(*[res[k][0] for k in (True, False)]):
+        assert_close_frac(a, b, rtol=1e-4, atol=1e-5 * float(b.abs().max()), name="encoder feature")
+    assert_close_frac(res[True][1], res[False][1], rtol=1e-3, atol=1e-4 * float(res[False][1].abs().max()),
+                      max_bad_frac=1e-3, name="d cost / d image")
+    enc.encoder.fuse_eval_bn = True
+    enc.train()
+    assert not enc.encoder.fused_eval_ok(x)
+    rm0 = enc.encoder.bn1.running_mean.clone()
+    enc(x)
+    assert not torch.equal(enc.encoder.bn1.running_mean, rm0)     # train mode still updates the running statistics
+
+
 def test_trainer_val_reports_attack_metrics(tmp_path):
     tr = _trainer(tmp_path, ["--adv_train", "--atk_steps", "1"])
     tr.val_eval_count = 1
