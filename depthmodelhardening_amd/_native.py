@@ -79,6 +79,9 @@ _SIGNATURES = {
     "dmh_bn_act_bwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp, _fp, _fp]),
     "dmh_stem_bn_relu_pool_fwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp] * 4),
     "dmh_stem_bn_relu_pool_bwd": (C.c_int, [_fp] * 5 + [C.c_int] * 4 + [_fp, _fp]),
+    "dmh_wino_weight_size": (C.c_int64, [C.c_int, C.c_int]),
+    "dmh_wino_weight_transform": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "dmh_wino_conv3x3": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

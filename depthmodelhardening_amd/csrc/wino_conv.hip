@@ -1,0 +1,457 @@
+// K10 -- 3x3 stride-1 convolution, Winograd F(2x2, 3x3) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Why: after K1-K9 the adversarial-training step is ~75 % MIOpen `miopenSp3AsmConv_v30_3_1_gfx9_fp32_f2x3`
+// (profiles/r01_bench_timed_region.csv: 564 launches, 133 ms of a 248 ms step).  That kernel is a gfx9-generic
+// Winograd on the VECTOR ALU: ~75 TFLOP/s direct-equivalent, i.e. ~33 TFLOP/s of real multiplies = half the scalar
+// v_fma_f32 issue roof measured on this chip (tools/micro/valu_rate.hip).  gfx950 has an exact-fp32 MFMA at the full
+// 157 TFLOP/s; the 16 transform-domain GEMMs  M_p[k][tile] = sum_c U_p[k][c] * V_p[c][tile]  map onto it directly.
+// This is the forward AND the backward-data pass (the latter = the same kernel on the flipped/transposed filter
+// with pad' = 2 - pad) of every 3x3/1 convolution of the ResNet encoder and the depth decoder
+// (MD2/networks/resnet_encoder.py:85-98 via torchvision BasicBlock, MD2/layers.py:127-141 Conv3x3).
+// The weight gradient stays on MIOpen (train pass only).
+//
+// Work decomposition (one workgroup = 4 waves, one wave per SIMD, 256 accumulator registers per lane):
+//   * workgroup tile : 64 output channels x 64 Winograd tiles (TRH x TRW tiles = 2TRH x 2TRW output pixels)
+//   * wave tile      : 32 output channels x 32 tiles x all 16 transform positions -> 16 accumulators of 32x32;
+//                      the output transform A^T M A is then pure per-lane register arithmetic.
+//   * K loop         : input channels in chunks of 8.  Per chunk: raw input region (8 x (2TRH+2) x (2TRW+2)) and the
+//                      pre-transformed filter chunk (16 x 64 x 8) go global -> registers (prefetched one chunk ahead,
+//                      in flight during the MFMA phase) -> LDS; the input transform B^T d B runs LDS -> LDS;
+//                      then per position 2 ds_read_b128 + 4 MFMAs (channel order inside a chunk is permuted so that
+//                      one 16-byte read feeds 4 consecutive k-steps of a lane).
+//   * LDS images     : U[p][h][kout][4], V[p][h][tile][4]  (h = lane >> 5 half of the MFMA k pair): consecutive
+//                      lanes read consecutive 16-byte words = conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS).
+// Zero padding (pad = 0, 1 or 2) is applied on the raw load (clamped address, masked value).
+#include "common.hpp"
+
+using namespace dmh;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));    // native vector: arrays of it stay in registers
+
+#ifndef DMH_WINO_ABLATE          // tools/wino_ablate.sh: 1 no global loads, 2 no input transform, 4 no LDS staging writes,
+#define DMH_WINO_ABLATE 0        // 16 no MFMAs in the steady-state loop (timing experiments only: results are garbage)
+#endif
+constexpr int CK = 8;            // input channels per chunk
+constexpr int NT = 256;
+
+struct WArgs {
+    const float* x;
+    const f32x4* U;              // [C/8][16][2][Kp][4 floats], Kp = K rounded up to 64
+    const float* bias;           // [K] or null
+    float* y;
+    int B, C, K, Kp, H, W, Ho, Wo, pad;
+    int gx, gy, kg;              // tile-region groups along x / y, output-channel groups
+    int nitems;                  // B * gy * gx * kg work items
+};
+
+// pre-transform the filter: U = G g G^T, scattered into the chunked layout the kernel streams.
+// mode 0: forward   u[k][c] from w[k][c][ky][kx]
+// mode 1: backward  u[c][k] from w[k][c][2-ky][2-kx]   (output channels of the pass = C of the filter)
+__global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict__ w, int Kw, int Cw, int mode,
+                                                         float* __restrict__ U, int Kp) {
+    // "out" / "in" are the channel roles of the pass this transform is for
+    const int n_out = mode ? Cw : Kw, n_in = mode ? Kw : Cw;
+    const int i = blockIdx.x * NT + threadIdx.x;       // over Kp * n_in
+    if (i >= Kp * n_in) return;
+    const int ko = i % Kp, ci = i / Kp;
+    float g[3][3];
+    if (ko < n_out) {
+        const float* src = mode ? w + ((size_t)ci * Cw + ko) * 9 : w + ((size_t)ko * Cw + ci) * 9;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = mode ? src[(2 - a) * 3 + (2 - b)] : src[a * 3 + b];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
+    }
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int cc = ci / CK, cl = ci % CK, h = cl >> 2, s = cl & 3;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
+                    u3 = t[a][2];
+        const float u[4] = {u0, u1, u2, u3};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int p = a * 4 + b;
+            U[((((size_t)cc * 16 + p) * 2 + h) * Kp + ko) * 4 + s] = u[b];
+        }
+    }
+}
+
+// Decoded work item: 64 output channels x one TRH x TRW tile region of one image.  Items are numbered with the
+// output-channel group fastest and every workgroup takes a CONTIGUOUS range, so the channel groups of one region run
+// back to back on the same CU and re-read its input from L1/L2.
+struct Item {
+    int b, ty0, tx0, k0;
+};
+template <int TRW>
+__device__ __forceinline__ Item decode_item(const WArgs& a, int item) {
+    constexpr int TRH = 64 / TRW;
+    Item it;
+    it.k0 = (item % a.kg) * 64;  item /= a.kg;
+    it.tx0 = (item % a.gx) * TRW;  item /= a.gx;
+    it.ty0 = (item % a.gy) * TRH;
+    it.b = item / a.gy;
+    return it;
+}
+
+template <int TRW>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_conv_kernel(WArgs a) {
+    constexpr int TRH = 64 / TRW;
+    constexpr int RH = 2 * TRH + 2, RW = 2 * TRW + 2;       // raw input region of a work item (per channel)
+    constexpr int RAW_N = CK * RH * RW;
+    constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;
+    constexpr int RAW_BUF = RAW_PER_T * NT;                 // floats per raw buffer: every thread stores all its slots
+    constexpr int BUF = 16 * 2 * 64;                        // f32x4 words of one U or V image (32 KB)
+    extern __shared__ f32x4 smem[];
+    f32x4* U_lds = smem;                                    // [2 buffers][16][2][64]
+    f32x4* V_lds = smem + 2 * BUF;                          // [2 buffers][16][2][64]
+    float* raw = reinterpret_cast<float*>(smem + 4 * BUF);  // [2 buffers][CK][RH][RW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const size_t HW = (size_t)a.H * a.W;
+    const int nch = a.C / CK;
+
+    // ---- this workgroup's contiguous item range, flattened with the channel chunks into one iteration space
+    const int q = a.nitems / (int)gridDim.x, r = a.nitems % (int)gridDim.x;
+    const int item0 = (int)blockIdx.x * q + min((int)blockIdx.x, r);
+    const int nmine = q + ((int)blockIdx.x < r ? 1 : 0);
+    const int item_last = item0 + nmine - 1;
+
+    // transform role: wave wv owns chunk channels {2wv, 2wv+1} = (h = wv>>1, s = 2(wv&1) + {0,1}); lane = tile
+    const int tly = lane / TRW, tlx = lane - tly * TRW;
+    const float* rsrc = raw + (2 * wv) * (RH * RW) + (2 * tly) * RW + 2 * tlx;
+    float* vdst = reinterpret_cast<float*>(V_lds + (wv >> 1) * 64 + lane) + 2 * (wv & 1);
+    const int kb = wv & 1, tb = wv >> 1;
+    const int aidx = (lane >> 5) * 64 + kb * 32 + (lane & 31);
+    const int bidx = (lane >> 5) * 64 + tb * 32 + (lane & 31);
+
+    // ---- raw-load stage constants of an item: offsets inside one channel chunk + validity bits (zero padding =
+    //      clamped address + masked value).  The load stages run ahead of the MFMAs across the item boundary, so the
+    //      constants of the NEXT item are kept beside the current ones and selected per iteration (no branch).
+    unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
+    unsigned rvalid = 0, rvalid_n = 0;
+    const float* xb = a.x;
+    const float* xb_n = a.x;
+    const f32x4* usrc = a.U;
+    const f32x4* usrc_n = a.U;
+#define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, RVALID, XB, USRC)                                        \
+    {                                                                                             \
+        const Item it = decode_item<TRW>(a, ITEM);                                                \
+        const int iy0 = 2 * it.ty0 - a.pad, ix0 = 2 * it.tx0 - a.pad;                             \
+        int tid_o = tid;    /* opaque copy: the slot decomposition below must not be hoisted and kept live */ \
+        asm volatile("" : "+v"(tid_o));                                                           \
+        XB = a.x + (size_t)it.b * a.C * HW;                                                       \
+        USRC = a.U + (size_t)it.k0;                                                               \
+        RVALID = 0;                                                                               \
+        _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
+            const int e = tid_o + NT * k;                                                         \
+            const int c = e / (RH * RW), rem = e - c * (RH * RW), rr = rem / RW, xx = rem - rr * RW; \
+            const int iy = iy0 + rr, ix = ix0 + xx;                                               \
+            const bool ok = (e < RAW_N) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;            \
+            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);               \
+            ROFF[k] = (unsigned)((e < RAW_N ? c : 0) * (int)HW + cy * a.W + cx);                  \
+            RVALID |= ok ? (1u << k) : 0u;                                                        \
+        }                                                                                         \
+    }
+
+    float rreg[RAW_PER_T];
+    // XC / UC: uniform chunk base pointers; ROFF: per-thread offsets
+#define DMH_WINO_LOAD_RAW(XC, ROFF)                                                               \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = (XC)[ROFF[k]];
+    // filter chunk: 32 rows (p, h) of 64 x 16 B, lane-linear both in global memory and in the LDS image -> LDS-DMA
+    // (global_load_lds_dwordx4: no registers, no ds_write); wave wv moves rows wv, wv+4, ...; K = row slot 0..7
+    // Written as asm: through the builtin hipcc treats every later LDS read as a possible alias of the DMA and drains
+    // vmcnt(0) -- the register-staged raw loads included -- a few slots later.  The asm DMA is invisible to hipcc's
+    // s_waitcnt bookkeeping, so its completion is counted by hand (the vmcnt before each barrier below); hipcc's own
+    // counted waits for the raw loads only become stricter (the DMAs are younger than the loads they wait for).
+#define DMH_WINO_GLDS_U_ROW(UC, BUFI, K)                                                          \
+    {                                                                                             \
+        const f32x4* gsrc = (UC) + (size_t)(wv + 4 * (K)) * a.Kp + lane;                          \
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(                                     \
+            (unsigned)(uintptr_t)(U_lds + (BUFI) * BUF + (wv + 4 * (K)) * 64));                   \
+        unsigned keep;                                                                            \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");                             \
+    }
+#define DMH_WINO_GLDS_U(UC, BUFI)                                                                 \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) DMH_WINO_GLDS_U_ROW(UC, BUFI, k)
+#define DMH_WINO_WRITE_RAW(BUFI, RVALID)                                                          \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k)                                         \
+        raw[(BUFI) * RAW_BUF + tid + NT * k] = ((RVALID) >> k) & 1u ? rreg[k] : 0.f;
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+
+    // Software pipeline over the flattened (item, chunk) sequence, ONE barrier and ONE fenced block per chunk.
+    // Iteration g = item * nch + ch runs
+    //   M(g)    64 MFMAs on U[g&1], V[g&1]
+    //   T(g+1)  input transform raw[(g+1)&1] -> V[(g+1)&1]
+    //   D       LDS-DMA (global_load_lds_dwordx4) of filter chunk g+1 -> U[(g+1)&1], issued first
+    //   W       prefetch registers (raw chunk g+2) -> raw[g&1]
+    //   L       global loads of raw chunk g+3 into the registers W just freed: in flight for a whole iteration
+    // The stages run across item boundaries (nch >= 3), so the next item's pipeline fill overlaps this item's last
+    // chunks; only the output transform + store of an item is serial.  Past the last item the stages re-stage its
+    // first chunks into buffers nobody reads any more.
+    DMH_WINO_ITEM_CONSTS(item0, roff, rvalid, xb, usrc)
+    DMH_WINO_LOAD_RAW(xb, roff)
+    DMH_WINO_GLDS_U(usrc, 0)
+    DMH_WINO_WRITE_RAW(0, rvalid)
+    DMH_WINO_LOAD_RAW(xb + (size_t)CK * HW, roff)
+    __syncthreads();
+    {   // T(0)
+        float t[2][4][4];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            float d[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float2 lo = *reinterpret_cast<const float2*>(rsrc + ch * (RH * RW) + i * RW);
+                const float2 hi = *reinterpret_cast<const float2*>(rsrc + ch * (RH * RW) + i * RW + 2);
+                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t[ch][0][j] = d[0][j] - d[2][j];
+                t[ch][1][j] = d[1][j] + d[2][j];
+                t[ch][2][j] = d[2][j] - d[1][j];
+                t[ch][3][j] = d[1][j] - d[3][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float2*>(vdst + (i * 4 + 0) * 512) = make_float2(t[0][i][0] - t[0][i][2], t[1][i][0] - t[1][i][2]);
+            *reinterpret_cast<float2*>(vdst + (i * 4 + 1) * 512) = make_float2(t[0][i][1] + t[0][i][2], t[1][i][1] + t[1][i][2]);
+            *reinterpret_cast<float2*>(vdst + (i * 4 + 2) * 512) = make_float2(t[0][i][2] - t[0][i][1], t[1][i][2] - t[1][i][1]);
+            *reinterpret_cast<float2*>(vdst + (i * 4 + 3) * 512) = make_float2(t[0][i][1] - t[0][i][3], t[1][i][1] - t[1][i][3]);
+        }
+    }
+    DMH_WINO_WRITE_RAW(1, rvalid)
+    DMH_WINO_LOAD_RAW(xb + (size_t)2 * CK * HW, roff)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_PER_T) : "memory");   // the LDS-DMA of U[0] has landed
+    __syncthreads();
+
+    int g = 0;
+    for (int mi = 0; mi < nmine; ++mi) {
+        const int item = item0 + mi;
+        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), roff_n, rvalid_n, xb_n, usrc_n)
+        for (int ch = 0; ch < nch; ++ch, ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            const f32x4* Uc = U_lds + cur * BUF + aidx;
+            const f32x4* Vc = V_lds + cur * BUF + bidx;
+            const float* rs = rsrc + nxt * RAW_BUF;
+            float* vd = vdst + nxt * BUF * 4;
+            // load-stage operands of this iteration: raw chunk ch+3 and filter chunk ch+1, possibly of the next item;
+            // the raw registers written to LDS in this iteration hold chunk ch+2
+            const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
+            const float* xc = (r_next ? xb_n + (size_t)(ch + 3 - nch) * CK * HW : xb + (size_t)(ch + 3) * CK * HW);
+            const f32x4* uc = (u_next ? usrc_n : usrc + (size_t)(ch + 1) * 32 * a.Kp);
+            unsigned ro[RAW_PER_T];
+#pragma unroll
+            for (int k = 0; k < RAW_PER_T; ++k) ro[k] = r_next ? roff_n[k] : roff[k];
+            const unsigned rv = (ch + 2 >= nch) ? rvalid_n : rvalid;
+            // The block is written in issue order and fenced (sched_barrier) per SLOT = 2 MFMAs on two alternating
+            // accumulators (128 cycles of matrix pipe) + one operand read for the next position pair + a few
+            // instructions of staging work, so that no gap between MFMAs carries more than the pipe can shadow.
+            f32x4 ua[16], vb[16];
+            ua[0] = Uc[0]; vb[0] = Vc[0];
+            ua[1] = Uc[128]; vb[1] = Vc[128];
+            float d[4][4], t[2][4][4];
+            __builtin_amdgcn_sched_barrier(0);
+#if DMH_WINO_ABLATE & 16
+#define DMH_MFMA(A, B, C) (C)
+#else
+#define DMH_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x2f32(A, B, C, 0, 0, 0)
+#endif
+#pragma unroll
+            for (int sl = 0; sl < 32; ++sl) {
+                const int p0 = 2 * (sl >> 2), p1 = p0 + 1, ks = sl & 3;
+                acc[p0] = DMH_MFMA(ua[p0][ks], vb[p0][ks], acc[p0]);
+                acc[p1] = DMH_MFMA(ua[p1][ks], vb[p1][ks], acc[p1]);
+                if (p0 + 2 < 16) {                          // operands of the next position pair, one read per slot
+                    if (ks == 0) ua[p0 + 2] = Uc[(p0 + 2) * 128];
+                    if (ks == 1) vb[p0 + 2] = Vc[(p0 + 2) * 128];
+                    if (ks == 2) ua[p1 + 2] = Uc[(p1 + 2) * 128];
+                    if (ks == 3) vb[p1 + 2] = Vc[(p1 + 2) * 128];
+                }
+                if (sl < 8) {                               // filter chunk g+1 -> U[nxt] by LDS-DMA, one row per slot
+                    if (!(DMH_WINO_ABLATE & 1)) DMH_WINO_GLDS_U_ROW(uc, nxt, sl)
+                } else if (DMH_WINO_ABLATE & 2) {
+                } else if ((sl >= 8 && sl < 12) || (sl >= 14 && sl < 18)) {   // raw patch row of channel 0 / 1
+                    const int c2 = sl >= 14, i = c2 ? sl - 14 : sl - 8;
+                    const float2 lo = *reinterpret_cast<const float2*>(rs + c2 * (RH * RW) + i * RW);
+                    const float2 hi = *reinterpret_cast<const float2*>(rs + c2 * (RH * RW) + i * RW + 2);
+                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                } else if (sl == 12 || sl == 13 || sl == 18 || sl == 19) {    // rows of B^T d, two columns per slot
+                    const int c2 = sl >= 18, j0 = 2 * (sl & 1);
+#pragma unroll
+                    for (int j = j0; j < j0 + 2; ++j) {
+                        t[c2][0][j] = d[0][j] - d[2][j];
+                        t[c2][1][j] = d[1][j] + d[2][j];
+                        t[c2][2][j] = d[2][j] - d[1][j];
+                        t[c2][3][j] = d[1][j] - d[3][j];
+                    }
+                } else if (sl >= 20 && sl < 28) {           // columns: half an output row (2 positions) per slot -> V
+                    const int rr = (sl - 20) >> 1;
+                    if ((sl & 1) == 0) {
+                        *reinterpret_cast<float2*>(vd + (rr * 4 + 0) * 512) = make_float2(t[0][rr][0] - t[0][rr][2], t[1][rr][0] - t[1][rr][2]);
+                        *reinterpret_cast<float2*>(vd + (rr * 4 + 1) * 512) = make_float2(t[0][rr][1] + t[0][rr][2], t[1][rr][1] + t[1][rr][2]);
+                    } else {
+                        *reinterpret_cast<float2*>(vd + (rr * 4 + 2) * 512) = make_float2(t[0][rr][2] - t[0][rr][1], t[1][rr][2] - t[1][rr][1]);
+                        *reinterpret_cast<float2*>(vd + (rr * 4 + 3) * 512) = make_float2(t[0][rr][1] - t[0][rr][3], t[1][rr][1] - t[1][rr][3]);
+                    }
+                }
+                if (sl >= 28) {                             // raw registers -> LDS, then refill them (4 slots)
+#pragma unroll
+                    for (int k = (sl - 28) * ((RAW_PER_T + 3) / 4); k < min((sl - 27) * ((RAW_PER_T + 3) / 4), RAW_PER_T); ++k) {
+                        if (!(DMH_WINO_ABLATE & 4)) raw[cur * RAW_BUF + tid + NT * k] = (rv >> k) & 1u ? rreg[k] : 0.f;
+                        if (!(DMH_WINO_ABLATE & 1)) rreg[k] = xc[ro[k]];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // all older vector-memory operations (the LDS-DMA of U[nxt] and the loads consumed above) have landed when
+            // only this iteration's RAW_PER_T raw loads are still outstanding; a raw s_barrier keeps those in flight
+            // (__syncthreads() would drain them: its fence waits vmcnt(0) once an LDS-DMA has been issued)
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RAW_PER_T) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // ---- item done: output transform  Y = A^T M A, store, clear the accumulators; lane -> tile,
+        //      register -> output channel
+        {
+            const Item it = decode_item<TRW>(a, item);
+            int lane_o = lane;      // opaque copy: keeps the per-lane store addresses from being hoisted out of the item loop
+            asm volatile("" : "+v"(lane_o));
+            const int tl = tb * 32 + (lane_o & 31);
+            const int oy = 2 * (it.ty0 + tl / TRW), ox = 2 * (it.tx0 + tl % TRW);
+            const bool inside = oy < a.Ho && ox < a.Wo;
+            float* yb = a.y + (size_t)it.b * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
+            const int kbase = it.k0 + kb * 32 + 4 * (lane_o >> 5);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ko = kbase + (v & 3) + 8 * (v >> 2);
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = acc[j][v] + acc[4 + j][v] + acc[8 + j][v];
+                    s1[j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
+                }
+                if (inside && ko < a.K) {
+                    const float bs = a.bias ? a.bias[ko] : 0.f;
+                    const float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
+                    const float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
+                    float* yp = yb + (size_t)ko * a.Ho * a.Wo;
+                    *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
+                    *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
+                }
+            }
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[pp][v] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
+        rvalid = rvalid_n;
+        xb = xb_n;
+        usrc = usrc_n;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+template <int TRW>
+int launch(WArgs& a, hipStream_t st) {
+    constexpr int TRH = 64 / TRW;
+    // U and V images (double-buffered, 128 KB) + two raw input regions
+    constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)2 * ((CK * (2 * TRH + 2) * (2 * TRW + 2) + NT - 1) / NT * NT) * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<TRW>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
+        configured = true;
+    }
+    // persistent: one workgroup per CU (its 154 KB of LDS and 512 registers per lane fill the CU), each walking a
+    // contiguous range of work items
+    const int grid = a.nitems < num_cus() ? a.nitems : num_cus();
+    hipLaunchKernelGGL(wino_conv_kernel<TRW>, dim3((unsigned)grid), dim3(NT), smem, st, a);
+    return check_launch("dmh_wino_conv3x3");
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dmh_wino_weight_size(int n_out, int n_in) {
+    if (n_out <= 0 || n_in <= 0 || n_in % CK) return -1;
+    const int64_t Kp = ((int64_t)n_out + 63) / 64 * 64;
+    return (int64_t)(n_in / CK) * 16 * 2 * Kp * 4;
+}
+
+int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream) {
+    DMH_REQUIRE(w && U, "null pointer");
+    const int n_out = backward ? C : K, n_in = backward ? K : C;
+    DMH_REQUIRE(K > 0 && C > 0 && n_in % CK == 0, "the pass's input channel count must be a multiple of 8");
+    const int Kp = (n_out + 63) / 64 * 64;
+    const long long n = (long long)Kp * n_in;
+    hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, w, K, C,
+                       backward ? 1 : 0, U, Kp);
+    return check_launch("dmh_wino_weight_transform");
+}
+
+int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                     float* y, void* stream) {
+    DMH_REQUIRE(x && U && y, "null pointer");
+    DMH_REQUIRE(B > 0 && C >= 3 * CK && K > 0 && C % CK == 0, "input channels must be a multiple of 8, at least 24");
+    DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    DMH_REQUIRE(Ho >= 2 && Wo >= 2 && (Ho & 1) == 0 && (Wo & 1) == 0, "output height and width must be even");
+    DMH_REQUIRE((int64_t)C * H * W < ((int64_t)1 << 31) && (int64_t)K * Ho * Wo < ((int64_t)1 << 31), "image too large");
+    WArgs a;
+    a.x = x; a.U = reinterpret_cast<const f32x4*>(U); a.bias = bias; a.y = y;
+    a.B = B; a.C = C; a.K = K; a.Kp = (K + 63) / 64 * 64; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
+    a.kg = a.Kp / 64;
+    const int Ht = Ho / 2, Wt = Wo / 2;
+    // narrow images: 4 x 16 tile regions waste fewer lanes than 2 x 32 ones
+    const bool narrow = (Wt % 32) != 0 && (Wt <= 16 || ((Wt + 15) / 16 * 16 - Wt) < ((Wt + 31) / 32 * 32 - Wt));
+    if (narrow) {
+        a.gx = (Wt + 15) / 16; a.gy = (Ht + 3) / 4;
+        DMH_REQUIRE((int64_t)B * a.gx * a.gy * a.kg < ((int64_t)1 << 31), "too many work items");
+        a.nitems = B * a.gx * a.gy * a.kg;
+        return launch<16>(a, (hipStream_t)stream);
+    }
+    a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2;
+    DMH_REQUIRE((int64_t)B * a.gx * a.gy * a.kg < ((int64_t)1 << 31), "too many work items");
+    a.nitems = B * a.gx * a.gy * a.kg;
+    return launch<32>(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -38,17 +38,23 @@ class DepthDecoder(nn.Module):
     def _forward_fused(self, input_features):
         """Same arithmetic as the reference forward, with the element-wise passes between the convolutions fused
         into the HIP glue kernels (ops.up_cat_pad / ops.elu_pad) and the convolutions run un-padded on pre-padded
-        tensors.  Identical parameters / state_dict."""
+        tensors (ops.conv3x3: the Winograd-MFMA kernel where the shape fills the chip, MIOpen otherwise).  Identical
+        parameters / state_dict."""
         from .. import ops
+
+        def conv(block, t):
+            c = block.conv
+            return ops.conv3x3(t, c.weight, c.bias, 0)
+
         self.outputs = {}
         p = ops.elu_pad(input_features[-1], apply_elu=False)
         for i in range(4, -1, -1):
-            y = self.convs[("upconv", i, 0)].conv.conv(p)
+            y = conv(self.convs[("upconv", i, 0)].conv, p)
             p = ops.up_cat_pad(y, input_features[i - 1] if i > 0 else None)
-            z = self.convs[("upconv", i, 1)].conv.conv(p)
+            z = conv(self.convs[("upconv", i, 1)].conv, p)
             p = ops.elu_pad(z)                      # feeds both the next stage and this scale's disparity head
             if i in self.scales:
-                self.outputs[("disp", i)] = self.sigmoid(self.convs[("dispconv", i)].conv(p))
+                self.outputs[("disp", i)] = self.sigmoid(conv(self.convs[("dispconv", i)], p))
         return self.outputs
 
     def _forward_reference(self, input_features):

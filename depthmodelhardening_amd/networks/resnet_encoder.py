@@ -17,6 +17,15 @@ import torch.nn as nn
 from .. import ops
 
 
+def _conv(conv, x):
+    """conv(x); 3x3 stride-1 pad-1 convolutions of CUDA tensors go through ops.conv3x3 (Winograd-MFMA kernel where the
+    shape fills the chip, MIOpen otherwise) -- same parameters, same result within fp32 rounding."""
+    if (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1):
+        return ops.conv3x3(x, conv.weight, conv.bias, 1)
+    return conv(x)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -31,14 +40,14 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
+        out = self.relu(self.bn1(_conv(self.conv1, x)))
+        out = self.bn2(_conv(self.conv2, out))
         return self.relu(out + idt)
 
     def forward_fused(self, x, aff):
         idt = x if self.downsample is None else ops.bn_act(self.downsample[0](x), *aff[self.downsample[1]], relu=False)
-        out = ops.bn_act(self.conv1(x), *aff[self.bn1])
-        return ops.bn_act(self.conv2(out), *aff[self.bn2], residual=idt)
+        out = ops.bn_act(_conv(self.conv1, x), *aff[self.bn1])
+        return ops.bn_act(_conv(self.conv2, out), *aff[self.bn2], residual=idt)
 
 
 class Bottleneck(nn.Module):
@@ -58,14 +67,14 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(self.conv1(x)))
-        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.relu(self.bn2(_conv(self.conv2, out)))
         out = self.bn3(self.conv3(out))
         return self.relu(out + idt)
 
     def forward_fused(self, x, aff):
         idt = x if self.downsample is None else ops.bn_act(self.downsample[0](x), *aff[self.downsample[1]], relu=False)
         out = ops.bn_act(self.conv1(x), *aff[self.bn1])
-        out = ops.bn_act(self.conv2(out), *aff[self.bn2])
+        out = ops.bn_act(_conv(self.conv2, out), *aff[self.bn2])
         return ops.bn_act(self.conv3(out), *aff[self.bn3], residual=idt)
 
 

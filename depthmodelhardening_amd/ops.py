@@ -4,7 +4,9 @@ PyTorch is plumbing here: it owns device memory, streams and the autograd graph;
 below is one or a few launches of hand-written gfx950 kernels through the C ABI
 (include/dmh_hip.h).  There is no eager/CPU fallback: CPU tensors raise RuntimeError.
 """
+import contextlib
 import ctypes as C
+import os
 from collections import namedtuple
 
 import torch
@@ -579,6 +581,118 @@ def stem_bn_relu_pool(x, scale, shift):
     MD2/networks/resnet_encoder.py:88-91 (features[0] and the input of layer1).  H and W must be even."""
     feat, pooled, _ = _StemBnReluPool.apply(_c(x), _c(scale.detach()), _c(shift.detach()))
     return feat, pooled
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# K10: 3x3 stride-1 convolution, Winograd F(2x2,3x3) on the fp32 matrix cores (forward and backward-data); the weight
+# gradient stays on MIOpen.  Dispatch is by shape: the kernel wins where a launch fills the chip with >= 64 output
+# channels (tools/wino_bench.py, profiles/); everything else is the ATen/MIOpen convolution.
+# ---------------------------------------------------------------------------------------------------------------
+WINO_ENABLED = os.environ.get("DMH_WINO", "1") != "0"
+_wino_frozen = 0
+_wino_cache = {}
+
+
+@contextlib.contextmanager
+def frozen_weights():
+    """Scope in which the network parameters are constants (an attack: torchattacks/attack.py brackets it with
+    model.eval() and differentiates w.r.t. the perturbation only -- phy_obj_atk.py:96, phy_obj_atk_l0.py:134,
+    pgd_depth.py:72).  Inside, the Winograd-transformed filters are computed once per weight tensor instead of once
+    per call (the cache is dropped on exit) and ops.conv3x3 produces no weight/bias gradients: a custom autograd
+    Function cannot see that torch.autograd.grad() was asked for the input gradient only, and the weight-gradient
+    convolutions would otherwise run in every attack step just to be thrown away."""
+    global _wino_frozen
+    _wino_frozen += 1
+    try:
+        yield
+    finally:
+        _wino_frozen -= 1
+        if _wino_frozen == 0:
+            _wino_cache.clear()
+
+
+def _wino_filter(weight, backward):
+    lib = N.lib()
+    K, Cc = weight.shape[0], weight.shape[1]
+    key = (weight.data_ptr(), weight._version, bool(backward))
+    if _wino_frozen and key in _wino_cache:
+        return _wino_cache[key]
+    n_out, n_in = (Cc, K) if backward else (K, Cc)
+    U = torch.empty(lib.dmh_wino_weight_size(n_out, n_in), device=weight.device, dtype=torch.float32)
+    N.check(lib.dmh_wino_weight_transform(N.ptr(_c(weight.detach())), K, Cc, int(backward), N.ptr(U), N.stream()))
+    if _wino_frozen:
+        _wino_cache[key] = U
+    return U
+
+
+def _wino_ok(B, n_in, n_out, Ho, Wo):
+    """Shapes the Winograd-MFMA kernel takes: channel counts it tiles without waste and enough 64-channel x 64-tile
+    work items to fill the 256 CUs (measured crossover, tools/wino_bench.py)."""
+    if not WINO_ENABLED or n_in % 8 or n_in < 24 or n_out < 64 or Ho % 2 or Wo % 2 or Ho < 2 or Wo < 2:
+        return False
+    ht, wt = Ho // 2, Wo // 2
+    narrow = wt % 32 != 0 and (wt <= 16 or (-wt) % 16 < (-wt) % 32)
+    groups = (-(-wt // 16)) * (-(-ht // 4)) if narrow else (-(-wt // 32)) * (-(-ht // 2))
+    return B * groups * (-(-n_out // 64)) >= 200
+
+
+def _wino_conv(x, U, bias, K, pad):
+    lib = N.lib()
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
+    nb = 4 * (x.numel() + y.numel()) + 4 * U.numel()
+    N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad,
+                                                               N.ptr(y), N.stream()), nb))
+    return y
+
+
+class _Conv3x3(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, pad):
+        B, Cc, H, W = x.shape
+        K = weight.shape[0]
+        ctx.pad = pad
+        ctx.has_bias = bias is not None
+        ctx.params_const = _wino_frozen > 0
+        ctx.save_for_backward(x, weight)
+        if _wino_ok(B, Cc, K, H + 2 * pad - 2, W + 2 * pad - 2):
+            return _wino_conv(x, _wino_filter(weight, False), None if bias is None else _c(bias.detach()), K, pad)
+        return torch.conv2d(x, weight, bias, 1, pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        B, Cc, H, W = x.shape
+        K = weight.shape[0]
+        pad = ctx.pad
+        g = _c(g)
+        need_x = ctx.needs_input_grad[0]
+        need_w = ctx.needs_input_grad[1] and not ctx.params_const
+        need_b = ctx.has_bias and ctx.needs_input_grad[2] and not ctx.params_const
+        g_x = g_w = g_b = None
+        if need_x and _wino_ok(B, K, Cc, H, W):
+            # backward-data = the same convolution on g with the flipped/transposed filter and pad' = 2 - pad
+            g_x = _wino_conv(g, _wino_filter(weight, True), None, Cc, 2 - pad)
+            need_x = False
+        if need_x or need_w or need_b:
+            r = torch.ops.aten.convolution_backward(g, x, weight, [K] if ctx.has_bias else None, [1, 1], [pad, pad], [1, 1],
+                                                    False, [0, 0], 1, [need_x, need_w, need_b])
+            g_x = r[0] if need_x else g_x
+            g_w = r[1] if need_w else None
+            g_b = r[2] if need_b else None
+        return g_x, g_w, g_b, None
+
+
+def conv3x3(x, weight, bias=None, padding=1):
+    """nn.Conv2d(C, K, 3, stride=1, padding=padding) with zero padding 0, 1 or 2 -- the 3x3 convolutions of the ResNet
+    encoder (torchvision BasicBlock under MD2/networks/resnet_encoder.py:85-98) and of the depth decoder
+    (MD2/layers.py:127-141 Conv3x3).  Forward and the gradient w.r.t. x run the K10 Winograd-MFMA kernel where the
+    shape fills the chip; the weight/bias gradients and the remaining shapes are ATen/MIOpen."""
+    if padding not in (0, 1, 2) or weight.shape[2:] != (3, 3):
+        raise RuntimeError("conv3x3: 3x3 kernel with padding 0, 1 or 2 expected")
+    if not x.is_cuda:
+        raise RuntimeError("libdmh_hip ops need CUDA (ROCm) tensors; got device %s -- there is no CPU path" % x.device)
+    return _Conv3x3.apply(_c(x), weight, bias, int(padding))
 
 
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,

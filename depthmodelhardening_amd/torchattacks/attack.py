@@ -6,6 +6,8 @@ mode restored afterwards, optional uint8 return).
 """
 import torch
 
+from ..ops import frozen_weights
+
 
 class Attack(object):
     def __init__(self, name, model):
@@ -61,7 +63,10 @@ class Attack(object):
                     m.eval()
         else:
             self.model.eval()
-        images = self.forward(*input, **kwargs)
+        # the attack only updates the perturbation: weight-derived tensors (Winograd-transformed filters) are
+        # computed once for all its steps
+        with frozen_weights():
+            images = self.forward(*input, **kwargs)
         if given_training:
             self.model.train()
         if self._return_type == 'int':

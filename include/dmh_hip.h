@@ -250,6 +250,22 @@ int dmh_stem_bn_relu_pool_fwd(const float* x, const float* scale, const float* s
 int dmh_stem_bn_relu_pool_bwd(const float* feat, const unsigned char* argmax, const float* g_feat, const float* g_pooled,
                               const float* scale, int B, int C, int H, int W, float* g_x, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K10 3x3 stride-1 convolution, Winograd F(2x2,3x3) on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *     Replaces the MIOpen call behind nn.Conv2d(.., 3, 1, pad) in torchvision BasicBlock (encoder,
+ *     MD2/networks/resnet_encoder.py:85-98) and Conv3x3 (decoder, MD2/layers.py:127-141), forward and backward-data.
+ *   weight_transform: U = G w G^T in the chunked layout the kernel streams; `backward` != 0 builds the filter of the
+ *                     backward-data pass (flipped, channel roles swapped).  U holds dmh_wino_weight_size(n_out, n_in)
+ *                     floats, n_out/n_in = channel roles of that pass; n_in must be a multiple of 8.
+ *   conv3x3         : y[B,K,H+2pad-2,W+2pad-2] = corr3x3(zero_pad(x[B,C,H,W], pad), w) (+ bias[K]);  pad in {0,1,2};
+ *                     output height and width must be even.  Backward-data of a pad-p convolution is this call on
+ *                     g_out with the backward filter and pad = 2 - p.
+ * ---------------------------------------------------------------------------------- */
+int64_t dmh_wino_weight_size(int n_out, int n_in);
+int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream);
+int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                     float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

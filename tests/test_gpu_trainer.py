@@ -256,6 +256,93 @@ def test_fused_eval_encoder_matches_module_path(num_layers):
     assert not torch.equal(enc.encoder.bn1.running_mean, rm0)     # train mode still updates the running statistics
 
 
+@pytest.mark.parametrize("shape", [
+    # B, C, K, Ho, Wo, pad      (Ho, Wo = output size)
+    (2, 64, 64, 16, 128, 1),    # encoder layer1-like, 2x32 tile regions
+    (3, 32, 64, 20, 32, 1),     # narrow image: 4x16 tile regions, ragged rows of tiles
+    (1, 128, 192, 12, 64, 0),   # decoder-like: un-padded input, K not a multiple of 64... of 128
+    (2, 64, 96, 10, 66, 2),     # backward-data geometry of a pad-0 convolution (pad 2), ragged tile columns
+    (1, 24, 64, 6, 34, 1),      # minimum channel count (3 chunks)
+])
+def test_wino_conv3x3_kernel_vs_aten(shape):
+    """K10 through the C ABI == ATen conv2d, forward and backward-data (the same kernel on the flipped filter)."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    B, C, K, Ho, Wo, pad = shape
+    H, W = Ho + 2 - 2 * pad, Wo + 2 - 2 * pad
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + C)
+    x = torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5
+    w = (torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.2
+    b = torch.rand(K, device="cuda", generator=g) - 0.5
+    gy = torch.rand(B, K, Ho, Wo, device="cuda", generator=g) - 0.5
+
+    def run(inp, wt, bias, n_out, p, backward):
+        Bn, Ci, Hi, Wi = inp.shape
+        U = torch.empty(lib.dmh_wino_weight_size(n_out, Ci), device="cuda")
+        N.check(lib.dmh_wino_weight_transform(N.ptr(wt), wt.shape[0], wt.shape[1], int(backward), N.ptr(U), N.stream()))
+        y = torch.full((Bn, n_out, Hi + 2 * p - 2, Wi + 2 * p - 2), float("nan"), device="cuda")
+        N.check(lib.dmh_wino_conv3x3(N.ptr(inp), N.ptr(U), N.ptr(bias), Bn, Ci, n_out, Hi, Wi, p, N.ptr(y), N.stream()))
+        return y
+
+    ref = F.conv2d(x, w, b, padding=pad)
+    got = run(x, w, b, K, pad, False)
+    xr = x.clone().requires_grad_(True)
+    gref = torch.autograd.grad(F.conv2d(xr, w, None, padding=pad), xr, gy)[0]
+    scale = float(ref.abs().max())
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6 * scale)
+    if K >= 24 and K % 8 == 0 and H % 2 == 0 and W % 2 == 0:
+        ggot = run(gy, w, None, C, 2 - pad, True)
+        torch.testing.assert_close(ggot, gref, rtol=1e-5, atol=2e-6 * float(gref.abs().max()))
+
+
+def test_wino_conv3x3_rejects_bad_shapes():
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    x = torch.zeros(1, 16, 8, 8, device="cuda")
+    U = torch.zeros(1 << 16, device="cuda")
+    y = torch.zeros(1, 64, 8, 8, device="cuda")
+    assert lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), None, 1, 16, 64, 8, 8, 1, N.ptr(y), N.stream()) != 0   # C < 24
+    assert b"multiple of 8" in lib.dmh_last_error()
+    assert lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), None, 1, 32, 64, 7, 8, 1, N.ptr(y), N.stream()) != 0    # odd height
+    assert lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), None, 1, 32, 64, 8, 8, 3, N.ptr(y), N.stream()) != 0    # pad
+    assert lib.dmh_wino_weight_size(64, 12) == -1
+
+
+def test_conv3x3_op_autograd_matches_aten():
+    """ops.conv3x3 (Winograd-MFMA forward + backward-data, MIOpen weight gradient) == F.conv2d under autograd, on a
+    shape the dispatcher sends to K10 and on one it leaves to MIOpen; frozen_weights() caches the transformed filter."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for (B, C, K, H, W, pad, expect_wino) in [(12, 64, 64, 40, 128, 1, True), (2, 64, 16, 20, 32, 1, False),
+                                              (12, 128, 64, 42, 130, 0, True)]:
+        assert ops._wino_ok(B, C, K, H + 2 * pad - 2, W + 2 * pad - 2) == expect_wino
+        x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
+        w = ((torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.2).requires_grad_(True)
+        b = (torch.rand(K, device="cuda", generator=g) - 0.5).requires_grad_(True)
+        got = ops.conv3x3(x, w, b, pad)
+        ref = F.conv2d(x, w, b, padding=pad)
+        wt = torch.rand(ref.shape, device="cuda", generator=g)
+        ga = torch.autograd.grad((got * wt).sum(), [x, w, b])
+        gb = torch.autograd.grad((ref * wt).sum(), [x, w, b])
+        torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+        for a_, b_ in zip(ga, gb):
+            torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5 * float(b_.abs().max()))
+    w = torch.rand(64, 64, 3, 3, device="cuda").requires_grad_(True)
+    x = torch.rand(12, 64, 40, 128, device="cuda").requires_grad_(True)
+    with ops.frozen_weights():                              # parameters are constants of an attack: no weight gradient
+        gx, gw = torch.autograd.grad(ops.conv3x3(x, w, None, 1).sum(), [x, w], allow_unused=True)
+        assert gw is None and gx is not None
+    w = w.detach()
+    with ops.frozen_weights():
+        u1 = ops._wino_filter(w, False)
+        assert ops._wino_filter(w, False) is u1 and ops._wino_filter(w, True) is not u1
+        w.add_(1.0)                                     # an in-place update invalidates the cached transform
+        assert ops._wino_filter(w, False) is not u1
+    assert not ops._wino_cache
+
+
 def test_trainer_val_reports_attack_metrics(tmp_path):
     tr = _trainer(tmp_path, ["--adv_train", "--atk_steps", "1"])
     tr.val_eval_count = 1
