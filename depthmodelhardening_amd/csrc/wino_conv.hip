@@ -44,7 +44,9 @@ struct WArgs {
     float* y;
     int B, C, K, Kp, H, W, Ho, Wo, pad;
     int gx, gy, kg;              // tile-region groups along x / y, output-channel groups
-    int nitems;                  // B * gy * gx * kg work items
+    int csplit;                  // 1, or 2: the input channels of a region are split over two items that add
+                                 // their halves into a zeroed y (fills the chip when there are few regions)
+    int nitems;                  // B * gy * gx * kg * csplit work items
 };
 
 // pre-transform the filter: U = G g G^T, scattered into the chunked layout the kernel streams.
@@ -96,12 +98,13 @@ __global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict
 // output-channel group fastest and every workgroup takes a CONTIGUOUS range, so the channel groups of one region run
 // back to back on the same CU and re-read its input from L1/L2.
 struct Item {
-    int b, ty0, tx0, k0;
+    int b, ty0, tx0, k0, c0;     // c0: first channel chunk of the item (channel split)
 };
 template <int TRW>
 __device__ __forceinline__ Item decode_item(const WArgs& a, int item) {
     constexpr int TRH = 64 / TRW;
     Item it;
+    it.c0 = (item % a.csplit) * (a.C / CK / a.csplit);  item /= a.csplit;
     it.k0 = (item % a.kg) * 64;  item /= a.kg;
     it.tx0 = (item % a.gx) * TRW;  item /= a.gx;
     it.ty0 = (item % a.gy) * TRH;
@@ -124,7 +127,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t HW = (size_t)a.H * a.W;
-    const int nch = a.C / CK;
+    const int nch = a.C / CK / a.csplit;                    // channel chunks per item
 
     // ---- this workgroup's contiguous item range, flattened with the channel chunks into one iteration space
     const int q = a.nitems / (int)gridDim.x, r = a.nitems % (int)gridDim.x;
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const int iy0 = 2 * it.ty0 - a.pad, ix0 = 2 * it.tx0 - a.pad;                             \
         int tid_o = tid;    /* opaque copy: the slot decomposition below must not be hoisted and kept live */ \
         asm volatile("" : "+v"(tid_o));                                                           \
-        XB = a.x + (size_t)it.b * a.C * HW;                                                       \
-        USRC = a.U + (size_t)it.k0;                                                               \
+        XB = a.x + ((size_t)it.b * a.C + (size_t)it.c0 * CK) * HW;                                \
+        USRC = a.U + (size_t)it.k0 + (size_t)it.c0 * 32 * a.Kp;                                   \
         RVALID = 0;                                                                               \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
@@ -355,12 +358,19 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     s1[j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
                 }
                 if (inside && ko < a.K) {
-                    const float bs = a.bias ? a.bias[ko] : 0.f;
+                    const float bs = (a.bias && it.c0 == 0) ? a.bias[ko] : 0.f;
                     const float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
                     const float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
                     float* yp = yb + (size_t)ko * a.Ho * a.Wo;
-                    *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
-                    *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
+                    if (a.csplit == 1) {
+                        *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
+                        *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
+                    } else {    // two partial sums into zeros: 0 + a + b is the same in either order (deterministic)
+                        unsafeAtomicAdd(yp, y00);
+                        unsafeAtomicAdd(yp + 1, y01);
+                        unsafeAtomicAdd(yp + a.Wo, y10);
+                        unsafeAtomicAdd(yp + a.Wo + 1, y11);
+                    }
                 }
             }
 #pragma unroll
@@ -406,6 +416,20 @@ int launch(WArgs& a, hipStream_t st) {
     return check_launch("dmh_wino_conv3x3");
 }
 
+// few regions (small images): split the channels of every region over two items so that the launch covers the chip
+template <int TRW>
+int launch_split(WArgs& a, hipStream_t st) {
+    const int64_t regions = (int64_t)a.B * a.gx * a.gy * a.kg;
+    if (regions >= ((int64_t)1 << 30)) return fail(DMH_EINVAL, "%s: too many work items", "dmh_wino_conv3x3");
+    const int nch = a.C / CK;
+    a.csplit = (regions < (3 * num_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
+    a.nitems = (int)regions * a.csplit;
+    if (a.csplit > 1 &&
+        hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.B * a.K * a.Ho * a.Wo, st) != hipSuccess)
+        return fail(DMH_ELAUNCH, "%s: hipMemsetAsync failed", "dmh_wino_conv3x3");
+    return launch<TRW>(a, st);
+}
+
 }  // namespace
 
 extern "C" {
@@ -444,14 +468,10 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
     const bool narrow = (Wt % 32) != 0 && (Wt <= 16 || ((Wt + 15) / 16 * 16 - Wt) < ((Wt + 31) / 32 * 32 - Wt));
     if (narrow) {
         a.gx = (Wt + 15) / 16; a.gy = (Ht + 3) / 4;
-        DMH_REQUIRE((int64_t)B * a.gx * a.gy * a.kg < ((int64_t)1 << 31), "too many work items");
-        a.nitems = B * a.gx * a.gy * a.kg;
-        return launch<16>(a, (hipStream_t)stream);
+        return launch_split<16>(a, (hipStream_t)stream);
     }
     a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2;
-    DMH_REQUIRE((int64_t)B * a.gx * a.gy * a.kg < ((int64_t)1 << 31), "too many work items");
-    a.nitems = B * a.gx * a.gy * a.kg;
-    return launch<32>(a, (hipStream_t)stream);
+    return launch_split<32>(a, (hipStream_t)stream);
 }
 
 }  // extern "C"

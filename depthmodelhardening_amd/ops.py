@@ -630,10 +630,14 @@ def _wino_ok(B, n_in, n_out, Ho, Wo):
     work items to fill the 256 CUs (measured crossover, tools/wino_bench.py)."""
     if not WINO_ENABLED or n_in % 8 or n_in < 24 or n_out < 64 or Ho % 2 or Wo % 2 or Ho < 2 or Wo < 2:
         return False
+    if n_in < 64 and n_out % 64:        # few chunks per item and a half-empty channel group: MIOpen is level or ahead
+        return False
     ht, wt = Ho // 2, Wo // 2
     narrow = wt % 32 != 0 and (wt <= 16 or (-wt) % 16 < (-wt) % 32)
-    groups = (-(-wt // 16)) * (-(-ht // 4)) if narrow else (-(-wt // 32)) * (-(-ht // 2))
-    return B * groups * (-(-n_out // 64)) >= 200
+    regions = B * ((-(-wt // 16)) * (-(-ht // 4)) if narrow else (-(-wt // 32)) * (-(-ht // 2))) * (-(-n_out // 64))
+    nch = n_in // 8
+    split = 2 if (regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split() in wino_conv.hip
+    return regions * split >= 200
 
 
 def _wino_conv(x, U, bias, K, pad):

@@ -263,6 +263,7 @@ def test_fused_eval_encoder_matches_module_path(num_layers):
     (1, 128, 192, 12, 64, 0),   # decoder-like: un-padded input, K not a multiple of 64... of 128
     (2, 64, 96, 10, 66, 2),     # backward-data geometry of a pad-0 convolution (pad 2), ragged tile columns
     (1, 24, 64, 6, 34, 1),      # minimum channel count (3 chunks)
+    (2, 128, 128, 8, 32, 1),    # few regions: the channels are split over two items that add into a zeroed output
 ])
 def test_wino_conv3x3_kernel_vs_aten(shape):
     """K10 through the C ABI == ATen conv2d, forward and backward-data (the same kernel on the flipped filter)."""
