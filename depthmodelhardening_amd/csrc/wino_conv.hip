@@ -266,9 +266,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
             const float* xc = (r_next ? xb_n + (size_t)(ch + 3 - nch) * CK * HW : xb + (size_t)(ch + 3) * CK * HW);
             const f32x4* uc = (u_next ? usrc_n : usrc + (size_t)(ch + 1) * 32 * a.Kp);
-            unsigned ro[RAW_PER_T];
-#pragma unroll
-            for (int k = 0; k < RAW_PER_T; ++k) ro[k] = r_next ? roff_n[k] : roff[k];
             const unsigned rv = (ch + 2 >= nch) ? rvalid_n : rvalid;
             // The block is written in issue order and fenced (sched_barrier) per SLOT = 2 MFMAs on two alternating
             // accumulators (128 cycles of matrix pipe) + one operand read for the next position pair + a few
@@ -325,7 +322,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                     for (int k = (sl - 28) * ((RAW_PER_T + 3) / 4); k < min((sl - 27) * ((RAW_PER_T + 3) / 4), RAW_PER_T); ++k) {
                         if (!(DMH_WINO_ABLATE & 4)) raw[cur * RAW_BUF + tid + NT * k] = (rv >> k) & 1u ? rreg[k] : 0.f;
-                        if (!(DMH_WINO_ABLATE & 1)) rreg[k] = xc[ro[k]];
+                        if (!(DMH_WINO_ABLATE & 1)) rreg[k] = xc[r_next ? roff_n[k] : roff[k]];
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -372,6 +369,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         unsafeAtomicAdd(yp + a.Wo + 1, y11);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);   // one output channel at a time: hoisted accumulator reads spill
             }
 #pragma unroll
             for (int pp = 0; pp < 16; ++pp)
