@@ -650,6 +650,23 @@ def _wino_conv(x, U, bias, K, pad):
     return y
 
 
+def _small_ok(n_in, n_out):
+    """Channel counts of the K11 direct-MFMA kernel (last decoder stage, disparity heads)."""
+    return WINO_ENABLED and ((n_in == 16 and n_out <= 32) or (n_in == 32 and n_out <= 16))
+
+
+def _small_conv(x, weight, bias, pad, backward):
+    lib = N.lib()
+    B, _, H, W = x.shape
+    Kw, Cw = weight.shape[0], weight.shape[1]
+    n_out = Cw if backward else Kw
+    y = torch.empty((B, n_out, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
+    nb = 4 * (x.numel() + y.numel())
+    N.check(_timed("conv3x3_small", lambda: lib.dmh_conv3x3_small(N.ptr(x), N.ptr(_c(weight.detach())), N.ptr(bias), B, Kw,
+                                                                 Cw, H, W, pad, int(backward), N.ptr(y), N.stream()), nb))
+    return y
+
+
 class _Conv3x3(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, pad):
@@ -661,6 +678,8 @@ class _Conv3x3(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         if _wino_ok(B, Cc, K, H + 2 * pad - 2, W + 2 * pad - 2):
             return _wino_conv(x, _wino_filter(weight, False), None if bias is None else _c(bias.detach()), K, pad)
+        if _small_ok(Cc, K):
+            return _small_conv(x, weight, None if bias is None else _c(bias.detach()), pad, False)
         return torch.conv2d(x, weight, bias, 1, pad)
 
     @staticmethod
@@ -677,6 +696,9 @@ class _Conv3x3(torch.autograd.Function):
         if need_x and _wino_ok(B, K, Cc, H, W):
             # backward-data = the same convolution on g with the flipped/transposed filter and pad' = 2 - pad
             g_x = _wino_conv(g, _wino_filter(weight, True), None, Cc, 2 - pad)
+            need_x = False
+        elif need_x and _small_ok(K, Cc):
+            g_x = _small_conv(g, weight, None, 2 - pad, True)
             need_x = False
         if need_x or need_w or need_b:
             r = torch.ops.aten.convolution_backward(g, x, weight, [K] if ctx.has_bias else None, [1, 1], [pad, pad], [1, 1],

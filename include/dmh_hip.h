@@ -266,6 +266,17 @@ int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float*
 int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
                      float* y, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K11 3x3 stride-1 convolution with few channels (16 -> <=32 or 32 -> <=16) at full image resolution, direct implicit
+ *     GEMM on v_mfma_f32_16x16x4_f32 with the filter held in registers: the last decoder stage and the disparity heads
+ *     (MD2/networks/depth_decoder.py:38-44).  w is the FORWARD filter [Kw][Cw][3][3] in both directions:
+ *       backward == 0:  y[B,Kw,H+2pad-2,W+2pad-2] = corr3x3(zero_pad(x[B,Cw,H,W], pad), w) + bias
+ *       backward != 0:  y[B,Cw,...]               = corr3x3(zero_pad(x[B,Kw,H,W], pad), flip(w)^T)   (bias ignored if NULL)
+ *     so the gradient w.r.t. the input of a pad-p convolution is the backward call on g_out with pad = 2 - p.
+ * ---------------------------------------------------------------------------------- */
+int dmh_conv3x3_small(const float* x, const float* w, const float* bias, int B, int Kw, int Cw, int H, int W, int pad,
+                      int backward, float* y, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -310,6 +310,40 @@ def test_wino_conv3x3_rejects_bad_shapes():
     assert lib.dmh_wino_weight_size(64, 12) == -1
 
 
+@pytest.mark.parametrize("shape", [
+    # B, C, K, Ho, Wo, pad
+    (2, 16, 16, 24, 130, 0),    # decoder upconv(0,1)-like, ragged tile columns
+    (1, 32, 16, 9, 64, 1),      # upconv(0,0)-like with zero padding, ragged tile rows
+    (2, 16, 1, 16, 70, 0),      # disparity head: one output channel
+    (1, 16, 32, 12, 66, 2),     # backward-data geometry of a 32 -> 16 convolution
+])
+def test_small_conv3x3_kernel_vs_aten(shape):
+    """K11 through the C ABI == ATen conv2d, forward; and the backward flag == the gradient w.r.t. the input."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    B, C, K, Ho, Wo, pad = shape
+    H, W = Ho + 2 - 2 * pad, Wo + 2 - 2 * pad
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + C + K)
+    x = torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5
+    w = (torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.3
+    b = torch.rand(K, device="cuda", generator=g) - 0.5
+    y = torch.full((B, K, Ho, Wo), float("nan"), device="cuda")
+    N.check(lib.dmh_conv3x3_small(N.ptr(x), N.ptr(w), N.ptr(b), B, K, C, H, W, pad, 0, N.ptr(y), N.stream()))
+    ref = F.conv2d(x, w, b, padding=pad)
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+    # backward-data of a convolution whose INPUT has K channels and OUTPUT C channels: filter [C][K][3][3]
+    wf = (torch.rand(C, K, 3, 3, device="cuda", generator=g) - 0.5) * 0.3
+    if (C == 16 and K <= 32) or (C == 32 and K <= 16):
+        gy = torch.rand(B, C, Ho, Wo, device="cuda", generator=g) - 0.5
+        xin = torch.zeros(B, K, Ho + 2 - 2 * pad, Wo + 2 - 2 * pad, device="cuda", requires_grad=True)
+        gref = torch.autograd.grad(F.conv2d(xin, wf, None, padding=pad), xin, gy)[0]
+        gx = torch.full_like(gref, float("nan"))
+        N.check(lib.dmh_conv3x3_small(N.ptr(gy), N.ptr(wf), None, B, C, K, Ho, Wo, 2 - pad, 1, N.ptr(gx), N.stream()))
+        torch.testing.assert_close(gx, gref, rtol=1e-5, atol=2e-6 * float(gref.abs().max()))
+    assert lib.dmh_conv3x3_small(N.ptr(x), N.ptr(w), None, B, 64, 64, H, W, pad, 0, N.ptr(y), N.stream()) != 0
+
+
 def test_conv3x3_op_autograd_matches_aten():
     """ops.conv3x3 (Winograd-MFMA forward + backward-data, MIOpen weight gradient) == F.conv2d under autograd, on a
     shape the dispatcher sends to K10 and on one it leaves to MIOpen; frozen_weights() caches the transformed filter."""
@@ -317,7 +351,8 @@ def test_conv3x3_op_autograd_matches_aten():
     from depthmodelhardening_amd import ops
     g = torch.Generator(device="cuda").manual_seed(7)
     for (B, C, K, H, W, pad, expect_wino) in [(12, 64, 64, 40, 128, 1, True), (2, 64, 16, 20, 32, 1, False),
-                                              (12, 128, 64, 42, 130, 0, True)]:
+                                              (12, 128, 64, 42, 130, 0, True), (2, 16, 16, 34, 66, 0, False),
+                                              (2, 32, 16, 18, 66, 0, False)]:      # the last two: K11
         assert ops._wino_ok(B, C, K, H + 2 * pad - 2, W + 2 * pad - 2) == expect_wino
         x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
         w = ((torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.2).requires_grad_(True)

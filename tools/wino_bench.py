@@ -26,7 +26,7 @@ SHAPES = [
     (512, 256, 10, 32, 0, "dec upconv4_0"), (512, 256, 20, 64, 0, "dec upconv4_1"), (256, 128, 20, 64, 0, "dec upconv3_0"),
     (256, 128, 40, 128, 0, "dec upconv3_1"), (128, 64, 40, 128, 0, "dec upconv2_0"), (128, 64, 80, 256, 0, "dec upconv2_1"),
     (64, 32, 80, 256, 0, "dec upconv1_0"), (96, 32, 160, 512, 0, "dec upconv1_1"), (32, 16, 160, 512, 0, "dec upconv0_0"),
-    (16, 16, 320, 1024, 0, "dec upconv0_1"),
+    (16, 16, 320, 1024, 0, "dec upconv0_1"), (16, 1, 320, 1024, 0, "dec dispconv0"), (32, 1, 160, 512, 0, "dec dispconv1"),
 ]
 
 
@@ -38,7 +38,7 @@ def transform(w, backward):
     return U
 
 
-def wino(x, U, bias, K, pad):
+def wino_k10(x, U, bias, K, pad):
     Bn, C, H, W = x.shape
     y = torch.empty(Bn, K, H + 2 * pad - 2, W + 2 * pad - 2, device=dev)
     N.check(lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), N.ptr(bias), Bn, C, K, H, W, pad, N.ptr(y), N.stream()))
@@ -76,17 +76,30 @@ for (C, K, Ho, Wo, pad, name) in SHAPES:
     gref = torch.autograd.grad(F.conv2d(xr, w, None, padding=pad), xr, gy)[0]
     torch.cuda.synchronize()
     first = time.time() - t0
-    Uf, Ub = transform(w, False), transform(w, True)
+    small = (C == 16 and K <= 32) or (C == 32 and K <= 16)
+    if small:       # K11 (direct MFMA, filter in registers) instead of K10
+        def wino(inp, U, bs, n_out, p, _w=w):
+            Bn, _, Hi, Wi = inp.shape
+            out = torch.empty(Bn, n_out, Hi + 2 * p - 2, Wi + 2 * p - 2, device=dev)
+            N.check(lib.dmh_conv3x3_small(N.ptr(inp), N.ptr(_w), N.ptr(bs), Bn, _w.shape[0], _w.shape[1], Hi, Wi, p,
+                                          int(U is None), N.ptr(out), N.stream()))
+            return out
+        Uf, Ub = 1, None
+        bwd_ok = (K == 16 and C <= 32) or (K == 32 and C <= 16)
+    else:
+        wino = wino_k10
+        Uf, Ub = transform(w, False), transform(w, True)
+        bwd_ok = True
     got = wino(x, Uf, bias, K, pad)
-    ggot = wino(gy, Ub, None, C, 2 - pad)
+    ggot = wino(gy, Ub, None, C, 2 - pad) if bwd_ok else gref
     ef = float((got - ref).abs().max() / ref.abs().max())
     eb = float((ggot - gref).abs().max() / gref.abs().max())
     mi_f = timeit(lambda: F.conv2d(x, w, bias, padding=pad))
     wi_f = timeit(lambda: wino(x, Uf, bias, K, pad))
     y = F.conv2d(xr, w, None, padding=pad)
     mi_b = timeit(lambda: torch.autograd.grad(y, xr, gy, retain_graph=True))
-    wi_b = timeit(lambda: wino(gy, Ub, None, C, 2 - pad))
-    tr = timeit(lambda: transform(w, False))
+    wi_b = timeit(lambda: wino(gy, Ub, None, C, 2 - pad)) if bwd_ok else float('nan')
+    tr = timeit(lambda: transform(w, False)) if not small else 0.0
     for k, v in zip(("mi_f", "wi_f", "mi_b", "wi_b"), (mi_f, wi_f, mi_b, wi_b)):
         tot[k] += v
     print("%-14s C%4d K%4d %4dx%-4d pad%d | fwd miopen %7.1f (%5.1f TF/s) wino %7.1f (%5.1f TF/s) err %.1e | "
