@@ -1,4 +1,4 @@
-// K11 -- 3x3 stride-1 convolution with FEW channels (16 or 32 in, <= 32 out) at full image resolution: the last
+// K11 -- 3x3 stride-1 convolution with FEW channels (<= 4, 16 or 32 in, <= 32 out) at full image resolution: the last
 // decoder stage, MD2/networks/depth_decoder.py:38-41 upconv(0,0) 32->16 @160x512, upconv(0,1) 16->16 @320x1024 and the
 // disparity heads (MD2/layers.py:127-141 Conv3x3), forward and backward-data.
 //
@@ -48,13 +48,13 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
     const int b = bid / a.gy;
     const int oy0 = gyi * TH, ox0 = gxi * TW;
     const size_t HW = (size_t)a.H * a.W;
-    const float* xb = a.x + (size_t)b * C * HW;
+    const float* xb = a.x + (size_t)b * a.n_in * HW;      // n_in <= C: missing channels are staged as zeros
 
     // ---- stage the input tile: rows oy0-pad .. +RH, cols ox0-pad .. +RW of every channel (zero outside the image).
     //      All loads are issued before the first LDS write, so their latencies overlap.  Two index schemes, chosen by
     //      measurement (tools/wino_bench.py): flat element index for 16 channels, one wave-load per (channel, row) with
     //      scalar row arithmetic for 32.
-    if (NQ == 4) {
+    if (NQ <= 4) {
         constexpr int PER_T = (C * RH * RW + NT - 1) / NT;
         float stage[PER_T];
 #pragma unroll
@@ -62,9 +62,9 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
             const int e = tid + NT * k;
             const int c = e / (RH * RW), rem = e - c * (RH * RW), r = rem / RW, xx = rem - r * RW;
             const int iy = oy0 - a.pad + r, ix = ox0 - a.pad + xx;
-            const bool ok = e < C * RH * RW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const bool ok = e < C * RH * RW && c < a.n_in && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-            const float v = xb[(size_t)(e < C * RH * RW ? c : 0) * HW + (size_t)cy * a.W + cx];
+            const float v = xb[(size_t)(ok ? c : 0) * HW + (size_t)cy * a.W + cx];
             stage[k] = ok ? v : 0.f;
         }
 #pragma unroll
@@ -122,7 +122,7 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 float v = 0.f;
-                if (ko < a.n_out)
+                if (ko < a.n_out && ci < a.n_in)
                     v = a.backward ? a.w[((size_t)ci * a.Cw + ko) * 9 + (8 - t)] : a.w[((size_t)ko * a.Cw + ci) * 9 + t];
                 wreg[kb][q][t] = v;
             }
@@ -208,10 +208,12 @@ int dmh_conv3x3_small(const float* x, const float* w, const float* bias, int B, 
     DMH_REQUIRE((int64_t)a.n_in * H * W < ((int64_t)1 << 31) && (int64_t)a.n_out * a.Ho * a.Wo < ((int64_t)1 << 31),
                 "image too large");
     hipStream_t st = (hipStream_t)stream;
+    if (a.n_in <= 4 && a.n_out <= 16) return launch<1, 1, 8>(a, st);      // disparity-head backward: 1 -> 16
+    if (a.n_in <= 4 && a.n_out <= 32) return launch<1, 2, 8>(a, st);
     if (a.n_in == 16 && a.n_out <= 16) return launch<4, 1, 8>(a, st);
     if (a.n_in == 16 && a.n_out <= 32) return launch<4, 2, 8>(a, st);
     if (a.n_in == 32 && a.n_out <= 16) return launch<8, 1, 4>(a, st);
-    return fail(DMH_EINVAL, "%s: supported channel counts are 16 -> <=32 and 32 -> <=16", "dmh_conv3x3_small");
+    return fail(DMH_EINVAL, "%s: supported channel counts are <=4 -> <=32, 16 -> <=32 and 32 -> <=16", "dmh_conv3x3_small");
 }
 
 }  // extern "C"

@@ -652,7 +652,7 @@ def _wino_conv(x, U, bias, K, pad):
 
 def _small_ok(n_in, n_out):
     """Channel counts of the K11 direct-MFMA kernel (last decoder stage, disparity heads)."""
-    return WINO_ENABLED and ((n_in == 16 and n_out <= 32) or (n_in == 32 and n_out <= 16))
+    return WINO_ENABLED and ((n_in in (1, 2, 3, 4, 16) and n_out <= 32) or (n_in == 32 and n_out <= 16))
 
 
 def _small_conv(x, weight, bias, pad, backward):

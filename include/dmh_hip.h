@@ -267,7 +267,7 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
                      float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * K11 3x3 stride-1 convolution with few channels (16 -> <=32 or 32 -> <=16) at full image resolution, direct implicit
+ * K11 3x3 stride-1 convolution with few channels (<=4 -> <=32, 16 -> <=32 or 32 -> <=16) at full resolution, direct implicit
  *     GEMM on v_mfma_f32_16x16x4_f32 with the filter held in registers: the last decoder stage and the disparity heads
  *     (MD2/networks/depth_decoder.py:38-44).  w is the FORWARD filter [Kw][Cw][3][3] in both directions:
  *       backward == 0:  y[B,Kw,H+2pad-2,W+2pad-2] = corr3x3(zero_pad(x[B,Cw,H,W], pad), w) + bias
