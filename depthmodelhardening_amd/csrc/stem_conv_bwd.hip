@@ -1,0 +1,132 @@
+// K12 -- gradient w.r.t. the INPUT IMAGE of the encoder's first convolution (7x7, stride 2, pad 3, 3 -> 64 channels,
+// torchvision ResNet.conv1 under MD2/networks/resnet_encoder.py:88).  Every attack step needs it (the patch gradient
+// flows through the pasted scene), and MIOpen serves it with a per-image GEMM + col2im + layout transposes
+// (profiles/r01_bench_timed_region.csv: 120 + 120 launches, ~8.4 ms of a step).
+//
+// Direct gather form, no atomics.  One thread owns a 2x2 block of image pixels (the four stride-2 parity classes) and
+// all CIN image channels.  For gradient channel k the block reads a 4x4 neighbourhood of g_y[k] (shared by the four
+// pixels) and applies the 49 taps split by parity: 9 + 12 + 12 + 16 taps x CIN FMAs,
+//     g_x[c][2Y+py][2X+px] = sum_k sum_{dy,dx} g_y[k][Y-1+dy][X-1+dx] * w[k][c][py+5-2dy][px+5-2dx]   (taps in 0..6).
+// The filter is uniform across the wave: it is read through scalar loads and fed to the FMAs as SGPR operands; g_y
+// tiles are staged in LDS 8 channels at a time (zero outside the image).  VALU-bound: 147 FMAs + 16 LDS reads per
+// (thread, k).
+#include "common.hpp"
+
+using namespace dmh;
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int BY = 8, BX = 32;              // 2x2 blocks per workgroup: 16 x 64 image pixels
+constexpr int KC = 8;                       // gradient channels per LDS stage
+constexpr int RH = BY + 3, RW = BX + 3;     // g_y region: rows Y0-1 .. Y0+BY+1, cols X0-1 .. X0+BX+1
+
+template <int CIN>
+__global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ w,
+                                                           int K, int Ho, int Wo, int gx, int gyb,
+                                                           float* __restrict__ gxo) {
+    __shared__ float tile[KC * RH * RW];
+    const int tid = threadIdx.x;
+    int bid = blockIdx.x;
+    const int bxi = bid % gx;  bid /= gx;
+    const int byi = bid % gyb;
+    const int b = bid / gyb;
+    const int Y0 = byi * BY, X0 = bxi * BX;
+    const int ty = tid / BX, tx = tid - ty * BX;
+    const size_t HWo = (size_t)Ho * Wo;
+    const float* gb = gy + (size_t)b * K * HWo;
+
+    float acc[2][2][CIN];
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+            for (int c = 0; c < CIN; ++c) acc[py][px][c] = 0.f;
+
+    constexpr int PER_T = (KC * RH * RW + NT - 1) / NT;
+    for (int k0 = 0; k0 < K; k0 += KC) {
+        float stage[PER_T];
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int e = tid + NT * i;
+            const int kk = e / (RH * RW), rem = e - kk * (RH * RW), r = rem / RW, xx = rem - r * RW;
+            const int oy = Y0 - 1 + r, ox = X0 - 1 + xx;
+            const bool ok = e < KC * RH * RW && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
+            const float v = gb[(size_t)(k0 + (ok ? kk : 0)) * HWo + (size_t)min(max(oy, 0), Ho - 1) * Wo + min(max(ox, 0), Wo - 1)];
+            stage[i] = ok ? v : 0.f;
+        }
+        __syncthreads();                    // the previous stage has been consumed
+#pragma unroll
+        for (int i = 0; i < PER_T; ++i) {
+            const int e = tid + NT * i;
+            if (e < KC * RH * RW) tile[e] = stage[i];
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int kk = 0; kk < KC; ++kk) {
+            const float* tp = tile + kk * (RH * RW) + ty * RW + tx;
+            const float* wk = w + (size_t)(k0 + kk) * CIN * 49;          // uniform: scalar loads
+            float g[4][4];
+#pragma unroll
+            for (int dy = 0; dy < 4; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 4; ++dx) g[dy][dx] = tp[dy * RW + dx];
+#pragma unroll
+            for (int c = 0; c < CIN; ++c)
+#pragma unroll
+                for (int py = 0; py < 2; ++py)
+#pragma unroll
+                    for (int dy = 0; dy < 4; ++dy) {
+                        const int ky = py + 5 - 2 * dy;
+                        if (ky < 0 || ky > 6) continue;
+#pragma unroll
+                        for (int px = 0; px < 2; ++px)
+#pragma unroll
+                            for (int dx = 0; dx < 4; ++dx) {
+                                const int kx = px + 5 - 2 * dx;
+                                if (kx < 0 || kx > 6) continue;
+                                acc[py][px][c] = fmaf(g[dy][dx], wk[c * 49 + ky * 7 + kx], acc[py][px][c]);
+                            }
+                    }
+        }
+    }
+    const int Y = Y0 + ty, X = X0 + tx;
+    if (Y < Ho && X < Wo) {
+        const int H = 2 * Ho, W = 2 * Wo;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+            float* op = gxo + (((size_t)b * CIN + c) * H + 2 * Y) * W + 2 * X;
+            *reinterpret_cast<float2*>(op) = make_float2(acc[0][0][c], acc[0][1][c]);
+            *reinterpret_cast<float2*>(op + W) = make_float2(acc[1][0][c], acc[1][1][c]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int Cin, int H, int W, float* g_x,
+                           void* stream) {
+    DMH_REQUIRE(g_y && w && g_x, "null pointer");
+    DMH_REQUIRE(B > 0 && K > 0 && K % KC == 0, "gradient channel count must be a multiple of 8");
+    DMH_REQUIRE(Cin >= 1 && Cin <= 4, "1 to 4 image channels");
+    DMH_REQUIRE(H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "image height and width must be even");
+    const int Ho = H / 2, Wo = W / 2;
+    DMH_REQUIRE((int64_t)K * Ho * Wo < ((int64_t)1 << 31), "image too large");
+    const int gx = (Wo + BX - 1) / BX, gyb = (Ho + BY - 1) / BY;
+    const long long blocks = (long long)B * gx * gyb;
+    DMH_REQUIRE(blocks < (1ll << 31), "grid too large");
+    hipStream_t st = (hipStream_t)stream;
+#define DMH_LAUNCH(CIN) \
+    hipLaunchKernelGGL(stem_conv_bwd_kernel<CIN>, dim3((unsigned)blocks), dim3(NT), 0, st, g_y, w, K, Ho, Wo, gx, gyb, g_x)
+    if (Cin == 1) DMH_LAUNCH(1);
+    else if (Cin == 2) DMH_LAUNCH(2);
+    else if (Cin == 3) DMH_LAUNCH(3);
+    else DMH_LAUNCH(4);
+#undef DMH_LAUNCH
+    return check_launch("dmh_conv7x7s2_bwd_data");
+}
+
+}  // extern "C"

@@ -157,7 +157,7 @@ class ResnetEncoder(nn.Module):
         if e.fused_eval_ok(x):
             self.features = self._forward_fused_eval(x)
             return self.features
-        f0 = e.relu(e.bn1(e.conv1(x)))
+        f0 = e.relu(e.bn1(self._conv1(x)))
         f1 = e.layer1(e.maxpool(f0))
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)
@@ -165,10 +165,17 @@ class ResnetEncoder(nn.Module):
         self.features = [f0, f1, f2, f3, f4]
         return self.features
 
+    def _conv1(self, x):
+        c = self.encoder.conv1
+        if (x.is_cuda and x.dtype == torch.float32 and c.kernel_size == (7, 7) and c.stride == (2, 2)
+                and c.padding == (3, 3) and c.dilation == (1, 1) and c.groups == 1 and c.bias is None):
+            return ops.stem_conv(x, c.weight)
+        return c(x)
+
     def _forward_fused_eval(self, x):
         e = self.encoder
         aff = e.eval_affine()
-        z = e.conv1(x)
+        z = self._conv1(x)
         if z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
             f0, y = ops.stem_bn_relu_pool(z, *aff[e.bn1])
         else:

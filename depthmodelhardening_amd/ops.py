@@ -721,6 +721,44 @@ def conv3x3(x, weight, bias=None, padding=1):
     return _Conv3x3.apply(_c(x), weight, bias, int(padding))
 
 
+class _StemConv(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        ctx.params_const = _wino_frozen > 0
+        return torch.conv2d(x, weight, None, 2, 3)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        lib = N.lib()
+        g = _c(g)
+        B, Cin, H, W = x.shape
+        K = weight.shape[0]
+        g_x = g_w = None
+        need_w = ctx.needs_input_grad[1] and not ctx.params_const
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty_like(x)
+            nb = 4 * (g.numel() + g_x.numel())
+            N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(_c(weight.detach())), B, K,
+                                                                              Cin, H, W, N.ptr(g_x), N.stream()), nb))
+        if need_w:
+            g_w = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                      [False, True, False])[1]
+        return g_x, g_w
+
+
+def stem_conv(x, weight):
+    """nn.Conv2d(Cin, K, 7, stride=2, padding=3, bias=False) -- the encoder's first convolution
+    (MD2/networks/resnet_encoder.py:88).  Forward and the weight gradient are MIOpen; the gradient w.r.t. the image (what
+    every attack step back-propagates to the patch) is the K12 gather kernel."""
+    B, Cin, H, W = x.shape
+    if (not x.is_cuda or not WINO_ENABLED or weight.shape[1:] != (Cin, 7, 7) or Cin > 4 or weight.shape[0] % 8 or H % 2
+            or W % 2 or not x.requires_grad):
+        return torch.conv2d(x, weight, None, 2, 3)
+    return _StemConv.apply(_c(x), weight)
+
+
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,
                         clamp_hi=80.0):
     """The eight attack-evaluation metrics of MD2/evaluate_depth.py:57-99 computed from two disparity maps in one

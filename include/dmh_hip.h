@@ -277,6 +277,14 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
 int dmh_conv3x3_small(const float* x, const float* w, const float* bias, int B, int Kw, int Cw, int H, int W, int pad,
                       int backward, float* y, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K12 gradient w.r.t. the input image of the encoder's first convolution, nn.Conv2d(Cin, K, 7, stride 2, padding 3)
+ *     (torchvision ResNet.conv1, MD2/networks/resnet_encoder.py:88): g_x[B,Cin,H,W] from g_y[B,K,H/2,W/2] and the forward
+ *     filter w[K][Cin][7][7].  Direct gather, no atomics.  Cin <= 4, K a multiple of 8, H and W even.
+ * ---------------------------------------------------------------------------------- */
+int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int Cin, int H, int W, float* g_x,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -345,6 +345,30 @@ def test_small_conv3x3_kernel_vs_aten(shape):
     assert lib.dmh_conv3x3_small(N.ptr(x), N.ptr(w), None, B, 64, 64, H, W, pad, 0, N.ptr(y), N.stream()) != 0
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 64, 32, 96), (1, 3, 64, 20, 66), (1, 4, 16, 18, 34), (2, 1, 8, 6, 8)])
+def test_stem_conv_bwd_data_vs_aten(shape):
+    """K12 == the gradient of conv2d(k=7, stride 2, pad 3) w.r.t. its input; ops.stem_conv under autograd."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import _native as N, ops
+    lib = N.lib()
+    B, Cin, K, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(B + Cin + K)
+    x = (torch.rand(B, Cin, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    w = ((torch.rand(K, Cin, 7, 7, device="cuda", generator=g) - 0.5) * 0.2).requires_grad_(True)
+    y = F.conv2d(x, w, None, 2, 3)
+    gy = torch.rand(y.shape, device="cuda", generator=g) - 0.5
+    gref, gwref = torch.autograd.grad(y, [x, w], gy)
+    gx = torch.full_like(x, float("nan"))
+    N.check(lib.dmh_conv7x7s2_bwd_data(N.ptr(gy), N.ptr(w.detach()), B, K, Cin, H, W, N.ptr(gx), N.stream()))
+    torch.testing.assert_close(gx, gref, rtol=1e-5, atol=2e-6 * float(gref.abs().max()))
+    y2 = ops.stem_conv(x, w)
+    torch.testing.assert_close(y2, y)
+    g2, gw2 = torch.autograd.grad(y2, [x, w], gy)
+    torch.testing.assert_close(g2, gref, rtol=1e-5, atol=2e-6 * float(gref.abs().max()))
+    torch.testing.assert_close(gw2, gwref, rtol=1e-4, atol=1e-5 * float(gwref.abs().max()))
+    assert lib.dmh_conv7x7s2_bwd_data(N.ptr(gy), N.ptr(w.detach()), B, K, Cin, H + 1, W, N.ptr(gx), N.stream()) != 0
+
+
 def test_conv3x3_op_autograd_matches_aten():
     """ops.conv3x3 (Winograd-MFMA forward + backward-data, MIOpen weight gradient) == F.conv2d under autograd, on a
     shape the dispatcher sends to K10 and on one it leaves to MIOpen; frozen_weights() caches the transformed filter."""
