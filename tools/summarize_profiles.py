@@ -55,6 +55,29 @@ for k, v in tabs.items():
         print("%-50s HBM traffic = 2*FETCH_SIZE + WRITE_SIZE = %.1f + %.1f = %.1f MB per launch" % (
             k[:50], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
 
+ks10 = first(G + "k10_trace/*/*_kernel_stats.csv")
+if ks10:
+    shutil.copy(ks10, "profiles/%s_k10_kernel_stats.csv" % tag)
+tabs10 = {}
+for d in ["k10_pmc_a", "k10_fetch", "k10_write"]:
+    t, meta = pmc(d)
+    for k, v in t.items():
+        if "wino_" in k:
+            tabs10.setdefault(k, {}).update(v)
+            tabs10[k]["_meta"] = meta[k]
+if tabs10:
+    cols = sorted({c for v in tabs10.values() for c in v if c != "_meta"})
+    with open("profiles/%s_k10_pmc.csv" % tag, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "VGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"] + cols)
+        for k, v in tabs10.items():
+            w.writerow([k] + list(v["_meta"]) + [round(v.get(c, 0)) for c in cols])
+            if "conv_kernel" in k:
+                rd, wr = 2 * v.get("FETCH_SIZE", 0) * 1024, v.get("WRITE_SIZE", 0) * 1024
+                print("%-60s HBM traffic %.1f MB read + %.1f MB written; MFMA busy %.1f %% of CU-cycles" % (
+                    k[:60], rd / 1e6, wr / 1e6,
+                    100.0 * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(1.0, 4.0 * v.get("SQ_BUSY_CU_CYCLES", 1))))
+
 bs = first(G + "bench_trace/*/*_kernel_stats.csv")
 bt = first(G + "bench_trace/*/*_kernel_trace.csv")
 if bs and bt:
