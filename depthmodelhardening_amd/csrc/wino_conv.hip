@@ -46,7 +46,8 @@ struct WArgs {
     int gx, gy, kg;              // tile-region groups along x / y, output-channel groups
     int csplit;                  // 1, or 2: the input channels of a region are split over two items that add
                                  // their halves into a zeroed y (fills the chip when there are few regions)
-    int nitems;                  // B * gy * gx * kg * csplit work items
+    int bitems;                  // B (2x32 regions: per image) or 1 (4x16 regions: tile rows flattened over the batch)
+    int nitems;                  // bitems * gy * gx * kg * csplit work items
 };
 
 // pre-transform the filter: U = G g G^T, scattered into the chunked layout the kernel streams.
@@ -115,15 +116,23 @@ __device__ __forceinline__ Item decode_item(const WArgs& a, int item) {
 template <int TRW>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_conv_kernel(WArgs a) {
     constexpr int TRH = 64 / TRW;
-    constexpr int RH = 2 * TRH + 2, RW = 2 * TRW + 2;       // raw input region of a work item (per channel)
+    // 2 x 32 tile regions lie inside one image and their tile rows share input rows.  4 x 16 regions (small or ragged
+    // images) take their 4 tile rows from the rows of tiles of the WHOLE batch (row R = b * Ht + ty), so a 5-row image
+    // wastes nothing; consecutive tile rows may then belong to different images, so each stages its own 4 input rows
+    // (FLAT), and to stay inside 160 KB of LDS the raw region is single-buffered with a second barrier per chunk.
+    constexpr bool FLAT = TRW == 16;
+    constexpr int RW = 2 * TRW + 2;
+    constexpr int RH = FLAT ? 4 * TRH : 2 * TRH + 2;        // raw input rows of a work item (per channel)
+    constexpr int TRS = (FLAT ? 4 : 2) * RW;                // raw floats from one tile row to the next
     constexpr int RAW_N = CK * RH * RW;
     constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;
-    constexpr int RAW_BUF = RAW_PER_T * NT;                 // floats per raw buffer: every thread stores all its slots
+    constexpr int RAW_BUF = FLAT ? 0 : RAW_PER_T * NT;      // floats from raw buffer 0 to buffer 1 (FLAT: one buffer)
     constexpr int BUF = 16 * 2 * 64;                        // f32x4 words of one U or V image (32 KB)
     extern __shared__ f32x4 smem[];
     f32x4* U_lds = smem;                                    // [2 buffers][16][2][64]
     f32x4* V_lds = smem + 2 * BUF;                          // [2 buffers][16][2][64]
-    float* raw = reinterpret_cast<float*>(smem + 4 * BUF);  // [2 buffers][CK][RH][RW]
+    float* raw = reinterpret_cast<float*>(smem + 4 * BUF);  // [1 or 2 buffers][CK][RH][RW]
+    const int Ht = a.Ho >> 1, NR = a.B * Ht;                // FLAT: rows of tiles per image / in the batch
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const size_t HW = (size_t)a.H * a.W;
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     // transform role: wave wv owns chunk channels {2wv, 2wv+1} = (h = wv>>1, s = 2(wv&1) + {0,1}); lane = tile
     const int tly = lane / TRW, tlx = lane - tly * TRW;
-    const float* rsrc = raw + (2 * wv) * (RH * RW) + (2 * tly) * RW + 2 * tlx;
+    const float* rsrc = raw + (2 * wv) * (RH * RW) + tly * TRS + 2 * tlx;
     float* vdst = reinterpret_cast<float*>(V_lds + (wv >> 1) * 64 + lane) + 2 * (wv & 1);
     const int kb = wv & 1, tb = wv >> 1;
     const int aidx = (lane >> 5) * 64 + kb * 32 + (lane & 31);
@@ -155,19 +164,38 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, RVALID, XB, USRC)                                        \
     {                                                                                             \
         const Item it = decode_item<TRW>(a, ITEM);                                                \
-        const int iy0 = 2 * it.ty0 - a.pad, ix0 = 2 * it.tx0 - a.pad;                             \
+        const int ix0 = 2 * it.tx0 - a.pad;                                                       \
         int tid_o = tid;    /* opaque copy: the slot decomposition below must not be hoisted and kept live */ \
         asm volatile("" : "+v"(tid_o));                                                           \
         XB = a.x + ((size_t)it.b * a.C + (size_t)it.c0 * CK) * HW;                                \
         USRC = a.U + (size_t)it.k0 + (size_t)it.c0 * 32 * a.Kp;                                   \
         RVALID = 0;                                                                               \
+        /* FLAT: image and tile row of the region's 4 rows of tiles (uniform: scalar divisions) */ \
+        int fb[4], fy[4];                                                                         \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                           \
+            const int Rg = min(it.ty0 + t, NR - 1);                                               \
+            fb[t] = FLAT ? Rg / Ht : 0;                                                           \
+            fy[t] = FLAT ? Rg - fb[t] * Ht : 0;                                                   \
+        }                                                                                         \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
             const int c = e / (RH * RW), rem = e - c * (RH * RW), rr = rem / RW, xx = rem - rr * RW; \
-            const int iy = iy0 + rr, ix = ix0 + xx;                                               \
-            const bool ok = (e < RAW_N) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;            \
+            int iy, bofs = 0;                                                                     \
+            bool okr = e < RAW_N;                                                                 \
+            if (FLAT) {                                                                           \
+                const int t = rr >> 2;                                                            \
+                const int bb = t == 0 ? fb[0] : t == 1 ? fb[1] : t == 2 ? fb[2] : fb[3];          \
+                const int ty = t == 0 ? fy[0] : t == 1 ? fy[1] : t == 2 ? fy[2] : fy[3];          \
+                iy = 2 * ty - a.pad + (rr & 3);                                                   \
+                bofs = bb * a.C * (int)HW;                                                        \
+                okr = okr && it.ty0 + t < NR;                                                     \
+            } else {                                                                              \
+                iy = 2 * it.ty0 - a.pad + rr;                                                     \
+            }                                                                                     \
+            const int ix = ix0 + xx;                                                              \
+            const bool ok = okr && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                    \
             const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);               \
-            ROFF[k] = (unsigned)((e < RAW_N ? c : 0) * (int)HW + cy * a.W + cx);                  \
+            ROFF[k] = (unsigned)(bofs + (e < RAW_N ? c : 0) * (int)HW + cy * a.W + cx);           \
             RVALID |= ok ? (1u << k) : 0u;                                                        \
         }                                                                                         \
     }
@@ -246,6 +274,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             *reinterpret_cast<float2*>(vdst + (i * 4 + 3) * 512) = make_float2(t[0][i][1] - t[0][i][3], t[1][i][1] - t[1][i][3]);
         }
     }
+    if (FLAT) __syncthreads();          // single raw buffer: every wave has transformed chunk 0 out of it
     DMH_WINO_WRITE_RAW(1, rvalid)
     DMH_WINO_LOAD_RAW(xb + (size_t)2 * CK * HW, roff)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_PER_T) : "memory");   // the LDS-DMA of U[0] has landed
@@ -318,6 +347,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         *reinterpret_cast<float2*>(vd + (rr * 4 + 3) * 512) = make_float2(t[0][rr][1] - t[0][rr][3], t[1][rr][1] - t[1][rr][3]);
                     }
                 }
+                if (FLAT && sl == 28) {     // single raw buffer: every wave has read this chunk's patches (slots 8-17)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                }
                 if (sl >= 28) {                             // raw registers -> LDS, then refill them (4 slots)
 #pragma unroll
                     for (int k = (sl - 28) * ((RAW_PER_T + 3) / 4); k < min((sl - 27) * ((RAW_PER_T + 3) / 4), RAW_PER_T); ++k) {
@@ -341,9 +374,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             int lane_o = lane;      // opaque copy: keeps the per-lane store addresses from being hoisted out of the item loop
             asm volatile("" : "+v"(lane_o));
             const int tl = tb * 32 + (lane_o & 31);
-            const int oy = 2 * (it.ty0 + tl / TRW), ox = 2 * (it.tx0 + tl % TRW);
-            const bool inside = oy < a.Ho && ox < a.Wo;
-            float* yb = a.y + (size_t)it.b * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
+            const int Rt = it.ty0 + tl / TRW;                       // row of tiles: in the image, or (FLAT) in the batch
+            const int ob = FLAT ? min(Rt, NR - 1) / Ht : it.b;
+            const int oy = 2 * (FLAT ? Rt - ob * Ht : Rt), ox = 2 * (it.tx0 + tl % TRW);
+            const bool inside = (FLAT ? Rt < NR : oy < a.Ho) && ox < a.Wo;
+            float* yb = a.y + (size_t)ob * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
             const int kbase = it.k0 + kb * 32 + 4 * (lane_o >> 5);
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
@@ -398,8 +433,9 @@ int num_cus() {
 template <int TRW>
 int launch(WArgs& a, hipStream_t st) {
     constexpr int TRH = 64 / TRW;
-    // U and V images (double-buffered, 128 KB) + two raw input regions
-    constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)2 * ((CK * (2 * TRH + 2) * (2 * TRW + 2) + NT - 1) / NT * NT) * 4;
+    // U and V images (double-buffered, 128 KB) + the raw input region(s): see FLAT in the kernel
+    constexpr int RAWN = CK * (TRW == 16 ? 4 * TRH : 2 * TRH + 2) * (2 * TRW + 2);
+    constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(TRW == 16 ? 1 : 2) * ((RAWN + NT - 1) / NT * NT) * 4;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<TRW>),
@@ -417,7 +453,7 @@ int launch(WArgs& a, hipStream_t st) {
 // few regions (small images): split the channels of every region over two items so that the launch covers the chip
 template <int TRW>
 int launch_split(WArgs& a, hipStream_t st) {
-    const int64_t regions = (int64_t)a.B * a.gx * a.gy * a.kg;
+    const int64_t regions = (int64_t)a.bitems * a.gx * a.gy * a.kg;
     if (regions >= ((int64_t)1 << 30)) return fail(DMH_EINVAL, "%s: too many work items", "dmh_wino_conv3x3");
     const int nch = a.C / CK;
     a.csplit = (regions < (3 * num_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
@@ -465,10 +501,11 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
     // narrow images: 4 x 16 tile regions waste fewer lanes than 2 x 32 ones
     const bool narrow = (Wt % 32) != 0 && (Wt <= 16 || ((Wt + 15) / 16 * 16 - Wt) < ((Wt + 31) / 32 * 32 - Wt));
     if (narrow) {
-        a.gx = (Wt + 15) / 16; a.gy = (Ht + 3) / 4;
+        DMH_REQUIRE((int64_t)B * C * H * W < ((int64_t)1 << 31), "batch too large");
+        a.gx = (Wt + 15) / 16; a.gy = (B * Ht + 3) / 4; a.bitems = 1;     // rows of tiles flattened over the batch
         return launch_split<16>(a, (hipStream_t)stream);
     }
-    a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2;
+    a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2; a.bitems = B;
     return launch_split<32>(a, (hipStream_t)stream);
 }
 

@@ -634,7 +634,8 @@ def _wino_ok(B, n_in, n_out, Ho, Wo):
         return False
     ht, wt = Ho // 2, Wo // 2
     narrow = wt % 32 != 0 and (wt <= 16 or (-wt) % 16 < (-wt) % 32)
-    regions = B * ((-(-wt // 16)) * (-(-ht // 4)) if narrow else (-(-wt // 32)) * (-(-ht // 2))) * (-(-n_out // 64))
+    # 4x16 regions take their rows of tiles from the whole batch, 2x32 regions lie inside one image
+    regions = ((-(-wt // 16)) * (-(-(B * ht) // 4)) if narrow else B * (-(-wt // 32)) * (-(-ht // 2))) * (-(-n_out // 64))
     nch = n_in // 8
     split = 2 if (regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split() in wino_conv.hip
     return regions * split >= 200
