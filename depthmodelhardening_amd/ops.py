@@ -634,8 +634,12 @@ def _wino_ok(B, n_in, n_out, Ho, Wo):
         return False
     ht, wt = Ho // 2, Wo // 2
     narrow = wt % 32 != 0 and (wt <= 16 or (-wt) % 16 < (-wt) % 32)
-    # 4x16 regions take their rows of tiles from the whole batch, 2x32 regions lie inside one image
-    regions = ((-(-wt // 16)) * (-(-(B * ht) // 4)) if narrow else B * (-(-wt // 32)) * (-(-ht // 2))) * (-(-n_out // 64))
+    if narrow:      # 4x16 regions; rows of tiles flattened over the batch when per-image regions would waste >= 1/5
+        flat = 5 * ht <= 4 * (-(-ht // 4) * 4)
+        regions = (-(-wt // 16)) * (-(-(B * ht) // 4) if flat else B * -(-ht // 4))
+    else:
+        regions = B * (-(-wt // 32)) * (-(-ht // 2))
+    regions *= -(-n_out // 64)
     nch = n_in // 8
     split = 2 if (regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split() in wino_conv.hip
     return regions * split >= 200

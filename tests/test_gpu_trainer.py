@@ -265,7 +265,7 @@ def test_fused_eval_encoder_matches_module_path(num_layers):
     (1, 24, 64, 6, 34, 1),      # minimum channel count (3 chunks)
     (2, 128, 128, 8, 32, 1),    # few regions: the channels are split over two items that add into a zeroed output
     (5, 64, 64, 10, 32, 1),     # 5 rows of tiles per image: 4x16 regions straddle images (rows flattened over the batch)
-    (3, 48, 64, 6, 34, 2),      # the same with ragged tile columns and pad 2
+    (3, 48, 64, 6, 66, 2),      # the same with ragged tile columns (33 -> 3 x 16) and pad 2
 ])
 def test_wino_conv3x3_kernel_vs_aten(shape):
     """K10 through the C ABI == ATen conv2d, forward and backward-data (the same kernel on the flipped filter)."""
