@@ -26,6 +26,8 @@ __device__ __forceinline__ float elu_grad(float x) { return x > 0.f ? 1.f : expf
 // sum of the padded-gradient entries that ReflectionPad2d(1) reads from interior position (Y, X)
 __device__ __forceinline__ float fold2d(const float* __restrict__ gp, int Y, int X, int H, int W) {
     const int PW = W + 2;
+    // only rows/columns 1 and H-2 / W-2 receive reflected border entries: everything else is one load
+    if (Y != 1 && Y != H - 2 && X != 1 && X != W - 2) return gp[(Y + 1) * PW + X + 1];
     int rows[3], cols[3], nr = 1, nc = 1;
     rows[0] = Y + 1;
     cols[0] = X + 1;

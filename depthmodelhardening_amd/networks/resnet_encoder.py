@@ -105,7 +105,11 @@ class ResNet(nn.Module):
 
     def eval_affine(self):
         """{bn: (scale, shift)} of every BatchNorm2d from its running statistics, recomputed on each forward in one
-        batched pass over all layers (9 small launches instead of 4 per layer)."""
+        batched pass over all layers (9 small launches instead of 4 per layer); inside ops.frozen_weights() (an
+        attack: parameters and statistics are constants) once per scope."""
+        return ops.frozen_memo(("eval_affine", id(self)), self._eval_affine)
+
+    def _eval_affine(self):
         with torch.no_grad():
             w, b, mu, var = (torch.cat([getattr(bn, n).detach().float() for bn in self._bns])
                              for n in ("weight", "bias", "running_mean", "running_var"))

@@ -611,6 +611,16 @@ def frozen_weights():
             _wino_cache.clear()
 
 
+def frozen_memo(key, fn):
+    """fn() memoised for the lifetime of the enclosing frozen_weights() scope (parameters are constants there);
+    outside a scope fn() is simply evaluated."""
+    if not _wino_frozen:
+        return fn()
+    if key not in _wino_cache:
+        _wino_cache[key] = fn()
+    return _wino_cache[key]
+
+
 def _wino_filter(weight, backward):
     lib = N.lib()
     K, Cc = weight.shape[0], weight.shape[1]
