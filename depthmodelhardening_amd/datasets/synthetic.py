@@ -20,7 +20,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import ops
-from ..my_utils import ori_H, ori_W, train_dist_range
+from ..my_utils import ori_H, ori_W, to_device_async, train_dist_range
 from ..physicalTrans import PhysicalTrans
 from ..torchattacks import Phy_obj_atk, Phy_obj_atk_l0
 
@@ -98,19 +98,19 @@ class SyntheticKITTIDataset(object):
     # ------------------------------------------------------------------ batches
     def next_scenes(self, n):
         """n attack scenes [n,3,375,1242] (KittiLoader stand-in)."""
-        idx = torch.tensor([self.rng.randrange(self.pool_size) for _ in range(n)], device=self.device)
+        idx = to_device_async([self.rng.randrange(self.pool_size) for _ in range(n)], self.device, torch.int64)
         return self.raw_left.index_select(0, idx)
 
     def next_batch(self, batch_size):
         dev, H, W = self.device, self.height, self.width
-        idx = torch.tensor([self.rng.randrange(self.pool_size) for _ in range(batch_size)], device=dev)
+        idx = to_device_async([self.rng.randrange(self.pool_size) for _ in range(batch_size)], dev, torch.int64)
         raw_l, raw_r = self.raw_left.index_select(0, idx), self.raw_right.index_select(0, idx)
         inputs = {}
         if self.is_adv_train:
             z0 = [self.rng.choice(self.adv_trans.dist_range) for _ in range(batch_size)]
             al = [self.rng.choice(self.adv_trans.angle_range) for _ in range(batch_size)]
-            c_l = torch.from_numpy(self.adv_trans.coeffs_for(z0, al, K=self.adv_K)).to(dev)
-            c_r = torch.from_numpy(self.ben_trans.coeffs_for(z0, al, K=self.adv_K, T=self.stereo_T)).to(dev)
+            c_l = to_device_async(self.adv_trans.coeffs_for(z0, al, K=self.adv_K), dev)
+            c_r = to_device_async(self.ben_trans.coeffs_for(z0, al, K=self.adv_K, T=self.stereo_T), dev)
             lp, tp = self.adv_trans.l_pad, self.adv_trans.t_pad
             with torch.no_grad():
                 left_adv, objmask = ops.eot_paste(raw_l, self.obj_img_adv, self.obj_mask, c_l, lp, tp, (H, W))
@@ -119,7 +119,7 @@ class SyntheticKITTIDataset(object):
             inputs[("color_aug", 0, 0)] = left_adv
             inputs[("color_ben", 0, 0)] = left_ben
             inputs[("color_objmask", 0, 0)] = objmask.expand(-1, 3, -1, -1)
-            inputs[("objdepth", 0, 0)] = torch.tensor(z0, device=dev, dtype=torch.float32).view(batch_size, 1)
+            inputs[("objdepth", 0, 0)] = to_device_async(z0, dev, torch.float32).view(batch_size, 1)
             left, right = left_ben, right_ben     # inputs[("color",0,-1)] = color_ben, mono_dataset.py:257-258
         else:
             left = F.interpolate(raw_l, [H, W], mode="bilinear", align_corners=False)

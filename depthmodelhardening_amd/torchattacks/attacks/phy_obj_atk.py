@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from ... import ops
-from ...my_utils import object_dataset_root, ori_H, ori_W
+from ...my_utils import object_dataset_root, ori_H, ori_W, to_device_async
 from ...physicalTrans import PhysicalTrans
 from ..attack import Attack
 
@@ -57,7 +57,7 @@ class Phy_obj_atk(Attack):
     def _coeffs(self, samples):
         """One device tensor [len(samples), B, 8] for a list of (z0, alpha) sample lists."""
         host = np.stack([self.phy_trans_ben.coeffs_for(z0, al) for z0, al in samples], 0)
-        return torch.from_numpy(host).to(self.device, non_blocking=True)
+        return to_device_async(host, self.device)
 
     def forward(self, images, batch_size, cfg_path=f'{object_dataset_root}/training/calib/003086.txt', eval=False):
         r"""

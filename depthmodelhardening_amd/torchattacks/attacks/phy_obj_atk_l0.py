@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 
 from ... import ops
-from ...my_utils import object_dataset_root, ori_H, ori_W
+from ...my_utils import object_dataset_root, ori_H, ori_W, to_device_async
 from ...physicalTrans import PhysicalTrans
 from ..attack import Attack
 
@@ -87,11 +87,11 @@ class Phy_obj_atk_l0(Attack):
             draws.append(pt.draw_samples(batch_size))
             rng_states.append(random.getstate())
         coeffs_host = np.stack([pt.coeffs_for(z0, al) for z0, al in draws], 0)
-        coeffs = torch.from_numpy(coeffs_host).to(self.device, non_blocking=True)
+        coeffs = to_device_async(coeffs_host, self.device)
         l_pad, t_pad = pt.l_pad, pt.t_pad
         mask = self.obj_mask.to(self.device)
-        thresh = torch.tensor(float(self.l0_thresh), device=self.device)
-        w_on = torch.tensor(float(self.mask_weight_init), device=self.device)
+        thresh = torch.full((), float(self.l0_thresh), device=self.device)      # fill kernels: no host sync
+        w_on = torch.full((), float(self.mask_weight_init), device=self.device)
         w_off = torch.zeros((), device=self.device)
         l0_norm_init = None
         mw = w_on
@@ -132,7 +132,7 @@ class Phy_obj_atk_l0(Attack):
         if eval:
             z0_sample[0] = 6.1
             alpha_sample[0] = 0
-        cf = torch.from_numpy(pt.coeffs_for(z0_sample, alpha_sample)).to(self.device)
+        cf = to_device_async(pt.coeffs_for(z0_sample, alpha_sample), self.device)
         with torch.no_grad():
             adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, cf, l_pad, t_pad, self.scene_size)
             ben_scenes, _ = ops.eot_paste(scene_imgs, self.obj_img, mask, cf, l_pad, t_pad, self.scene_size)
