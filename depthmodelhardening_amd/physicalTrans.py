@@ -137,13 +137,28 @@ class PhysicalTrans(object):
         return z0_sample, alpha_sample
 
     def coeffs_for(self, z0_sample, alpha_sample, K=None, T=None):
-        """[N,8] fp32 perspective coefficients (host numpy) for the given samples."""
+        """[N,8] fp32 perspective coefficients (host numpy) for the given samples.  (z0, alpha) come from small finite
+        ranges (13 x 25 in training), so each (camera, pose) is solved once and memoised: the per-step host cost of
+        ~200 8x8 solves otherwise leaves the GPU idle for milliseconds (the host is the slower side of the pipeline)."""
         out = np.zeros((len(z0_sample), 8), dtype=np.float32)
         start = [[float(v) for v in p] for p in self.pos_obj_img_start]
+        cam = (None if K is None else np.asarray(K).tobytes(), None if T is None else np.asarray(T).tobytes(),
+               tuple(map(tuple, start)))
+        memo = self.__dict__.setdefault("_coeff_memo", {})
+        warmed = self.__dict__.setdefault("_coeff_warm", set())
+        if cam not in warmed and len(z0_sample) > 1:        # first use of a camera: solve the whole pose grid once
+            warmed.add(cam)
+            grid = [(z, al) for z in self.dist_range for al in self.angle_range]
+            self.coeffs_for([g[0] for g in grid] + [grid[0][0]], [g[1] for g in grid] + [grid[0][1]], K, T)
         for i in range(len(z0_sample)):
-            quad = self.objPosOnImage(z0_sample[i], alpha_sample[i], K) if T is None else \
-                self._objPosOnImage_w_trans(T, z0_sample[i], alpha_sample[i], K)
-            out[i] = get_perspective_coeffs(start, [[float(v) for v in p] for p in quad])
+            key = (float(z0_sample[i]), float(alpha_sample[i]), cam)
+            c = memo.get(key)
+            if c is None:
+                quad = self.objPosOnImage(z0_sample[i], alpha_sample[i], K) if T is None else \
+                    self._objPosOnImage_w_trans(T, z0_sample[i], alpha_sample[i], K)
+                c = memo[key] = np.asarray(get_perspective_coeffs(start, [[float(v) for v in p] for p in quad]),
+                                           dtype=np.float32)
+            out[i] = c
         return out
 
     def _warp(self, coeffs_np):
