@@ -82,6 +82,8 @@ _SIGNATURES = {
     "dmh_wino_weight_size": (C.c_int64, [C.c_int, C.c_int]),
     "dmh_wino_weight_transform": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "dmh_wino_conv3x3": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp]),
+    "dmh_wino_weight_transform_scaled": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
+    "dmh_wino_conv3x3_act": (C.c_int, [_fp] * 4 + [C.c_int] * 7 + [_fp, _fp]),
     "dmh_conv3x3_small": (C.c_int, [_fp] * 3 + [C.c_int] * 7 + [_fp, _fp]),
     "dmh_conv7x7s2_bwd_data": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp]),
 }

@@ -41,6 +41,8 @@ struct WArgs {
     const float* x;
     const f32x4* U;              // [C/8][16][2][Kp][4 floats], Kp = K rounded up to 64
     const float* bias;           // [K] or null
+    const float* res;            // EPI kernels: tensor added to the output before the activation, or null
+    int relu;                    // EPI kernels: clamp the output at zero
     float* y;
     int B, C, K, Kp, H, W, Ho, Wo, pad;
     int gx, gy, kg;              // tile-region groups along x / y, output-channel groups
@@ -53,8 +55,10 @@ struct WArgs {
 // pre-transform the filter: U = G g G^T, scattered into the chunked layout the kernel streams.
 // mode 0: forward   u[k][c] from w[k][c][ky][kx]
 // mode 1: backward  u[c][k] from w[k][c][2-ky][2-kx]   (output channels of the pass = C of the filter)
+// scale (optional): per-channel factor of the convolution OUTPUT of the forward pass (an eval-mode BatchNorm folded
+// into the filter): multiplies filter row ko in mode 0 and filter column ci (the same channel) in mode 1.
 __global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict__ w, int Kw, int Cw, int mode,
-                                                         float* __restrict__ U, int Kp) {
+                                                         const float* __restrict__ scale, float* __restrict__ U, int Kp) {
     // "out" / "in" are the channel roles of the pass this transform is for
     const int n_out = mode ? Cw : Kw, n_in = mode ? Kw : Cw;
     const int i = blockIdx.x * NT + threadIdx.x;       // over Kp * n_in
@@ -63,10 +67,11 @@ __global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict
     float g[3][3];
     if (ko < n_out) {
         const float* src = mode ? w + ((size_t)ci * Cw + ko) * 9 : w + ((size_t)ko * Cw + ci) * 9;
+        const float sc = scale ? scale[mode ? ci : ko] : 1.f;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = mode ? src[(2 - a) * 3 + (2 - b)] : src[a * 3 + b];
+            for (int b = 0; b < 3; ++b) g[a][b] = sc * (mode ? src[(2 - a) * 3 + (2 - b)] : src[a * 3 + b]);
     } else {
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -113,7 +118,7 @@ __device__ __forceinline__ Item decode_item(const WArgs& a, int item) {
     return it;
 }
 
-template <int TRW, bool FLAT>
+template <int TRW, bool FLAT, bool EPI>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_conv_kernel(WArgs a) {
     constexpr int TRH = 64 / TRW;
     // Tile regions normally lie inside one image and their tile rows share input rows.  FLAT (4 x 16 regions on images
@@ -391,10 +396,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 if (inside && ko < a.K) {
                     const float bs = (a.bias && it.c0 == 0) ? a.bias[ko] : 0.f;
-                    const float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
-                    const float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
+                    float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
+                    float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
                     float* yp = yb + (size_t)ko * a.Ho * a.Wo;
-                    if (a.csplit == 1) {
+                    if (EPI) {      // fused eval-mode BatchNorm (scale in the filter, shift = bias) + identity + ReLU
+                        if (a.res) {
+                            const float* rp = a.res + (yp - a.y);
+                            const float2 r0 = *reinterpret_cast<const float2*>(rp);
+                            const float2 r1 = *reinterpret_cast<const float2*>(rp + a.Wo);
+                            y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+                        }
+                        if (a.relu) {
+                            y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+                        }
+                    }
+                    if (EPI || a.csplit == 1) {
                         *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
                         *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
                     } else {    // two partial sums into zeros: 0 + a + b is the same in either order (deterministic)
@@ -430,7 +446,7 @@ int num_cus() {
     return n;
 }
 
-template <int TRW, bool FLAT>
+template <int TRW, bool FLAT, bool EPI>
 int launch(WArgs& a, hipStream_t st) {
     constexpr int TRH = 64 / TRW;
     // U and V images (double-buffered, 128 KB) + the raw input region(s): see FLAT in the kernel
@@ -438,7 +454,7 @@ int launch(WArgs& a, hipStream_t st) {
     constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * ((RAWN + NT - 1) / NT * NT) * 4;
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<TRW, FLAT>),
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<TRW, FLAT, EPI>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
             return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
         configured = true;
@@ -446,22 +462,23 @@ int launch(WArgs& a, hipStream_t st) {
     // persistent: one workgroup per CU (its 154 KB of LDS and 512 registers per lane fill the CU), each walking a
     // contiguous range of work items
     const int grid = a.nitems < num_cus() ? a.nitems : num_cus();
-    hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT>), dim3((unsigned)grid), dim3(NT), smem, st, a);
+    hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, EPI>), dim3((unsigned)grid), dim3(NT), smem, st, a);
     return check_launch("dmh_wino_conv3x3");
 }
 
 // few regions (small images): split the channels of every region over two items so that the launch covers the chip
 template <int TRW, bool FLAT>
-int launch_split(WArgs& a, hipStream_t st) {
+int launch_split(WArgs& a, hipStream_t st, bool epi) {
     const int64_t regions = (int64_t)a.bitems * a.gx * a.gy * a.kg;
     if (regions >= ((int64_t)1 << 30)) return fail(DMH_EINVAL, "%s: too many work items", "dmh_wino_conv3x3");
     const int nch = a.C / CK;
-    a.csplit = (regions < (3 * num_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
+    // (a fused activation needs the complete sum in one item: no split)
+    a.csplit = (!epi && regions < (3 * num_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
     a.nitems = (int)regions * a.csplit;
     if (a.csplit > 1 &&
         hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.B * a.K * a.Ho * a.Wo, st) != hipSuccess)
         return fail(DMH_ELAUNCH, "%s: hipMemsetAsync failed", "dmh_wino_conv3x3");
-    return launch<TRW, FLAT>(a, st);
+    return epi ? launch<TRW, FLAT, true>(a, st) : launch<TRW, FLAT, false>(a, st);
 }
 
 }  // namespace
@@ -474,19 +491,24 @@ int64_t dmh_wino_weight_size(int n_out, int n_in) {
     return (int64_t)(n_in / CK) * 16 * 2 * Kp * 4;
 }
 
-int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream) {
+int dmh_wino_weight_transform_scaled(const float* w, int K, int C, int backward, const float* scale, float* U,
+                                     void* stream) {
     DMH_REQUIRE(w && U, "null pointer");
     const int n_out = backward ? C : K, n_in = backward ? K : C;
     DMH_REQUIRE(K > 0 && C > 0 && n_in % CK == 0, "the pass's input channel count must be a multiple of 8");
     const int Kp = (n_out + 63) / 64 * 64;
     const long long n = (long long)Kp * n_in;
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, w, K, C,
-                       backward ? 1 : 0, U, Kp);
+                       backward ? 1 : 0, scale, U, Kp);
     return check_launch("dmh_wino_weight_transform");
 }
 
-int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
-                     float* y, void* stream) {
+int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream) {
+    return dmh_wino_weight_transform_scaled(w, K, C, backward, nullptr, U, stream);
+}
+
+static int wino_conv_common(const float* x, const float* U, const float* bias, const float* residual, int relu, bool epi,
+                            int B, int C, int K, int H, int W, int pad, float* y, void* stream) {
     DMH_REQUIRE(x && U && y, "null pointer");
     DMH_REQUIRE(B > 0 && C >= 3 * CK && K > 0 && C % CK == 0, "input channels must be a multiple of 8, at least 24");
     DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
@@ -494,7 +516,7 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
     DMH_REQUIRE(Ho >= 2 && Wo >= 2 && (Ho & 1) == 0 && (Wo & 1) == 0, "output height and width must be even");
     DMH_REQUIRE((int64_t)C * H * W < ((int64_t)1 << 31) && (int64_t)K * Ho * Wo < ((int64_t)1 << 31), "image too large");
     WArgs a;
-    a.x = x; a.U = reinterpret_cast<const f32x4*>(U); a.bias = bias; a.y = y;
+    a.x = x; a.U = reinterpret_cast<const f32x4*>(U); a.bias = bias; a.res = residual; a.relu = relu; a.y = y;
     a.B = B; a.C = C; a.K = K; a.Kp = (K + 63) / 64 * 64; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.kg = a.Kp / 64;
     const int Ht = Ho / 2, Wt = Wo / 2;
@@ -505,13 +527,23 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
         // rows of tiles flattened over the batch when per-image regions would waste >= 1/5 of their tile rows
         if (5 * Ht <= 4 * ((Ht + 3) / 4 * 4) && (int64_t)B * C * H * W < ((int64_t)1 << 31)) {
             a.gy = (B * Ht + 3) / 4; a.bitems = 1;
-            return launch_split<16, true>(a, (hipStream_t)stream);
+            return launch_split<16, true>(a, (hipStream_t)stream, epi);
         }
         a.gy = (Ht + 3) / 4; a.bitems = B;
-        return launch_split<16, false>(a, (hipStream_t)stream);
+        return launch_split<16, false>(a, (hipStream_t)stream, epi);
     }
     a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2; a.bitems = B;
-    return launch_split<32, false>(a, (hipStream_t)stream);
+    return launch_split<32, false>(a, (hipStream_t)stream, epi);
+}
+
+int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                     float* y, void* stream) {
+    return wino_conv_common(x, U, bias, nullptr, 0, false, B, C, K, H, W, pad, y, stream);
+}
+
+int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,
+                         int K, int H, int W, int pad, float* y, void* stream) {
+    return wino_conv_common(x, U, bias, residual, relu, true, B, C, K, H, W, pad, y, stream);
 }
 
 }  // extern "C"

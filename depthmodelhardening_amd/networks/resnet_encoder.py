@@ -17,6 +17,15 @@ import torch.nn as nn
 from .. import ops
 
 
+def _conv_bn_act(conv, x, aff, residual=None):
+    """relu(bn_eval(conv(x)) (+ residual)): one fused K10 launch for 3x3 stride-1 convolutions that fill the chip,
+    conv + the K9 bn_act pass otherwise."""
+    if (x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.padding == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None):
+        return ops.conv3x3_bn_act(x, conv.weight, aff[0], aff[1], residual, True, 1)
+    return ops.bn_act(conv(x), aff[0], aff[1], residual)
+
+
 def _conv(conv, x):
     """conv(x); 3x3 stride-1 pad-1 convolutions of CUDA tensors go through ops.conv3x3 (Winograd-MFMA kernel where the
     shape fills the chip, MIOpen otherwise) -- same parameters, same result within fp32 rounding."""
@@ -46,8 +55,8 @@ class BasicBlock(nn.Module):
 
     def forward_fused(self, x, aff):
         idt = x if self.downsample is None else ops.bn_act(self.downsample[0](x), *aff[self.downsample[1]], relu=False)
-        out = ops.bn_act(_conv(self.conv1, x), *aff[self.bn1])
-        return ops.bn_act(_conv(self.conv2, out), *aff[self.bn2], residual=idt)
+        out = _conv_bn_act(self.conv1, x, aff[self.bn1])
+        return _conv_bn_act(self.conv2, out, aff[self.bn2], residual=idt)
 
 
 class Bottleneck(nn.Module):
@@ -74,7 +83,7 @@ class Bottleneck(nn.Module):
     def forward_fused(self, x, aff):
         idt = x if self.downsample is None else ops.bn_act(self.downsample[0](x), *aff[self.downsample[1]], relu=False)
         out = ops.bn_act(self.conv1(x), *aff[self.bn1])
-        out = ops.bn_act(_conv(self.conv2, out), *aff[self.bn2])
+        out = _conv_bn_act(self.conv2, out, aff[self.bn2])
         return ops.bn_act(self.conv3(out), *aff[self.bn3], residual=idt)
 
 

@@ -621,21 +621,24 @@ def frozen_memo(key, fn):
     return _wino_cache[key]
 
 
-def _wino_filter(weight, backward):
+def _wino_filter(weight, backward, scale=None):
+    """Winograd-transformed filter of the forward (backward=False) or backward-data pass; `scale` folds a per-channel
+    factor of the forward OUTPUT (an eval-mode BatchNorm) into it."""
     lib = N.lib()
     K, Cc = weight.shape[0], weight.shape[1]
-    key = (weight.data_ptr(), weight._version, bool(backward))
+    key = (weight.data_ptr(), weight._version, bool(backward), None if scale is None else scale.data_ptr())
     if _wino_frozen and key in _wino_cache:
         return _wino_cache[key]
     n_out, n_in = (Cc, K) if backward else (K, Cc)
     U = torch.empty(lib.dmh_wino_weight_size(n_out, n_in), device=weight.device, dtype=torch.float32)
-    N.check(lib.dmh_wino_weight_transform(N.ptr(_c(weight.detach())), K, Cc, int(backward), N.ptr(U), N.stream()))
+    N.check(lib.dmh_wino_weight_transform_scaled(N.ptr(_c(weight.detach())), K, Cc, int(backward), N.ptr(scale), N.ptr(U),
+                                                 N.stream()))
     if _wino_frozen:
         _wino_cache[key] = U
     return U
 
 
-def _wino_ok(B, n_in, n_out, Ho, Wo):
+def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     """Shapes the Winograd-MFMA kernel takes: channel counts it tiles without waste and enough 64-channel x 64-tile
     work items to fill the 256 CUs (measured crossover, tools/wino_bench.py)."""
     if not WINO_ENABLED or n_in % 8 or n_in < 24 or n_out < 64 or Ho % 2 or Wo % 2 or Ho < 2 or Wo < 2:
@@ -651,7 +654,7 @@ def _wino_ok(B, n_in, n_out, Ho, Wo):
         regions = B * (-(-wt // 32)) * (-(-ht // 2))
     regions *= -(-n_out // 64)
     nch = n_in // 8
-    split = 2 if (regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split() in wino_conv.hip
+    split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
     return regions * split >= 200
 
 
@@ -722,6 +725,69 @@ class _Conv3x3(torch.autograd.Function):
             g_w = r[1] if need_w else None
             g_b = r[2] if need_b else None
         return g_x, g_w, g_b, None
+
+
+class _ConvBnAct(torch.autograd.Function):
+    """conv3x3 -> eval-mode BatchNorm -> (+ residual) -> ReLU as ONE K10 launch (scale folded into the filter, shift as
+    the bias, residual and ReLU in the output transform).  Backward: ReLU mask (one K9 pass), then the backward-data
+    K10 launch on the filter with the scale folded in."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, shift, residual, relu, pad):
+        K = weight.shape[0]
+        lib = N.lib()
+        B, Cc, H, W = x.shape
+        y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
+        U = _wino_filter(weight, False, scale)
+        nb = 4 * (x.numel() + y.numel() * (1 if residual is None else 2)) + 4 * U.numel()
+        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(N.ptr(x), N.ptr(U), N.ptr(shift), N.ptr(residual),
+                                                                       int(relu), B, Cc, K, H, W, pad, N.ptr(y),
+                                                                       N.stream()), nb))
+        ctx.save_for_backward(x, weight, scale, y if relu else None)
+        ctx.pad, ctx.relu = pad, bool(relu)
+        ctx.res_grad = residual is not None and residual.requires_grad
+        ctx.params_const = _wino_frozen > 0
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, scale, y = ctx.saved_tensors
+        lib = N.lib()
+        B, Cc, H, W = x.shape
+        K = weight.shape[0]
+        g = _c(g)
+        if ctx.relu:        # g_pre = g * [y > 0] (K9 kernel with a unit scale); it is also the residual's gradient
+            ones = frozen_memo(("ones", K, g.device), lambda: torch.ones(K, device=g.device, dtype=torch.float32))
+            g_pre = torch.empty_like(g)
+            N.check(_timed("bn_act_bwd", lambda: lib.dmh_bn_act_bwd(N.ptr(y), N.ptr(g), N.ptr(ones), B, K, g.numel() // (B * K),
+                                                                   1, N.ptr(g_pre), None, N.stream()), 12 * g.numel()))
+        else:
+            g_pre = g
+        g_x = g_w = None
+        need_w = ctx.needs_input_grad[1] and not ctx.params_const
+        if ctx.needs_input_grad[0]:
+            if _wino_ok(B, K, Cc, H, W):
+                g_x = _wino_conv(g_pre, _wino_filter(weight, True, scale), None, Cc, 2 - ctx.pad)
+            else:
+                g_conv = g_pre * scale.view(1, -1, 1, 1)
+                g_x = torch.ops.aten.convolution_backward(g_conv, x, weight, None, [1, 1], [ctx.pad] * 2, [1, 1], False,
+                                                          [0, 0], 1, [True, False, False])[0]
+        if need_w:
+            g_conv = g_pre * scale.view(1, -1, 1, 1)
+            g_w = torch.ops.aten.convolution_backward(g_conv, x, weight, None, [1, 1], [ctx.pad] * 2, [1, 1], False, [0, 0],
+                                                      1, [False, True, False])[1]
+        return g_x, g_w, None, None, (g_pre if ctx.res_grad else None), None, None
+
+
+def conv3x3_bn_act(x, weight, scale, shift, residual=None, relu=True, padding=1):
+    """act(BatchNorm_eval(conv3x3(x, weight)) (+ residual)) with BatchNorm given as its per-channel (scale, shift): the
+    BasicBlock pattern of the encoder in eval() (MD2/networks/resnet_encoder.py:85-98).  One K10 launch where the shape
+    fills the chip, otherwise conv3x3 followed by the K9 bn_act pass.  No gradient flows to scale / shift."""
+    B, Cc, H, W = x.shape
+    if x.is_cuda and _wino_ok(B, Cc, weight.shape[0], H + 2 * padding - 2, W + 2 * padding - 2, allow_split=False):
+        return _ConvBnAct.apply(_c(x), weight, _c(scale.detach()), _c(shift.detach()),
+                                None if residual is None else _c(residual), bool(relu), int(padding))
+    return bn_act(conv3x3(x, weight, None, padding), scale, shift, residual, relu)
 
 
 def conv3x3(x, weight, bias=None, padding=1):

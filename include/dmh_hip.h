@@ -265,6 +265,15 @@ int64_t dmh_wino_weight_size(int n_out, int n_in);
 int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream);
 int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
                      float* y, void* stream);
+/* conv -> BatchNorm(eval) -> (+ identity) -> ReLU of a BasicBlock in one launch (torchvision BasicBlock.forward under
+ * MD2/networks/resnet_encoder.py:85-98, model in eval()): the per-channel scale is folded into the filter by
+ * weight_transform_scaled (backward != 0: into the filter of the backward-data pass, whose input is then the masked
+ * output gradient), the shift is `bias`, `residual` (same shape as y, may be NULL) is added before the ReLU.
+ *   y = act(corr3x3(zero_pad(x), w * scale[k]) + bias[k] (+ residual)),  act = ReLU when relu != 0 */
+int dmh_wino_weight_transform_scaled(const float* w, int K, int C, int backward, const float* scale, float* U,
+                                     void* stream);
+int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,
+                         int K, int H, int W, int pad, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K11 3x3 stride-1 convolution with few channels (<=4 -> <=32, 16 -> <=32 or 32 -> <=16) at full resolution, direct implicit

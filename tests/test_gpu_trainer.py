@@ -371,6 +371,41 @@ def test_stem_conv_bwd_data_vs_aten(shape):
     assert lib.dmh_conv7x7s2_bwd_data(N.ptr(gy), N.ptr(w.detach()), B, K, Cin, H + 1, W, N.ptr(gx), N.stream()) != 0
 
 
+@pytest.mark.parametrize("use_res", [False, True])
+def test_conv3x3_bn_act_fused_matches_unfused(use_res):
+    """ops.conv3x3_bn_act (one K10 launch: scale folded into the filter, shift/residual/ReLU in the output transform)
+    == relu(batch_norm_eval(conv2d(x)) + residual) from ATen, values and the gradients w.r.t. x and the residual."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5 + use_res)
+    B, C, K, H, W = 12, 64, 64, 40, 128
+    x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    w = ((torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.2).requires_grad_(True)
+    res = (torch.rand(B, K, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True) if use_res else None
+    gam, bet = torch.rand(K, device="cuda", generator=g) + 0.5, torch.rand(K, device="cuda", generator=g) - 0.5
+    mu, var = torch.rand(K, device="cuda", generator=g) - 0.5, torch.rand(K, device="cuda", generator=g) + 0.2
+    scale = gam / torch.sqrt(var + 1e-5)
+    shift = bet - mu * scale
+    assert ops._wino_ok(B, C, K, H, W, allow_split=False)
+    got = ops.conv3x3_bn_act(x, w, scale, shift, res, True, 1)
+    ref = F.batch_norm(F.conv2d(x, w, None, padding=1), mu, var, gam, bet, False, 0.0, 1e-5)
+    ref = F.relu(ref + res if use_res else ref)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=4e-6 * float(ref.abs().max()))
+    off_kink = (ref.abs() > 1e-4).float()           # both paths take the ReLU mask from their own output
+    wt = torch.rand(ref.shape, device="cuda", generator=g) * off_kink
+    ins = [x, res] if use_res else [x]
+    with ops.frozen_weights():                      # as inside an attack: parameters are constants
+        ga = torch.autograd.grad((got * wt).sum(), ins)
+    gb = torch.autograd.grad((ref * wt).sum(), ins, retain_graph=True)
+    for a_, b_ in zip(ga, gb):
+        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5 * float(b_.abs().max()))
+    # outside an attack the weight gradient is produced as well (MIOpen on the scaled output gradient)
+    got2 = ops.conv3x3_bn_act(x, w, scale, shift, res, True, 1)
+    gw = torch.autograd.grad((got2 * wt).sum(), w)[0]
+    gw_ref = torch.autograd.grad((ref * wt).sum(), w)[0]
+    torch.testing.assert_close(gw, gw_ref, rtol=1e-4, atol=1e-5 * float(gw_ref.abs().max()))
+
+
 def test_conv3x3_op_autograd_matches_aten():
     """ops.conv3x3 (Winograd-MFMA forward + backward-data, MIOpen weight gradient) == F.conv2d under autograd, on a
     shape the dispatcher sends to K10 and on one it leaves to MIOpen; frozen_weights() caches the transformed filter."""
