@@ -696,6 +696,14 @@ class _Conv3x3(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         if _wino_ok(B, Cc, K, H + 2 * pad - 2, W + 2 * pad - 2):
             return _wino_conv(x, _wino_filter(weight, False), None if bias is None else _c(bias.detach()), K, pad)
+        if (WINO_ENABLED and K == 1 and Cc % 16 == 0 and Cc >= 32      # disparity head: K13 (16 channels: K11 is level)
+                and B * -(-(H + 2 * pad - 2) // 8) * -(-(W + 2 * pad - 2) // 64) >= 512):
+            lib = N.lib()
+            y = torch.empty((B, 1, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
+            N.check(_timed("conv3x3_head", lambda: lib.dmh_conv3x3_head(
+                N.ptr(x), N.ptr(_c(weight.detach())), N.ptr(None if bias is None else _c(bias.detach())), B, Cc, H, W, pad,
+                N.ptr(y), N.stream()), 4 * (x.numel() + y.numel())))
+            return y
         if _small_ok(Cc, K):
             return _small_conv(x, weight, None if bias is None else _c(bias.detach()), pad, False)
         return torch.conv2d(x, weight, bias, 1, pad)

@@ -294,6 +294,14 @@ int dmh_conv3x3_small(const float* x, const float* w, const float* bias, int B, 
 int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int Cin, int H, int W, float* g_x,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K13 disparity head: 3x3 stride-1 convolution to ONE output channel (MD2/networks/depth_decoder.py:43-44 dispconv),
+ *     forward: y[B,1,H+2pad-2,W+2pad-2] = corr3x3(zero_pad(x[B,C,H,W], pad), w[1][C][3][3]) + bias[0].
+ *     Vector FMAs on an LDS tile, filter through scalar loads; C a multiple of 16.
+ * ---------------------------------------------------------------------------------- */
+int dmh_conv3x3_head(const float* x, const float* w, const float* bias, int B, int C, int H, int W, int pad, float* y,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -406,6 +406,30 @@ def test_conv3x3_bn_act_fused_matches_unfused(use_res):
     torch.testing.assert_close(gw, gw_ref, rtol=1e-4, atol=1e-5 * float(gw_ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 20, 130, 0), (1, 32, 9, 64, 1), (2, 64, 12, 33, 0), (1, 128, 6, 70, 2)])
+def test_head_conv3x3_kernel_vs_aten(shape):
+    """K13 (3x3 convolution to one output channel, the disparity heads) == ATen conv2d; ops.conv3x3 routes K = 1 to it."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import _native as N, ops
+    lib = N.lib()
+    B, C, Ho, Wo, pad = shape
+    H, W = Ho + 2 - 2 * pad, Wo + 2 - 2 * pad
+    g = torch.Generator(device="cuda").manual_seed(C + Wo)
+    x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    w = ((torch.rand(1, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.3).requires_grad_(True)
+    b = (torch.rand(1, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    ref = F.conv2d(x, w, b, padding=pad)
+    y = torch.full((B, 1, Ho, Wo), float("nan"), device="cuda")
+    N.check(lib.dmh_conv3x3_head(N.ptr(x.detach()), N.ptr(w.detach()), N.ptr(b.detach()), B, C, H, W, pad, N.ptr(y), N.stream()))
+    torch.testing.assert_close(y, ref, rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+    got = ops.conv3x3(x, w, b, pad)         # (small grids stay on K11 / MIOpen: any route must agree)
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+    wt = torch.rand(ref.shape, device="cuda", generator=g)
+    for a_, b_ in zip(torch.autograd.grad((got * wt).sum(), [x, w, b]), torch.autograd.grad((ref * wt).sum(), [x, w, b])):
+        torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5 * float(b_.abs().max()))
+    assert lib.dmh_conv3x3_head(N.ptr(x.detach()), N.ptr(w.detach()), None, B, 24, H, W, pad, N.ptr(y), N.stream()) != 0
+
+
 def test_conv3x3_op_autograd_matches_aten():
     """ops.conv3x3 (Winograd-MFMA forward + backward-data, MIOpen weight gradient) == F.conv2d under autograd, on a
     shape the dispatcher sends to K10 and on one it leaves to MIOpen; frozen_weights() caches the transformed filter."""

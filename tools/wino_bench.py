@@ -76,16 +76,20 @@ for (C, K, Ho, Wo, pad, name) in SHAPES:
     gref = torch.autograd.grad(F.conv2d(xr, w, None, padding=pad), xr, gy)[0]
     torch.cuda.synchronize()
     first = time.time() - t0
-    small = (C == 16 and K <= 32) or (C == 32 and K <= 16)
+    small = (C == 16 and K <= 32) or (C == 32 and K <= 16) or K == 1
     if small:       # K11 (direct MFMA, filter in registers) instead of K10
         def wino(inp, U, bs, n_out, p, _w=w):
             Bn, _, Hi, Wi = inp.shape
             out = torch.empty(Bn, n_out, Hi + 2 * p - 2, Wi + 2 * p - 2, device=dev)
+            if n_out == 1 and U is not None:      # K13: single output channel
+                N.check(lib.dmh_conv3x3_head(N.ptr(inp), N.ptr(_w), N.ptr(bs), Bn, _w.shape[1], Hi, Wi, p, N.ptr(out),
+                                             N.stream()))
+                return out
             N.check(lib.dmh_conv3x3_small(N.ptr(inp), N.ptr(_w), N.ptr(bs), Bn, _w.shape[0], _w.shape[1], Hi, Wi, p,
                                           int(U is None), N.ptr(out), N.stream()))
             return out
         Uf, Ub = 1, None
-        bwd_ok = (K == 16 and C <= 32) or (K == 32 and C <= 16)
+        bwd_ok = (K == 16 and C <= 32) or (K == 32 and C <= 16) or (K <= 4 and C <= 32)
     else:
         wino = wino_k10
         Uf, Ub = transform(w, False), transform(w, True)
