@@ -20,6 +20,9 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DMH_SMALL_ABLATE      // timing experiments (tools/small_ablate.sh): 1 no global loads, 2 no MFMA loop, 4 no stores
+#define DMH_SMALL_ABLATE 0
+#endif
 constexpr int NT = 256;
 constexpr int TW = 64;           // output columns per workgroup: 4 waves x 16 pixels
 
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
             const int iy = oy0 - a.pad + r, ix = ox0 - a.pad + xx;
             const bool ok = e < C * RH * RW && c < a.n_in && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
             const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-            const float v = xb[(size_t)(ok ? c : 0) * HW + (size_t)cy * a.W + cx];
+            const float v = (DMH_SMALL_ABLATE & 1) ? 1.f : xb[(size_t)(ok ? c : 0) * HW + (size_t)cy * a.W + cx];
             stage[k] = ok ? v : 0.f;
         }
 #pragma unroll
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) acc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = 0; q < ((DMH_SMALL_ABLATE & 2) ? 0 : NQ); ++q)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const float xv = src[4 * q * CS + (row + t / 3) * RW + (t % 3)];
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
                     acc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[kb][q][t], xv, acc[kb], 0, 0, 0);
             }
         const int oy = oy0 + row;
-        if (oy < a.Ho && ox < a.Wo) {
+        if (oy < a.Ho && ox < a.Wo && !((DMH_SMALL_ABLATE & 4) && acc[0][0] != 123.f)) {
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
