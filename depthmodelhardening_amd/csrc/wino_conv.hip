@@ -140,6 +140,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int Ht = a.Ho >> 1, NR = a.B * Ht;                // FLAT: rows of tiles per image / in the batch
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);    // wave index as a scalar
     const size_t HW = (size_t)a.H * a.W;
     const int nch = a.C / CK / a.csplit;                    // channel chunks per item
 
@@ -170,8 +171,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     {                                                                                             \
         const Item it = decode_item<TRW>(a, ITEM);                                                \
         const int ix0 = 2 * it.tx0 - a.pad;                                                       \
-        int tid_o = tid;    /* opaque copy: the slot decomposition below must not be hoisted and kept live */ \
-        asm volatile("" : "+v"(tid_o));                                                           \
+        /* thread index rebuilt from v_mbcnt + the scalar wave index: a copy of `tid` kept from kernel entry is  */ \
+        /* spilled, and its reload's vmcnt(0) waits for the previous item's stores (also keeps the slot          */ \
+        /* decomposition below from being hoisted and held in registers)                                         */ \
+        int tid_o;      /* volatile asm: the builtin form is loop-invariant, gets hoisted and spilled all the same   */ \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_o));           \
+        tid_o += wv_s * 64;                                                                       \
         XB = a.x + ((size_t)it.b * a.C + (size_t)it.c0 * CK) * HW;                                \
         USRC = a.U + (size_t)it.k0 + (size_t)it.c0 * 32 * a.Kp;                                   \
         RVALID = 0;                                                                               \
@@ -376,8 +381,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         //      register -> output channel
         {
             const Item it = decode_item<TRW>(a, item);
-            int lane_o = lane;      // opaque copy: keeps the per-lane store addresses from being hoisted out of the item loop
-            asm volatile("" : "+v"(lane_o));
+            // lane index from v_mbcnt (not a register kept since kernel entry: see DMH_WINO_ITEM_CONSTS); opaque, so the
+            // per-lane store addresses are not hoisted out of the item loop
+            int lane_o;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
             const int tl = tb * 32 + (lane_o & 31);
             const int Rt = it.ty0 + tl / TRW;                       // row of tiles: in the image, or (FLAT) in the batch
             const int ob = FLAT ? min(Rt, NR - 1) / Ht : it.b;
