@@ -649,9 +649,13 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     narrow = wt % 32 != 0 and (wt <= 16 or (-wt) % 16 < (-wt) % 32)
     if narrow:      # 4x16 regions; rows of tiles flattened over the batch when per-image regions would waste >= 1/5
         flat = 5 * ht <= 4 * (-(-ht // 4) * 4)
-        regions = (-(-wt // 16)) * (-(-(B * ht) // 4) if flat else B * -(-ht // 4))
+        rows = -(-(B * ht) // 4) * 4 if flat else B * -(-ht // 4) * 4
+        cols = -(-wt // 16) * 16
     else:
-        regions = B * (-(-wt // 32)) * (-(-ht // 2))
+        rows, cols = B * -(-ht // 2) * 2, -(-wt // 32) * 32
+    if B * ht * wt < 0.6 * rows * cols:     # ragged image: too many empty tiles (e.g. 17 tile columns in a 32-wide region)
+        return False
+    regions = (rows // (4 if narrow else 2)) * (cols // (16 if narrow else 32))
     regions *= -(-n_out // 64)
     nch = n_in // 8
     split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
