@@ -1,27 +1,32 @@
 // K10 -- 3x3 stride-1 convolution, Winograd F(2x2, 3x3) on the fp32 matrix cores (v_mfma_f32_32x32x2_f32).
 //
-// Why: after K1-K9 the adversarial-training step is ~75 % MIOpen `miopenSp3AsmConv_v30_3_1_gfx9_fp32_f2x3`
-// (profiles/r01_bench_timed_region.csv: 564 launches, 133 ms of a 248 ms step).  That kernel is a gfx9-generic
-// Winograd on the VECTOR ALU: ~75 TFLOP/s direct-equivalent, i.e. ~33 TFLOP/s of real multiplies = half the scalar
-// v_fma_f32 issue roof measured on this chip (tools/micro/valu_rate.hip).  gfx950 has an exact-fp32 MFMA at the full
-// 157 TFLOP/s; the 16 transform-domain GEMMs  M_p[k][tile] = sum_c U_p[k][c] * V_p[c][tile]  map onto it directly.
-// This is the forward AND the backward-data pass (the latter = the same kernel on the flipped/transposed filter
-// with pad' = 2 - pad) of every 3x3/1 convolution of the ResNet encoder and the depth decoder
-// (MD2/networks/resnet_encoder.py:85-98 via torchvision BasicBlock, MD2/layers.py:127-141 Conv3x3).
-// The weight gradient stays on MIOpen (train pass only).
+// Why: after K1-K9 the adversarial-training step was ~75 % MIOpen `miopenSp3AsmConv_v30_3_1_gfx9_fp32_f2x3`
+// (564 launches, 133 ms of a 248 ms step): a gfx9-generic Winograd on the VECTOR ALU at 80-105 TFLOP/s
+// direct-equivalent.  gfx950 has an exact-fp32 MFMA; the 16 transform-domain GEMMs
+//     M_p[k][tile] = sum_c U_p[k][c] * V_p[c][tile]
+// map onto it directly.  This is the forward AND the backward-data pass (the same kernel on the flipped/transposed
+// filter with pad' = 2 - pad) of the 3x3/1 convolutions of the ResNet encoder and the depth decoder
+// (MD2/networks/resnet_encoder.py:85-98 via torchvision BasicBlock, MD2/layers.py:127-141 Conv3x3).  The weight
+// gradient stays on MIOpen (train pass only).
 //
-// Work decomposition (one workgroup = 4 waves, one wave per SIMD, 256 accumulator registers per lane):
-//   * workgroup tile : 64 output channels x 64 Winograd tiles (TRH x TRW tiles = 2TRH x 2TRW output pixels)
-//   * wave tile      : 32 output channels x 32 tiles x all 16 transform positions -> 16 accumulators of 32x32;
-//                      the output transform A^T M A is then pure per-lane register arithmetic.
-//   * K loop         : input channels in chunks of 8.  Per chunk: raw input region (8 x (2TRH+2) x (2TRW+2)) and the
-//                      pre-transformed filter chunk (16 x 64 x 8) go global -> registers (prefetched one chunk ahead,
-//                      in flight during the MFMA phase) -> LDS; the input transform B^T d B runs LDS -> LDS;
-//                      then per position 2 ds_read_b128 + 4 MFMAs (channel order inside a chunk is permuted so that
-//                      one 16-byte read feeds 4 consecutive k-steps of a lane).
-//   * LDS images     : U[p][h][kout][4], V[p][h][tile][4]  (h = lane >> 5 half of the MFMA k pair): consecutive
-//                      lanes read consecutive 16-byte words = conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS).
-// Zero padding (pad = 0, 1 or 2) is applied on the raw load (clamped address, masked value).
+// Structure (measured background in profiles/README.md):
+//   * work item   : 64 output channels x 64 Winograd tiles (2 x 32 or 4 x 16 tiles) x all input channels.  4 waves,
+//                   one per SIMD, each 32 channels x 32 tiles x ALL 16 transform positions = 16 accumulators of 32x32
+//                   (256 registers per lane), so the output transform A^T M A is per-lane register arithmetic.
+//   * persistent  : 256 workgroups (154 KB LDS + 512 registers per lane fill a CU) walk contiguous item ranges; the
+//                   staging pipeline runs across item boundaries, only the output transform + store is serial.
+//   * per chunk of 8 input channels: filter chunk (pre-transformed U = G w G^T, stored as the LDS image) by LDS-DMA;
+//                   raw input region through registers (coalesced rows, zero padding = clamped address + mask) -> LDS;
+//                   input transform B^T d B LDS -> LDS; 64 MFMAs per wave with one ds_read_b128 per operand and
+//                   position (the channel order inside a chunk is permuted so that a 16-byte read feeds 4 k-steps).
+//                   U, V and raw are double-buffered, ONE barrier per chunk, software pipeline 3 chunks deep.
+//   * LDS images  : U[p][h][kout][4], V[p][h][tile][4] (h = lane >> 5 half of the MFMA k pair): consecutive lanes read
+//                   consecutive 16-byte words = conflict-free ds_read_b128 (MI355X_MICROARCH.md, LDS).
+//   * the fp32 MFMA shadows no other instruction (tools/micro/mfma_shadow.hip): the main loop is written in issue
+//                   order as 32 fenced slots of 2 MFMAs + a few staging instructions, to keep the non-MFMA
+//                   instruction count low and evenly spread.
+//   * variants    : FLAT (4 x 16 regions whose tile rows are taken from the whole batch, for 10x32-sized images), EPI
+//                   (conv + eval BatchNorm + identity + ReLU in one launch), 2-way channel split for small launches.
 #include "common.hpp"
 
 using namespace dmh;
