@@ -171,6 +171,87 @@ __global__ __launch_bounds__(NT) void stem_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// ---- train-mode BatchNorm statistics (torchvision BasicBlock / stem under model.train(), MD2/trainer.py:335-375):
+// per-channel mean and biased variance over (B, H, W) in two launches, Welford / Chan in fp32.
+//   partial : grid (S, C); block (s, c) reduces every S-th 1024-element slab of channel c -> (count, mean, M2)
+//   finalize: one thread per channel combines the S partials, writes the affine of the normalisation
+//             scale = weight * invstd, shift = bias - mean * scale, the saved mean / invstd for the backward, and
+//             updates the running statistics in place (unbiased variance, torch.nn.BatchNorm2d semantics).
+struct Wf {
+    float n, mean, m2;
+};
+__device__ __forceinline__ Wf wf_merge(Wf a, Wf b) {
+    if (b.n == 0.f) return a;
+    if (a.n == 0.f) return b;
+    const float n = a.n + b.n, d = b.mean - a.mean, f = b.n / n;
+    return Wf{n, a.mean + d * f, a.m2 + b.m2 + d * d * a.n * f};
+}
+
+__global__ __launch_bounds__(NT) void bn_stats_partial_kernel(const float* __restrict__ x, int B, int C, int HW, int S,
+                                                              float* __restrict__ part) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    // per thread: shifted sums  s1 = sum(v - k), s2 = sum((v - k)^2)  with k = the channel's first element (no division
+    // per element, no cancellation); slabs of 4*NT elements of one (b, c) plane, S slabs apart
+    const float k = x[(size_t)c * HW];
+    float n = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float* xp = x + ((size_t)b * C + c) * HW;
+        for (int r0 = s * 4 * NT; r0 < HW; r0 += S * 4 * NT) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = r0 + q * NT + threadIdx.x;
+                if (r < HW) {
+                    const float d = xp[r] - k;
+                    n += 1.f;
+                    s1 += d;
+                    s2 = fmaf(d, d, s2);
+                }
+            }
+        }
+    }
+    Wf w{n, n > 0.f ? k + s1 / n : 0.f, n > 0.f ? s2 - s1 * s1 / n : 0.f};
+    // wave, then block reduction (fixed order: reproducible)
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        Wf other{__shfl_down(w.n, o, WAVE), __shfl_down(w.mean, o, WAVE), __shfl_down(w.m2, o, WAVE)};
+        w = wf_merge(w, other);
+    }
+    __shared__ Wf red[NT / WAVE];
+    if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        Wf t = red[0];
+#pragma unroll
+        for (int i = 1; i < NT / WAVE; ++i) t = wf_merge(t, red[i]);
+        float* p = part + ((size_t)c * S + s) * 3;
+        p[0] = t.n; p[1] = t.mean; p[2] = t.m2;
+    }
+}
+
+__global__ __launch_bounds__(NT) void bn_stats_finalize_kernel(const float* __restrict__ part, int C, int S,
+                                                               const float* __restrict__ weight,
+                                                               const float* __restrict__ bias, float momentum, float eps,
+                                                               float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float* __restrict__ save_mean,
+                                                               float* __restrict__ save_invstd) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    Wf t{0.f, 0.f, 0.f};
+    for (int s = 0; s < S; ++s) {
+        const float* p = part + ((size_t)c * S + s) * 3;
+        t = wf_merge(t, Wf{p[0], p[1], p[2]});
+    }
+    const float var = t.m2 / t.n, invstd = rsqrtf(var + eps);
+    const float sc = (weight ? weight[c] : 1.f) * invstd;
+    scale[c] = sc;
+    shift[c] = (bias ? bias[c] : 0.f) - t.mean * sc;
+    save_mean[c] = t.mean;
+    save_invstd[c] = invstd;
+    if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * t.mean;
+    if (running_var) running_var[c] = (1.f - momentum) * running_var[c] + momentum * (t.m2 / fmaxf(t.n - 1.f, 1.f));
+}
+
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + NT - 1) / NT); }
 
 template <bool RELU, bool RES>
@@ -234,6 +315,27 @@ int dmh_bn_act_bwd(const float* out, const float* g_out, const float* scale, int
         else launch_bwd<false, false>(out, g_out, scale, C, HW, total, g_x, nullptr, st);
     }
     return check_launch("dmh_bn_act_bwd");
+}
+
+int64_t dmh_bn_stats_partials_size(int B, int C, int HW) {
+    if (B <= 0 || C <= 0 || HW <= 0) return -1;
+    int64_t S = ((int64_t)HW + 4 * NT - 1) / (4 * NT);
+    if (S > 64) S = 64;
+    return (int64_t)C * S * 3;
+}
+
+int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
+                       float eps, float* running_mean, float* running_var, float* partials, float* scale, float* shift,
+                       float* save_mean, float* save_invstd, void* stream) {
+    DMH_REQUIRE(x && partials && scale && shift && save_mean && save_invstd, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && HW > 0 && C <= 65535, "bad sizes");
+    int64_t S = ((int64_t)HW + 4 * NT - 1) / (4 * NT);     // slabs per plane
+    if (S > 64) S = 64;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((unsigned)S, C), dim3(NT), 0, st, x, B, C, HW, (int)S, partials);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(blocks_for(C)), dim3(NT), 0, st, partials, C, (int)S, weight, bias,
+                       momentum, eps, running_mean, running_var, scale, shift, save_mean, save_invstd);
+    return check_launch("dmh_bn_train_stats");
 }
 
 int dmh_stem_bn_relu_pool_fwd(const float* x, const float* scale, const float* shift, int B, int C, int H, int W,

@@ -26,6 +26,12 @@ def _conv_bn_act(conv, x, aff, residual=None):
     return ops.bn_act(conv(x), aff[0], aff[1], residual)
 
 
+def _train_fused(bn, x):
+    """Train-mode BatchNorm on a CUDA tensor with the standard configuration (affine, running statistics, momentum)."""
+    return (ops.WINO_ENABLED and x.is_cuda and x.dtype == torch.float32 and bn.training and bn.momentum is not None
+            and bn.weight is not None and bn.track_running_stats and torch.is_grad_enabled())
+
+
 def _conv(conv, x):
     """conv(x); 3x3 stride-1 pad-1 convolutions of CUDA tensors go through ops.conv3x3 (Winograd-MFMA kernel where the
     shape fills the chip, MIOpen otherwise) -- same parameters, same result within fp32 rounding."""
@@ -48,6 +54,10 @@ class BasicBlock(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        if _train_fused(self.bn1, x):       # train(): batch statistics by the K9 kernels, one pass for BN + add + ReLU
+            idt = x if self.downsample is None else ops.bn_act_train(self.downsample[1], self.downsample[0](x), relu=False)
+            out = ops.bn_act_train(self.bn1, _conv(self.conv1, x))
+            return ops.bn_act_train(self.bn2, _conv(self.conv2, out), residual=idt)
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(_conv(self.conv1, x)))
         out = self.bn2(_conv(self.conv2, out))
@@ -170,8 +180,13 @@ class ResnetEncoder(nn.Module):
         if e.fused_eval_ok(x):
             self.features = self._forward_fused_eval(x)
             return self.features
-        f0 = e.relu(e.bn1(self._conv1(x)))
-        f1 = e.layer1(e.maxpool(f0))
+        z = self._conv1(x)
+        if _train_fused(e.bn1, z) and z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
+            f0, p = ops.stem_bn_relu_pool_train(e.bn1, z)
+        else:
+            f0 = e.relu(e.bn1(z))
+            p = e.maxpool(f0)
+        f1 = e.layer1(p)
         f2 = e.layer2(f1)
         f3 = e.layer3(f2)
         f4 = e.layer4(f3)

@@ -541,6 +541,75 @@ def bn_act(x, scale, shift, residual=None, relu=True):
                         bool(relu))
 
 
+def _bn_train_stats(x, bn):
+    """Batch statistics of x for the BatchNorm2d module `bn` in train mode: (scale, shift, save_mean, save_invstd);
+    updates bn.running_mean / running_var / num_batches_tracked as nn.BatchNorm2d.forward does."""
+    lib = N.lib()
+    B, Cc = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * Cc)
+    dev = x.device
+    part = torch.empty(lib.dmh_bn_stats_partials_size(B, Cc, HW), device=dev, dtype=torch.float32)
+    scale, shift, mean, invstd = (torch.empty(Cc, device=dev, dtype=torch.float32) for _ in range(4))
+    if bn.momentum is None:
+        raise RuntimeError("bn_act_train: cumulative-average BatchNorm (momentum=None) is not supported")
+    track = bn.track_running_stats and bn.running_mean is not None
+    N.check(_timed("bn_train_stats", lambda: lib.dmh_bn_train_stats(
+        N.ptr(x), B, Cc, HW, N.ptr(None if bn.weight is None else _c(bn.weight.detach())),
+        N.ptr(None if bn.bias is None else _c(bn.bias.detach())), float(bn.momentum), float(bn.eps),
+        N.ptr(bn.running_mean if track else None), N.ptr(bn.running_var if track else None), N.ptr(part), N.ptr(scale),
+        N.ptr(shift), N.ptr(mean), N.ptr(invstd), N.stream()), 4 * x.numel()))
+    if track and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return scale, shift, mean, invstd
+
+
+class _BnActTrain(torch.autograd.Function):
+    """Train-mode BatchNorm2d -> (+ residual) -> ReLU: K9 statistics + one bn_act pass forward; backward = ReLU mask
+    (one K9 pass) + aten::native_batch_norm_backward (MIOpen) with the saved batch statistics."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, relu, bn):
+        lib = N.lib()
+        scale, shift, mean, invstd = _bn_train_stats(x, bn)
+        B, Cc = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * Cc)
+        out = torch.empty_like(x)
+        nb = 4 * (x.numel() * (2 if residual is None else 3))
+        N.check(_timed("bn_act_fwd", lambda: lib.dmh_bn_act_fwd(N.ptr(x), N.ptr(scale), N.ptr(shift), N.ptr(residual), B, Cc,
+                                                               HW, int(relu), N.ptr(out), N.stream()), nb))
+        ctx.save_for_backward(x, weight, mean, invstd, out if relu else None)
+        ctx.relu, ctx.eps, ctx.bn = bool(relu), float(bn.eps), bn
+        ctx.res_grad = residual is not None and residual.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight, mean, invstd, out = ctx.saved_tensors
+        lib = N.lib()
+        g = _c(g)
+        B, Cc = g.shape[0], g.shape[1]
+        if ctx.relu:
+            ones = frozen_memo(("ones", Cc, g.device), lambda: torch.ones(Cc, device=g.device, dtype=torch.float32))
+            g_pre = torch.empty_like(g)
+            N.check(_timed("bn_act_bwd", lambda: lib.dmh_bn_act_bwd(N.ptr(out), N.ptr(g), N.ptr(ones), B, Cc,
+                                                                   g.numel() // (B * Cc), 1, N.ptr(g_pre), None, N.stream()),
+                           12 * g.numel()))
+        else:
+            g_pre = g
+        bn = ctx.bn
+        gx, gw, gb = torch.ops.aten.native_batch_norm_backward(
+            g_pre, x, weight, bn.running_mean, bn.running_var, mean, invstd, True, ctx.eps,
+            [ctx.needs_input_grad[0], weight is not None and ctx.needs_input_grad[1],
+             weight is not None and ctx.needs_input_grad[2]])
+        return gx, gw, gb, (g_pre if ctx.res_grad else None), None, None
+
+
+def bn_act_train(bn, x, residual=None, relu=True):
+    """act(bn(x) (+ residual)) for an nn.BatchNorm2d in train mode (batch statistics, running statistics updated):
+    torchvision BasicBlock under model.train() (MD2/networks/resnet_encoder.py:85-98, the training pass)."""
+    return _BnActTrain.apply(_c(x), bn.weight, bn.bias, None if residual is None else _c(residual), bool(relu), bn)
+
+
 class _StemBnReluPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale, shift):
@@ -574,6 +643,56 @@ class _StemBnReluPool(torch.autograd.Function):
                                                                         N.ptr(g_pooled), N.ptr(scale), B, Cc, H, W,
                                                                         N.ptr(g_x), N.stream()), nb))
         return g_x, None, None
+
+
+class _StemTrain(torch.autograd.Function):
+    """Train-mode stem: BatchNorm2d (batch statistics) -> ReLU -> MaxPool2d(3, 2, 1) with the K9 kernels; backward =
+    max-pool adjoint + skip gradient + ReLU mask in one K9 pass, then aten::native_batch_norm_backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn):
+        lib = N.lib()
+        scale, shift, mean, invstd = _bn_train_stats(x, bn)
+        B, Cc, H, W = x.shape
+        feat = torch.empty_like(x)
+        pooled = torch.empty((B, Cc, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        arg = torch.empty((B, Cc, H // 2, W // 2), device=x.device, dtype=torch.uint8)
+        nb = 4 * (2 * x.numel() + pooled.numel()) + arg.numel()
+        N.check(_timed("stem_fwd", lambda: lib.dmh_stem_bn_relu_pool_fwd(N.ptr(x), N.ptr(scale), N.ptr(shift), B, Cc, H, W,
+                                                                        N.ptr(feat), N.ptr(pooled), N.ptr(arg),
+                                                                        N.stream()), nb))
+        ctx.save_for_backward(x, weight, mean, invstd, feat, arg)
+        ctx.eps, ctx.bn = float(bn.eps), bn
+        ctx.mark_non_differentiable(arg)
+        ctx.set_materialize_grads(False)
+        return feat, pooled, arg
+
+    @staticmethod
+    def backward(ctx, g_feat, g_pooled, _g_arg):
+        x, weight, mean, invstd, feat, arg = ctx.saved_tensors
+        if g_feat is None and g_pooled is None:
+            return None, None, None, None
+        lib = N.lib()
+        B, Cc, H, W = feat.shape
+        g_feat = None if g_feat is None else _c(g_feat)
+        g_pooled = None if g_pooled is None else _c(g_pooled)
+        ones = frozen_memo(("ones", Cc, feat.device), lambda: torch.ones(Cc, device=feat.device, dtype=torch.float32))
+        g_pre = torch.empty_like(feat)
+        N.check(_timed("stem_bwd", lambda: lib.dmh_stem_bn_relu_pool_bwd(N.ptr(feat), N.ptr(arg), N.ptr(g_feat),
+                                                                        N.ptr(g_pooled), N.ptr(ones), B, Cc, H, W,
+                                                                        N.ptr(g_pre), N.stream()), 12 * feat.numel()))
+        bn = ctx.bn
+        gx, gw, gb = torch.ops.aten.native_batch_norm_backward(
+            g_pre, x, weight, bn.running_mean, bn.running_var, mean, invstd, True, ctx.eps,
+            [ctx.needs_input_grad[0], weight is not None and ctx.needs_input_grad[1],
+             weight is not None and ctx.needs_input_grad[2]])
+        return gx, gw, gb, None
+
+
+def stem_bn_relu_pool_train(bn, x):
+    """(relu(bn(x)), maxpool3x3/2(relu(bn(x)))) for an nn.BatchNorm2d in train mode; H and W even."""
+    feat, pooled, _ = _StemTrain.apply(_c(x), bn.weight, bn.bias, bn)
+    return feat, pooled
 
 
 def stem_bn_relu_pool(x, scale, shift):

@@ -245,6 +245,16 @@ int dmh_bn_act_fwd(const float* x, const float* scale, const float* shift, const
                    int relu, float* out, void* stream);
 int dmh_bn_act_bwd(const float* out, const float* g_out, const float* scale, int B, int C, int HW, int relu, float* g_x,
                    float* g_residual, void* stream);
+/* train-mode BatchNorm statistics (model.train(): the training pass of MD2/trainer.py:335-375): per-channel batch mean
+ * and biased variance of x[B,C,HW] (two launches, fp32 Welford/Chan combination of shifted sums), from which
+ *   scale = weight * invstd, shift = bias - mean * scale      (feed dmh_bn_act_fwd / dmh_stem_bn_relu_pool_fwd)
+ *   save_mean, save_invstd                                    (for aten::native_batch_norm_backward)
+ * and running_mean / running_var are updated in place with `momentum` (unbiased variance), as nn.BatchNorm2d does.
+ * weight / bias / running_* may be NULL.  partials: dmh_bn_stats_partials_size(B, C, HW) floats of scratch. */
+int64_t dmh_bn_stats_partials_size(int B, int C, int HW);
+int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
+                       float eps, float* running_mean, float* running_var, float* partials, float* scale, float* shift,
+                       float* save_mean, float* save_invstd, void* stream);
 int dmh_stem_bn_relu_pool_fwd(const float* x, const float* scale, const float* shift, int B, int C, int H, int W,
                               float* feat, float* pooled, unsigned char* argmax, void* stream);
 int dmh_stem_bn_relu_pool_bwd(const float* feat, const unsigned char* argmax, const float* g_feat, const float* g_pooled,
