@@ -193,22 +193,27 @@ __global__ __launch_bounds__(NT) void bn_stats_partial_kernel(const float* __res
     // per thread: shifted sums  s1 = sum(v - k), s2 = sum((v - k)^2)  with k = the channel's first element (no division
     // per element, no cancellation); slabs of 4*NT elements of one (b, c) plane, S slabs apart
     const float k = x[(size_t)c * HW];
-    float n = 0.f, s1 = 0.f, s2 = 0.f;
+    float nq[4] = {0.f, 0.f, 0.f, 0.f}, s1q[4] = {0.f, 0.f, 0.f, 0.f}, s2q[4] = {0.f, 0.f, 0.f, 0.f};   // 4 independent chains
     for (int b = 0; b < B; ++b) {
         const float* xp = x + ((size_t)b * C + c) * HW;
         for (int r0 = s * 4 * NT; r0 < HW; r0 += S * 4 * NT) {
+            float v[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int r = r0 + q * NT + threadIdx.x;
-                if (r < HW) {
-                    const float d = xp[r] - k;
-                    n += 1.f;
-                    s1 += d;
-                    s2 = fmaf(d, d, s2);
-                }
+                v[q] = r < HW ? xp[r] : k;
+                nq[q] += r < HW ? 1.f : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float d = v[q] - k;           // padding lanes contribute d = 0
+                s1q[q] += d;
+                s2q[q] = fmaf(d, d, s2q[q]);
             }
         }
     }
+    const float n = (nq[0] + nq[1]) + (nq[2] + nq[3]), s1 = (s1q[0] + s1q[1]) + (s1q[2] + s1q[3]),
+                s2 = (s2q[0] + s2q[1]) + (s2q[2] + s2q[3]);
     Wf w{n, n > 0.f ? k + s1 / n : 0.f, n > 0.f ? s2 - s1 * s1 / n : 0.f};
     // wave, then block reduction (fixed order: reproducible)
 #pragma unroll

@@ -563,6 +563,15 @@ def _bn_train_stats(x, bn):
     return scale, shift, mean, invstd
 
 
+def _bn_backward(g_pre, x, weight, bn, mean, invstd, eps, mask):
+    """BatchNorm2d backward (train mode) from the saved batch statistics.  MIOpen's kernel when all three gradients
+    are wanted (the train pass: 157 us average against 258 us for ATen's native kernel on these shapes)."""
+    if all(mask) and weight is not None and hasattr(torch.ops.aten, "miopen_batch_norm_backward"):
+        return torch.ops.aten.miopen_batch_norm_backward(x, g_pre, weight, bn.running_mean, bn.running_var, mean, invstd, eps)
+    return torch.ops.aten.native_batch_norm_backward(g_pre, x, weight, bn.running_mean, bn.running_var, mean, invstd, True,
+                                                     eps, mask)
+
+
 class _BnActTrain(torch.autograd.Function):
     """Train-mode BatchNorm2d -> (+ residual) -> ReLU: K9 statistics + one bn_act pass forward; backward = ReLU mask
     (one K9 pass) + aten::native_batch_norm_backward (MIOpen) with the saved batch statistics."""
@@ -596,11 +605,9 @@ class _BnActTrain(torch.autograd.Function):
                            12 * g.numel()))
         else:
             g_pre = g
-        bn = ctx.bn
-        gx, gw, gb = torch.ops.aten.native_batch_norm_backward(
-            g_pre, x, weight, bn.running_mean, bn.running_var, mean, invstd, True, ctx.eps,
-            [ctx.needs_input_grad[0], weight is not None and ctx.needs_input_grad[1],
-             weight is not None and ctx.needs_input_grad[2]])
+        gx, gw, gb = _bn_backward(g_pre, x, weight, ctx.bn, mean, invstd, ctx.eps,
+                                  [ctx.needs_input_grad[0], weight is not None and ctx.needs_input_grad[1],
+                                   weight is not None and ctx.needs_input_grad[2]])
         return gx, gw, gb, (g_pre if ctx.res_grad else None), None, None
 
 
@@ -681,11 +688,9 @@ class _StemTrain(torch.autograd.Function):
         N.check(_timed("stem_bwd", lambda: lib.dmh_stem_bn_relu_pool_bwd(N.ptr(feat), N.ptr(arg), N.ptr(g_feat),
                                                                         N.ptr(g_pooled), N.ptr(ones), B, Cc, H, W,
                                                                         N.ptr(g_pre), N.stream()), 12 * feat.numel()))
-        bn = ctx.bn
-        gx, gw, gb = torch.ops.aten.native_batch_norm_backward(
-            g_pre, x, weight, bn.running_mean, bn.running_var, mean, invstd, True, ctx.eps,
-            [ctx.needs_input_grad[0], weight is not None and ctx.needs_input_grad[1],
-             weight is not None and ctx.needs_input_grad[2]])
+        gx, gw, gb = _bn_backward(g_pre, x, weight, ctx.bn, mean, invstd, ctx.eps,
+                                  [ctx.needs_input_grad[0], weight is not None and ctx.needs_input_grad[1],
+                                   weight is not None and ctx.needs_input_grad[2]])
         return gx, gw, gb, None
 
 
