@@ -49,3 +49,27 @@ def test_host_side_argument_checks_without_gpu():
     assert lib.dmh_pgd_linf_step(None, None, None, 0.1, 0.1, None, 0, None) == 1
     p = N.PhotoArgs()
     assert lib.dmh_photo_loss_fwd(ctypes.byref(p), (ctypes.c_void_p * 4)(), (ctypes.c_void_p * 4)(), None, None) == 1
+
+
+def test_convolution_entry_points_reject_bad_shapes_without_gpu():
+    """K10-K13 / K9 statistics: host-side argument checks and size helpers (no launch, no GPU)."""
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    one = ctypes.c_void_p(16)           # a non-NULL dummy: every call below must fail before any launch
+    assert lib.dmh_wino_weight_size(64, 64) == (64 // 8) * 16 * 2 * 64 * 4
+    assert lib.dmh_wino_weight_size(96, 32) == (32 // 8) * 16 * 2 * 128 * 4      # output channels padded to 64s
+    assert lib.dmh_wino_weight_size(64, 12) == -1
+    assert lib.dmh_wino_conv3x3(one, one, None, 1, 16, 64, 8, 8, 1, one, None) != 0          # < 24 input channels
+    assert b"multiple of 8" in lib.dmh_last_error()
+    assert lib.dmh_wino_conv3x3(one, one, None, 1, 32, 64, 9, 8, 1, one, None) != 0          # odd output height
+    assert lib.dmh_wino_conv3x3_act(one, one, None, None, 1, 1, 32, 64, 8, 8, 3, one, None) != 0   # pad
+    assert lib.dmh_conv3x3_small(one, one, None, 1, 64, 64, 8, 8, 1, 0, one, None) != 0
+    assert b"channel counts" in lib.dmh_last_error()
+    assert lib.dmh_conv3x3_head(one, one, None, 1, 24, 8, 8, 1, one, None) != 0
+    assert lib.dmh_conv7x7s2_bwd_data(one, one, 1, 64, 5, 8, 8, one, None) != 0               # > 4 image channels
+    assert lib.dmh_conv7x7s2_bwd_data(one, one, 1, 64, 3, 7, 8, one, None) != 0               # odd height
+    assert lib.dmh_bn_stats_partials_size(2, 8, 100) == 8 * 1 * 3
+    assert lib.dmh_bn_stats_partials_size(32, 64, 160 * 512) == 64 * 64 * 3
+    assert lib.dmh_bn_stats_partials_size(0, 8, 100) == -1
+    assert lib.dmh_stem_bn_relu_pool_fwd(one, one, one, 1, 2, 3, 4, one, one, one, None) != 0
+    assert b"even" in lib.dmh_last_error()
