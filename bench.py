@@ -23,6 +23,7 @@ sys.path.insert(0, REPO)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak of MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290
 
 # HBM bytes per launch measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of
@@ -192,12 +193,19 @@ def main():
                     "others": {names[k][0]: {"avg_ms": round(v, 4), "GB/s": round(names[k][1] / (v * 1e-3) / 1e9, 1)}
                                for k, v in kms.items() if k != dom}}
             # streaming kernels of the decoder glue: shapes vary per launch, so total bytes / total time
-            for k, (cnt, ms, nb) in sorted(kbytes.items()):
+            for k, (cnt, ms, nb, fl) in sorted(kbytes.items()):
                 if not k.startswith("photo_") and ms > 0:
-                    roof["others"][k + "_kernel"] = {"launches_per_step": round(cnt / a.steps, 1),
-                                                     "ms_per_step": round(ms / a.steps, 3),
-                                                     "GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
-                                                     "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+                    ent = {"launches_per_step": round(cnt / a.steps, 1), "ms_per_step": round(ms / a.steps, 3)}
+                    if fl > 0:      # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe, not by HBM
+                        direct = fl / (ms * 1e-3) / 1e12
+                        ent.update({"bound": "mfma", "TFLOP/s_direct_equivalent": round(direct, 1),
+                                    "achieved": round(direct / 2.25, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(direct / 2.25 / MFMA_F32_PEAK_TFLOPS, 4),
+                                    "note": "achieved = MFMA flops actually issued (Winograd F(2x2,3x3): direct / 2.25)"})
+                    else:
+                        ent.update({"GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
+                                    "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+                    roof["others"][k + "_kernel"] = ent
         out = {"metric": "adv-train images/sec @1024x320, 10-step PGD, bs32", "value": round(a.batch_size * world * a.steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",

@@ -30,25 +30,27 @@ def profile_ms():
     if not _profile:
         return {}
     torch.cuda.synchronize()
-    return {k: sum(a.elapsed_time(b) for a, b, _ in v) / len(v) for k, v in _profile.items() if v}
+    return {k: sum(e[0].elapsed_time(e[1]) for e in v) / len(v) for k, v in _profile.items() if v}
 
 
 def profile_bytes():
-    """Per instrumented kernel: (launches, total ms, total algorithmic bytes) -- for kernels whose shape varies."""
+    """Per instrumented kernel: (launches, total ms, total algorithmic bytes, total direct-convolution flops) -- for
+    kernels whose shape varies from launch to launch."""
     if not _profile:
         return {}
     torch.cuda.synchronize()
-    return {k: (len(v), sum(a.elapsed_time(b) for a, b, _ in v), sum(n for _, _, n in v)) for k, v in _profile.items() if v}
+    return {k: (len(v), sum(e[0].elapsed_time(e[1]) for e in v), sum(e[2] for e in v), sum(e[3] for e in v))
+            for k, v in _profile.items() if v}
 
 
-def _timed(name, launch, nbytes=0):
+def _timed(name, launch, nbytes=0, flops=0):
     if _profile is None:
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     rc = launch()
     e1.record()
-    _profile.setdefault(name, []).append((e0, e1, nbytes))
+    _profile.setdefault(name, []).append((e0, e1, nbytes, flops))
     return rc
 
 
@@ -792,7 +794,7 @@ def _wino_conv(x, U, bias, K, pad):
     y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
     nb = 4 * (x.numel() + y.numel()) + 4 * U.numel()
     N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad,
-                                                               N.ptr(y), N.stream()), nb))
+                                                               N.ptr(y), N.stream()), nb, 18 * Cc * y.numel()))
     return y
 
 
@@ -878,7 +880,7 @@ class _ConvBnAct(torch.autograd.Function):
         nb = 4 * (x.numel() + y.numel() * (1 if residual is None else 2)) + 4 * U.numel()
         N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(N.ptr(x), N.ptr(U), N.ptr(shift), N.ptr(residual),
                                                                        int(relu), B, Cc, K, H, W, pad, N.ptr(y),
-                                                                       N.stream()), nb))
+                                                                       N.stream()), nb, 18 * Cc * y.numel()))
         ctx.save_for_backward(x, weight, scale, y if relu else None)
         ctx.pad, ctx.relu = pad, bool(relu)
         ctx.res_grad = residual is not None and residual.requires_grad
