@@ -303,6 +303,46 @@ def test_wino_conv3x3_kernel_vs_aten(shape):
         torch.testing.assert_close(ggot, gref, rtol=1e-5, atol=2e-6 * float(gref.abs().max()))
 
 
+def test_network_kernels_vs_formulation_oracle():
+    """K10 / K11 / K12 through the C ABI == oracle/conv_ref.py (fp64 numpy restatement of the same formulations:
+    Winograd tiles, backward filter, parity gather), on seeded inputs small enough for the oracle's Python loops."""
+    import numpy as np
+    from depthmodelhardening_amd import _native as N
+    from oracle import conv_ref
+    lib = N.lib()
+    rs = np.random.RandomState(3)
+    dev = torch.device("cuda")
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).float().to(dev)   # noqa: E731
+
+    def close(got, want):
+        want = torch.from_numpy(want).float()
+        torch.testing.assert_close(got.cpu(), want, rtol=1e-5, atol=3e-6 * float(want.abs().max()))
+    # K10 forward and backward-data (pad 1)
+    B, C, K, H, W = 1, 24, 64, 8, 34
+    x, w = rs.rand(B, C, H, W) - 0.5, (rs.rand(K, C, 3, 3) - 0.5) * 0.3
+    wd = f32(w)                                  # (device tensors are kept in variables: N.ptr() does not hold them alive)
+    for backward, inp, n_out, p in ((0, x, K, 1), (1, rs.rand(B, K, H, W) - 0.5, C, 1)):
+        U = torch.empty(lib.dmh_wino_weight_size(n_out, inp.shape[1]), device=dev)
+        N.check(lib.dmh_wino_weight_transform(N.ptr(wd), K, C, backward, N.ptr(U), N.stream()))
+        y = torch.full((B, n_out, H, W), float("nan"), device=dev)
+        xd = f32(inp)
+        N.check(lib.dmh_wino_conv3x3(N.ptr(xd), N.ptr(U), None, B, inp.shape[1], n_out, H, W, p, N.ptr(y), N.stream()))
+        wf = conv_ref.backward_filter(w) if backward else w
+        close(y, conv_ref.conv3x3_winograd(np.float32(inp), np.float32(wf), p))
+    # K11 (direct MFMA), pad 0
+    x, w = rs.rand(1, 16, 10, 36) - 0.5, (rs.rand(16, 16, 3, 3) - 0.5) * 0.3
+    y = torch.full((1, 16, 8, 34), float("nan"), device=dev)
+    xd, wd = f32(x), f32(w)
+    N.check(lib.dmh_conv3x3_small(N.ptr(xd), N.ptr(wd), None, 1, 16, 16, 10, 36, 0, 0, N.ptr(y), N.stream()))
+    close(y, conv_ref.conv3x3_direct(np.float32(x), np.float32(w), 0))
+    # K12 (stem convolution image gradient)
+    gy, w = rs.rand(1, 8, 6, 10) - 0.5, (rs.rand(8, 3, 7, 7) - 0.5) * 0.2
+    gx = torch.full((1, 3, 12, 20), float("nan"), device=dev)
+    gd, wd = f32(gy), f32(w)
+    N.check(lib.dmh_conv7x7s2_bwd_data(N.ptr(gd), N.ptr(wd), 1, 8, 3, 12, 20, N.ptr(gx), N.stream()))
+    close(gx, conv_ref.stem_conv_bwd_data(np.float32(gy), np.float32(w), 12, 20))
+
+
 def test_wino_conv3x3_rejects_bad_shapes():
     from depthmodelhardening_amd import _native as N
     lib = N.lib()

@@ -151,3 +151,35 @@ def test_pgd_depth(golden, targeted):
     torch.testing.assert_close(adv[:, :, ::16, ::8], t(g["adv_rows"]), rtol=0, atol=1e-6)
     torch.testing.assert_close(adv.double().sum((2, 3)), t(g["adv_sum"]), rtol=1e-7, atol=0)
     assert abs(float((adv - clean).abs().max()) - float(g["delta_absmax"])) < 1e-7
+
+
+def test_network_kernel_formulations_match_torch_nn():
+    """oracle/conv_ref.py (the formulations inside K9-K13) == torch.nn on the CPU: Winograd F(2x2,3x3) incl. the
+    backward-data filter, the parity-gather stem gradient, the shifted-sum / Chan BatchNorm statistics."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from oracle import conv_ref
+    rs = np.random.RandomState(0)
+    for (B, C, K, H, W, pad) in [(2, 5, 4, 6, 8, 1), (1, 3, 6, 8, 6, 0), (1, 4, 3, 4, 6, 2)]:
+        x = rs.rand(B, C, H, W) - 0.5
+        w = rs.rand(K, C, 3, 3) - 0.5
+        ref = F.conv2d(torch.from_numpy(x), torch.from_numpy(w), None, padding=pad).numpy()
+        np.testing.assert_allclose(conv_ref.conv3x3_direct(x, w, pad), ref, atol=1e-12)
+        np.testing.assert_allclose(conv_ref.conv3x3_winograd(x, w, pad), ref, atol=1e-12)
+        # backward-data = the same convolution on g with the flipped/transposed filter and pad' = 2 - pad
+        xt = torch.from_numpy(x).requires_grad_(True)
+        y = F.conv2d(xt, torch.from_numpy(w), None, padding=pad)
+        g = rs.rand(*y.shape) - 0.5
+        gx = torch.autograd.grad(y, xt, torch.from_numpy(g))[0].numpy()
+        np.testing.assert_allclose(conv_ref.conv3x3_winograd(g, conv_ref.backward_filter(w), 2 - pad), gx, atol=1e-12)
+    x = torch.from_numpy(rs.rand(2, 3, 12, 16) - 0.5).requires_grad_(True)
+    w = rs.rand(8, 3, 7, 7) - 0.5
+    y = F.conv2d(x, torch.from_numpy(w), None, 2, 3)
+    g = rs.rand(*y.shape) - 0.5
+    gx = torch.autograd.grad(y, x, torch.from_numpy(g))[0].numpy()
+    np.testing.assert_allclose(conv_ref.stem_conv_bwd_data(g, w, 12, 16), gx, atol=1e-12)
+    xb = rs.rand(3, 4, 5, 7) * 3 + 10          # large offset: the shifted sums must not cancel
+    mean, var = conv_ref.bn_train_stats(xb)
+    np.testing.assert_allclose(mean, xb.mean((0, 2, 3)), rtol=1e-13)
+    np.testing.assert_allclose(var, xb.var((0, 2, 3)), rtol=1e-11)
