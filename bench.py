@@ -123,9 +123,6 @@ def main():
     argv += ["--loss_variant", a.loss_variant]
     opts = MonodepthOptions().parse(argv)
     trainer = Trainer(opts, rank=rank, world_size=world, device=device)
-    if int(os.environ.get("DMH_CHANNELS_LAST", "0")):   # experiment knob: NHWC activations for MIOpen
-        for m in trainer.models.values():
-            m.to(memory_format=torch.channels_last)
     trainer.set_train()
 
     def sync():

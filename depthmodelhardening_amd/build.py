@@ -4,6 +4,7 @@
 
 hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the tree.
 """
+import fcntl
 import os
 import subprocess
 import sys
@@ -39,8 +40,20 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=True):
+    """Compile what is stale and link.  Safe to call from several processes at once (torchrun ranks on a fresh
+    checkout): an exclusive file lock serialises the whole build, every object and the library are written to a
+    temporary name and moved into place atomically, so a reader never sees a half-written file."""
     os.makedirs(LIB_DIR, exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "dmh_hip.h")]
     jobs = []
@@ -48,14 +61,19 @@ def build(force=False, verbose=True):
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         if force or _stale(o, [s] + headers):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append(([hipcc] + FLAGS + ["-c", s, "-o"], o))
 
-    def run(cmd):
+    def run(job):
+        cmd, target = job
+        tmp = "%s.tmp.%d" % (target, os.getpid())
         if verbose:
-            print(" ".join(cmd), flush=True)
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            print(" ".join(cmd + [target]), flush=True)
+        r = subprocess.run(cmd + [tmp], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if r.returncode != 0:
+            if os.path.exists(tmp):
+                os.remove(tmp)
             raise RuntimeError("hipcc failed:\n" + r.stdout)
+        os.replace(tmp, target)
         return r.stdout
 
     with ThreadPoolExecutor(max_workers=4) as ex:
@@ -64,7 +82,7 @@ def build(force=False, verbose=True):
                 print(out)
     objs = [os.path.join(OBJ_DIR, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB_PATH, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs)
+        run(([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o"], LIB_PATH))
     return LIB_PATH
 
 

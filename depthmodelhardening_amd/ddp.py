@@ -50,18 +50,37 @@ class GradBucket(object):
         dev, dt = self.params[0].device, self.params[0].dtype
         self.numel = sum(p.numel() for p in self.params)
         self.flat = torch.zeros(self.numel, device=dev, dtype=dt)
+        self._offsets = []
         off = 0
         for p in self.params:
-            n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)  # autograd accumulates in place into the view
-            off += n
+            self._offsets.append(off)
+            off += p.numel()
+        self.attach()
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group) if dist.is_initialized() else 1)
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._work = None
         self._event = None
 
+    def attach(self):
+        """(Re-)point every parameter's ``.grad`` at its slice of the flat buffer."""
+        for p, off in zip(self.params, self._offsets):
+            p.grad = self.flat[off:off + p.numel()].view_as(p)  # autograd accumulates in place into the view
+
+    def check_attached(self):
+        """Every ``.grad`` must still alias its slice: ``optimizer.zero_grad(set_to_none=True)``, ``module.to(memory_format=
+        ...)`` or ``p.grad = None`` silently detach it, after which zero() and the all-reduce would act on a buffer
+        autograd no longer writes to.  Pointer compare only -- no device work."""
+        base, esz = self.flat.data_ptr(), self.flat.element_size()
+        for p, off in zip(self.params, self._offsets):
+            g = p.grad
+            if g is None or g.data_ptr() != base + off * esz or not g.is_contiguous():
+                raise RuntimeError("GradBucket: the .grad of a %s parameter no longer aliases the flat bucket (was "
+                                   "zero_grad(set_to_none=True) / .to(memory_format=...) called after the bucket was "
+                                   "built?); call bucket.attach() or build the bucket last" % (tuple(p.shape),))
+
     def zero(self):
+        self.check_attached()
         self.flat.zero_()
 
     def start_all_reduce(self):
@@ -112,3 +131,22 @@ def broadcast_parameters(modules, src=0, group=None):
             n = t.numel()
             t.copy_(flat[off:off + n].view_as(t))
             off += n
+
+
+def average_buffers(modules, group=None):
+    """Average the floating-point buffers (BatchNorm running statistics) over the ranks: BatchNorm stays per rank
+    during training (no SyncBN), so without this the rank-0 checkpoint and the eval-mode attack / val() would carry one
+    shard's statistics only.  Collective: every rank must call it (end of each epoch)."""
+    if not dist.is_initialized() or dist.get_world_size(group) <= 1:
+        return
+    bufs = [b for m in modules for b in m.buffers() if b.dtype.is_floating_point]
+    if not bufs:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    flat.div_(dist.get_world_size(group))
+    off = 0
+    for b in bufs:
+        n = b.numel()
+        b.copy_(flat[off:off + n].view_as(b))
+        off += n

@@ -140,8 +140,18 @@ class ResNet(nn.Module):
             shift = b - mu * scale
             return {bn: (sc, sh) for bn, sc, sh in zip(self._bns, scale.split(sizes), shift.split(sizes))}
 
+    def bn_params_constant(self):
+        """The fused eval path folds every BatchNorm into a detached (scale, shift): only valid when no gradient can be
+        owed to a BatchNorm weight / bias -- inside ops.frozen_weights() (an attack), under torch.no_grad(), or when no
+        affine parameter requires grad.  Fine-tuning with frozen statistics (eval() + grad on) must take the module
+        path, where nn.BatchNorm2d propagates to weight and bias as the reference's does."""
+        if ops.weights_frozen() or not torch.is_grad_enabled():
+            return True
+        return not any(p is not None and p.requires_grad for bn in self._bns for p in (bn.weight, bn.bias))
+
     def fused_eval_ok(self, x):
-        return self.fuse_eval_bn and x.is_cuda and x.dtype == torch.float32 and not any(bn.training for bn in self._bns)
+        return (self.fuse_eval_bn and x.is_cuda and x.dtype == torch.float32 and not any(bn.training for bn in self._bns)
+                and self.bn_params_constant())
 
     def _make_layer(self, block, planes, blocks, stride=1):
         downsample = None

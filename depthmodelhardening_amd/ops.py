@@ -534,11 +534,20 @@ class _BnAct(torch.autograd.Function):
         return g_x, None, None, g_res, None
 
 
+def _reject_affine_grad(name, scale, shift):
+    """scale / shift are constants of these ops (their backward returns None for them): refuse, loudly, a call that
+    expects a gradient through them instead of silently dropping it."""
+    if torch.is_grad_enabled() and not _wino_frozen and (scale.requires_grad or shift.requires_grad):
+        raise RuntimeError("%s: scale/shift require grad, but this op treats them as constants (eval-mode BatchNorm "
+                           "inside an attack); use the nn.BatchNorm2d module path, ops.frozen_weights() or detach()" % name)
+
+
 def bn_act(x, scale, shift, residual=None, relu=True):
     """act(x * scale[c] + shift[c] (+ residual)) in one pass: BatchNorm2d in eval() mode folded to its per-channel
     affine, the BasicBlock's identity add and the ReLU (torchvision BasicBlock.forward as used by
     MD2/networks/resnet_encoder.py:85-98).  No gradient flows to scale/shift (eval-mode statistics and affine
     parameters are constants of the attack; phy_obj_atk.py:96 differentiates w.r.t. the patch only)."""
+    _reject_affine_grad("bn_act", scale, shift)
     return _BnAct.apply(_c(x), _c(scale.detach()), _c(shift.detach()), None if residual is None else _c(residual),
                         bool(relu))
 
@@ -705,6 +714,7 @@ def stem_bn_relu_pool_train(bn, x):
 def stem_bn_relu_pool(x, scale, shift):
     """(ReLU(BN_eval(x)), MaxPool2d(3, 2, 1) of it) in one pass -- the encoder stem of
     MD2/networks/resnet_encoder.py:88-91 (features[0] and the input of layer1).  H and W must be even."""
+    _reject_affine_grad("stem_bn_relu_pool", scale, shift)
     feat, pooled, _ = _StemBnReluPool.apply(_c(x), _c(scale.detach()), _c(shift.detach()))
     return feat, pooled
 
@@ -735,6 +745,11 @@ def frozen_weights():
         _wino_frozen -= 1
         if _wino_frozen == 0:
             _wino_cache.clear()
+
+
+def weights_frozen():
+    """True inside a frozen_weights() scope (network parameters are constants there)."""
+    return _wino_frozen > 0
 
 
 def frozen_memo(key, fn):
@@ -922,6 +937,7 @@ def conv3x3_bn_act(x, weight, scale, shift, residual=None, relu=True, padding=1)
     BasicBlock pattern of the encoder in eval() (MD2/networks/resnet_encoder.py:85-98).  One K10 launch where the shape
     fills the chip, otherwise conv3x3 followed by the K9 bn_act pass.  No gradient flows to scale / shift."""
     B, Cc, H, W = x.shape
+    _reject_affine_grad("conv3x3_bn_act", scale, shift)
     if x.is_cuda and _wino_ok(B, Cc, weight.shape[0], H + 2 * padding - 2, W + 2 * padding - 2, allow_split=False):
         return _ConvBnAct.apply(_c(x), weight, _c(scale.detach()), _c(shift.detach()),
                                 None if residual is None else _c(residual), bool(relu), int(padding))

@@ -25,9 +25,9 @@ from . import _native as N
 from . import networks, ops
 from .contrastive import SimSiam
 from .datasets import SyntheticKITTIDataset, make_object
-from .ddp import GradBucket, broadcast_parameters
+from .ddp import GradBucket, average_buffers, broadcast_parameters
 from .depth_model import DepthModelWrapper, import_depth_model
-from .layers import SSIM, BackprojectDepth, Project3D, disp_to_depth
+from .layers import SSIM
 from .my_utils import ori_H, ori_W
 
 
@@ -112,13 +112,10 @@ class Trainer:
             self.adv_args = args
             self.dataset.update_adv_obj(self.dataset.next_scenes(args["batch_size"]))   # trainer.py:231-233
 
-        if not self.opt.no_ssim:
-            self.ssim = SSIM().to(self.device)
-        self.backproject_depth, self.project_3d = {}, {}
-        for scale in self.opt.scales:
-            h, w = self.opt.height // (2 ** scale), self.opt.width // (2 ** scale)
-            self.backproject_depth[scale] = BackprojectDepth(self.opt.batch_size, h, w).to(self.device)
-            self.project_3d[scale] = Project3D(self.opt.batch_size, h, w).to(self.device)
+        # The reference builds SSIM() and per-scale BackprojectDepth / Project3D modules here (MD2/trainer.py:240-254);
+        # the fused loss derives the pixel grid on chip, so those ~170 MB of device buffers (B=32) are not allocated.
+        # compute_reprojection_loss (stand-alone surface) builds its SSIM lazily.
+        self._ssim = None
         self.timings = {}
         self.val_eval_count = 10   # evaluate_attacks(..., eval_count=10), MD2/trainer.py:465
         if self.rank == 0:
@@ -193,6 +190,8 @@ class Trainer:
                 break
         self._apply_pending_update()
         self.model_lr_scheduler.step()
+        if self.world_size > 1:     # BatchNorm statistics are per rank during the epoch; the checkpoint gets their mean
+            average_buffers([m for n, m in self.models.items() if n != "DepthModelWrapper"])
 
     def val(self):
         """Validate on a single minibatch, then evaluate the model under attack (MD2/trainer.py:435-470: an L0 attack
@@ -201,8 +200,8 @@ class Trainer:
         with torch.no_grad():
             inputs = self.dataset.next_batch(self.opt.batch_size)
             self.process_batch(inputs)
-        eval_args = {"norm_type": "l_0", "step": self.opt.atk_steps, "adam_lr": 0.5, "mask_wt": 0.06, "l0_thresh": 0.1,
-                     "batch_size": 8}
+        eval_args = {"norm_type": "l_0", "step": 10, "adam_lr": 0.5, "mask_wt": 0.06, "l0_thresh": 0.1,
+                     "batch_size": 8}    # hard-coded in the reference, MD2/trainer.py:452-461
         from .evaluate_depth import evaluate_attacks
         errors = evaluate_attacks(self.models['DepthModelWrapper'], eval_args, eval_count=self.val_eval_count,
                                   scene_source=self.dataset.next_scenes)
@@ -250,7 +249,9 @@ class Trainer:
         l1_loss = torch.abs(target - pred).mean(1, True)
         if self.opt.no_ssim:
             return l1_loss
-        return 0.85 * self.ssim(pred, target).mean(1, True) + 0.15 * l1_loss
+        if self._ssim is None:
+            self._ssim = SSIM().to(pred.device)
+        return 0.85 * self._ssim(pred, target).mean(1, True) + 0.15 * l1_loss
 
     def compute_losses(self, inputs, outputs):
         """Compute the reprojection and smoothness losses for a minibatch."""
@@ -315,6 +316,8 @@ class Trainer:
         save_folder = os.path.join(self.log_path, "models", "weights_{}".format(self.epoch))
         os.makedirs(save_folder, exist_ok=True)
         for model_name, model in self.models.items():
+            if model_name == 'DepthModelWrapper':       # a view of encoder + depth, not a model of its own (:773-774)
+                continue
             to_save = model.state_dict()
             if model_name == 'encoder':
                 to_save['height'] = self.opt.height
