@@ -48,8 +48,10 @@ _SIGNATURES = {
     "dmh_version": (C.c_char_p, []),
     "dmh_last_error": (C.c_char_p, []),
     "dmh_photo_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
-    "dmh_photo_loss_fwd": (C.c_int, [C.POINTER(PhotoArgs), _PtrArr, _PtrArr, _fp, _fp]),
-    "dmh_photo_loss_bwd": (C.c_int, [C.POINTER(PhotoArgs), _PtrArr, _fp, _fp, _PtrArr, _fp]),
+    "dmh_photo_stage_size": (C.c_int64, [C.POINTER(PhotoArgs)]),
+    "dmh_photo_loss_fwd": (C.c_int, [C.POINTER(PhotoArgs), _fp, _PtrArr, _fp, _fp]),
+    "dmh_photo_loss_bwd": (C.c_int, [C.POINTER(PhotoArgs), _fp, _fp, _fp, _fp, _PtrArr, _fp]),
+    "dmh_unpack_selection": (C.c_int, [_fp, C.c_int64, C.c_int, _fp, _fp]),
     "dmh_upsample_bilinear_adjoint": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "dmh_warp_view_fwd": (C.c_int, [_fp] * 5 + [C.c_int] * 5 + [C.c_float, C.c_float] + [_fp] * 4),
     "dmh_warp_view_bwd": (C.c_int, [_fp] * 5 + [C.c_int] * 5 + [C.c_float, C.c_float] + [_fp] * 4),

@@ -1,768 +1,827 @@
-// K1 -- fused photometric-reprojection loss for gfx950 (MI355X).
+// K1 -- fused photometric-reprojection loss for gfx950 (MI355X), wave-strip formulation.
 //
-// One launch covers every scale: a 64x16 output tile keeps the target tile (+halo) resident in
-// LDS, evaluates the identity term once, then for each scale warps the source view into an LDS
-// tile (bilinear-upsampled disparity -> depth -> back-project -> project -> border-clamped
-// bilinear gather), evaluates SSIM(3x3, reflect)+L1 out of LDS, takes the per-pixel min/argmin
-// and accumulates block partial sums.  The backward kernel recomputes the warp on a halo-2 tile,
-// turns d loss / d warped into three 3x3 box sums of per-pixel SSIM coefficient fields, and chains
-// through the bilinear weights, the projective divide and 1/(a+b*disp).
+// One wave owns a vertical strip of the image: lane l holds column X0 - halo + l and the wave walks down the rows.
+// Everything a 3x3 SSIM window needs from the neighbouring columns comes from the neighbouring LANES (DPP wave
+// shifts fused into v_add_f32), everything it needs from the neighbouring rows from a rolling pair of row-sum
+// records in registers -- no LDS tile, no barrier, every pixel's warp is evaluated exactly once per strip.
+//
+//   forward : per row, the target row sums once, the identity term once (the reference recomputes it per scale,
+//             MD2/trainer.py:608-621), then for every scale bilinear-upsampled disparity -> projection -> border-
+//             clamped bilinear gather of the source (buffer loads, L1/L2 resident) -> row sums -> SSIM + L1 for
+//             the row above -> per-pixel min / argmin -> one selection byte per pixel (2 bits per scale) and
+//             fixed-order partial sums per wave (bitwise reproducible, no atomics).
+//   backward: one wave per (strip, scale); recomputes the warp, turns d loss / d warped into three SSIM
+//             coefficient fields whose 3x3 box sums (reflection-pad adjoint folded in as x2 multipliers) give the
+//             gradient of every warped pixel two rows later, chains through the bilinear taps and the projection,
+//             and applies the ADJOINT OF THE DISPARITY UP-SAMPLING in the same wave: horizontal part through a
+//             128-float LDS row, vertical part in two accumulators.  Coarse-scale results go to a per-strip
+//             staging block (strips overlap by one low-resolution texel); a small gather kernel adds the <= 4
+//             overlapping blocks in a fixed order.  No full-resolution gradient is ever written.
+//
+// Numerics.  The sample coordinate is carried as pixel + delta:  with A = (K T)[:3,:3] inv_K[:3,:3] and D = A - I
+// (evaluated in float64 per wave, so that the 1e-7-sized entries of D survive),
+//     delta_x = (e_x + sd * (P03 - x m)) / (a_z + sd m),   e_x = D0.(x,y,1) - x D2.(x,y,1),  a_z = 1 + D2.(x,y,1),
+//     sd = min_disp + (max_disp - min_disp) disp = 1 / depth,  m = P23 + 1e-7          (MD2/layers.py:16-25,163-198)
+// which is the reference's projection divided through by depth.  floor() and the bilinear fraction are taken from
+// delta alone, so the coordinate noise is ~1e-7 * |delta| instead of ~1e-7 * |x| of the reference's own fp32 chain:
+// far fewer bilinear-cell flips against exact arithmetic than the fp32 reference itself has.  SSIM sums are taken
+// of (value - 0.5), which removes most of the E[x^2] - mu^2 cancellation (sigma is shift invariant).
 //
 // Reference semantics: MD2/trainer.py:472-537,589-660; MD2/layers.py:16-25,139-198,223-253;
 // DH/trainer.py:557-590,638-708.  (file:line relative to /root/reference/DepthNetworks/...)
-//
-// HBM-bound stencil+gather: no MFMA.  Rows are read as 64-lane coalesced 256-B segments; the
-// gather rides L1/L2 (stereo flow is horizontal, so neighbouring lanes hit neighbouring texels).
 #include "common.hpp"
 
 using namespace dmh;
 
 namespace {
 
-constexpr int TW = 64, TH = 16, NT = 256;
-constexpr int PXT = TH / (NT / TW);  // pixels per thread (vertical run) = 4
-static_assert(PXT == 4, "thread owns a vertical run of 4 pixels");
-
-// forward: halo-1 tile
-constexpr int F_HW = TW + 2, F_HH = TH + 2, F_LD = F_HW + 1, F_PLANE = F_HH * F_LD;
-// backward: halo-2 tile
-constexpr int B_HW = TW + 4, B_HH = TH + 4, B_LD = B_HW + 1, B_PLANE = B_HH * B_LD;
-
+constexpr int NT = 256;            // 4 independent waves per workgroup, one strip tile each; no barriers
+constexpr int WPB = NT / WAVE;
+constexpr int FW_OUT = WAVE - 2;   // forward strips: halo of 1 column each side
+constexpr int BW_OUT = WAVE - 4;   // backward strips: halo of 2 columns each side
+constexpr float SHIFT = 0.5f;      // SSIM statistics are taken of (value - SHIFT)
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+constexpr float K81C1 = 81.f * C1, K81C2 = 81.f * C2, K9S = 9.f * SHIFT;
 
-// min waves per SIMD requested from the register allocator (tuning knobs)
-#ifndef DMH_FWD_WAVES
-#define DMH_FWD_WAVES 2
-#endif
-#ifndef DMH_BWD_WAVES
-#define DMH_BWD_WAVES 2
-#endif
-
-
-struct Cam {
-    float ik[9];   // inv_K[:3,:3]           MD2/layers.py:164
-    float P[12];   // (K @ T)[:3,:]          MD2/layers.py:188
-    float A[9];    // P[:, :3] @ inv_K[:3,:3]: d(X,Y,Z)/d depth is affine in the pixel coordinates (fast path)
-};
-
-// second stage of load_cam (after a barrier): A = P[:, :3] @ ik
-__device__ __forceinline__ void compose_cam(Cam* cam, int t) {
-    if (t < 9) {
-        const int i = t / 3, j = t % 3;
-        cam->A[t] = cam->P[i * 4 + 0] * cam->ik[0 * 3 + j] + cam->P[i * 4 + 1] * cam->ik[1 * 3 + j] +
-                    cam->P[i * 4 + 2] * cam->ik[2 * 3 + j];
-    }
+// ---------------------------------------------------------------------------------------------- cross-lane
+// wave_shr:1 / wave_shl:1 DPP controls (GFX9): lane i reads lane i-1 / i+1; the edge lane reads 0.  The compiler
+// folds them into the consuming v_add_f32 / v_fma_f32.
+__device__ __forceinline__ float lane_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
 }
-
-struct KArgs {
-    dmh_photo_args a;
-    float* sel[DMH_MAX_SCALES];
-    float* to_opt[DMH_MAX_SCALES];
-    float* partials;
-    const float* csel[DMH_MAX_SCALES];
-    const float* gvec;
-    const float* fin;
-    float* g_up[DMH_MAX_SCALES];
-    int tiles_x, tiles_y, nblk;
-    float min_disp, dmul;  // scaled_disp = min_disp + dmul*disp   MD2/layers.py:21-23
-};
-
-__device__ __forceinline__ void load_cam(Cam* cam, const float* __restrict__ K, const float* __restrict__ invK,
-                                         const float* __restrict__ T, int b, int t) {
-    // t in [0,21): 9 inv_K entries + 12 entries of (K@T)[:3,:]
-    if (t < 9) {
-        cam->ik[t] = invK[b * 16 + (t / 3) * 4 + (t % 3)];
-    } else if (t < 21) {
-        const int i = (t - 9) / 4, j = (t - 9) % 4;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc += K[b * 16 + i * 4 + k] * T[b * 16 + k * 4 + j];
-        cam->P[(t - 9)] = acc;
-    }
+__device__ __forceinline__ float lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
 }
+__device__ __forceinline__ float hsum3(float v) { return (lane_prev(v) + v) + lane_next(v); }
 
-// F.interpolate(disp,[H,W],mode="bilinear",align_corners=False) at one output pixel (MD2/trainer.py:481-482)
-__device__ __forceinline__ float disp_at(const float* __restrict__ d, int Hs, int Ws, float rh, float rw, bool same,
-                                         int y, int x) {
-    if (same) return d[y * Ws + x];
-    const float sy = fmaxf(rh * ((float)y + 0.5f) - 0.5f, 0.f);
-    const float sx = fmaxf(rw * ((float)x + 0.5f) - 0.5f, 0.f);
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    const float v00 = d[y0 * Ws + x0], v01 = d[y0 * Ws + x1], v10 = d[y1 * Ws + x0], v11 = d[y1 * Ws + x1];
-    return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+__device__ __forceinline__ float uni(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-struct Proj {
-    float ix, iy;        // un-clipped sample coordinates in pixels (grid_sample, align_corners=True)
-    float px, py, den;   // projected pixel, Z + eps
-    float ax, ay, az;    // d(X,Y,Z)/d depth
-    float depth;
-};
-
-// disp_to_depth -> BackprojectDepth -> Project3D -> grid normalise/un-normalise, op order of the reference.
-// FAST (the fused loss kernels): reciprocals by rcp + one Newton step instead of IEEE divides, and the sampling
-// coordinate is the projected pixel itself instead of the reference's x/(W-1) -> (.-0.5)*2 -> ((.+1)/2)*(W-1)
-// round trip (an identity up to ~1.5 ulp of the coordinate, 6e-5 px at x~500, which both sides carry anyway).
-template <bool FAST>
-__device__ __forceinline__ Proj project(const Cam& c, float disp, int x, int y, int H, int W, float min_disp,
-                                        float dmul) {
-    Proj p;
-    const float sd = min_disp + dmul * disp;
-    p.depth = FAST ? fast_rcp(sd) : 1.0f / sd;
-    const float fx = (float)x, fy = (float)y;
-    if (FAST) {
-        p.ax = c.A[0] * fx + c.A[1] * fy + c.A[2];
-        p.ay = c.A[3] * fx + c.A[4] * fy + c.A[5];
-        p.az = c.A[6] * fx + c.A[7] * fy + c.A[8];
-        p.den = (p.depth * p.az + c.P[11]) + 1e-7f;
-        const float rden = fast_rcp(p.den);
-        p.px = (p.depth * p.ax + c.P[3]) * rden;
-        p.py = (p.depth * p.ay + c.P[7]) * rden;
-        p.ix = p.px;
-        p.iy = p.py;
-        return p;
-    }
-    const float rx = c.ik[0] * fx + c.ik[1] * fy + c.ik[2];
-    const float ry = c.ik[3] * fx + c.ik[4] * fy + c.ik[5];
-    const float rz = c.ik[6] * fx + c.ik[7] * fy + c.ik[8];
-    const float cx = p.depth * rx, cy = p.depth * ry, cz = p.depth * rz;
-    const float X = c.P[0] * cx + c.P[1] * cy + c.P[2] * cz + c.P[3];
-    const float Y = c.P[4] * cx + c.P[5] * cy + c.P[6] * cz + c.P[7];
-    const float Z = c.P[8] * cx + c.P[9] * cy + c.P[10] * cz + c.P[11];
-    p.ax = c.P[0] * rx + c.P[1] * ry + c.P[2] * rz;
-    p.ay = c.P[4] * rx + c.P[5] * ry + c.P[6] * rz;
-    p.az = c.P[8] * rx + c.P[9] * ry + c.P[10] * rz;
-    p.den = Z + 1e-7f;
-    p.px = X / p.den;
-    p.py = Y / p.den;
-    const float gx = (p.px / (float)(W - 1) - 0.5f) * 2.f;  // MD2/layers.py:195-197
-    const float gy = (p.py / (float)(H - 1) - 0.5f) * 2.f;
-    p.ix = ((gx + 1.f) / 2.f) * (float)(W - 1);             // grid_sampler_unnormalize, align_corners=True
-    p.iy = ((gy + 1.f) / 2.f) * (float)(H - 1);
-    return p;
-}
-
-struct Tap {
-    unsigned o00, o01, o10, o11;  // unsigned 32-bit offsets: scalar base + 32-bit VGPR offset addressing
-    float w00, w01, w10, w11, fx, fy;
-};
-
-__device__ __forceinline__ Tap make_tap(float ix, float iy, int H, int W) {
-    // padding_mode="border": clip_coordinates, then bilinear corner weights as grid_sampler does
-    ix = fminf(fmaxf(ix, 0.f), (float)(W - 1));
-    iy = fminf(fmaxf(iy, 0.f), (float)(H - 1));
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const int x0 = (int)x0f, y0 = (int)y0f;
-    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
-    Tap t;
-    t.fx = ix - x0f;
-    t.fy = iy - y0f;
-    const float gx = (x0f + 1.f) - ix, gy = (y0f + 1.f) - iy;
-    t.w00 = gx * gy;
-    t.w01 = t.fx * gy;
-    t.w10 = gx * t.fy;
-    t.w11 = t.fx * t.fy;
-    t.o00 = (unsigned)(y0 * W + x0);
-    t.o01 = (unsigned)(y0 * W + x1);
-    t.o10 = (unsigned)(y1 * W + x0);
-    t.o11 = (unsigned)(y1 * W + x1);
-    return t;
-}
-
-// Gather through a buffer resource: one 128-bit descriptor in SGPRs per source image, 32-bit byte offsets in
-// VGPRs and the colour-plane offset in an SGPR -- no 64-bit address arithmetic per load (guide T8).
+// ---------------------------------------------------------------------------------------------- buffer loads
+// One 128-bit descriptor in SGPRs per image, 32-bit byte offsets in VGPRs, the colour-plane offset in an SGPR:
+// no 64-bit address arithmetic per load, and out-of-range offsets read 0 instead of faulting.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
-__device__ __forceinline__ rsrc_t make_rsrc(const float* p, unsigned bytes) {
-    // the pointer is the same in every lane (derived from blockIdx); tell the compiler so
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     const unsigned long long v = (unsigned long long)p;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
-
-__device__ __forceinline__ float tap_sample_buf(rsrc_t rs, unsigned plane_bytes, const Tap& t) {
-#ifdef DMH_ABLATE_GATHER
-    return (float)t.o00 * t.w00 + (float)t.o01 * t.w01 + (float)t.o10 * t.w10 + (float)t.o11 * t.w11;
-#else
-    const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o00 * 4u, plane_bytes, 0));
-    const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o01 * 4u, plane_bytes, 0));
-    const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o10 * 4u, plane_bytes, 0));
-    const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o11 * 4u, plane_bytes, 0));
-    return v00 * t.w00 + v01 * t.w01 + v10 * t.w10 + v11 * t.w11;
-#endif
+__device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned plane_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, plane_off, 0));
 }
 
-__device__ __forceinline__ float ld_buf(rsrc_t rs, unsigned elem) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, elem * 4u, 0, 0));
-}
-
-// disp_at through a buffer resource (same arithmetic)
-__device__ __forceinline__ float disp_at_buf(rsrc_t rd, int Hs, int Ws, float rh, float rw, bool same, int y, int x) {
-    if (same) return ld_buf(rd, (unsigned)(y * Ws + x));
-    const float sy = fmaxf(rh * ((float)y + 0.5f) - 0.5f, 0.f);
-    const float sx = fmaxf(rw * ((float)x + 0.5f) - 0.5f, 0.f);
-    const int y0 = (int)sy, x0 = (int)sx;
-    const int y1 = y0 + (y0 < Hs - 1 ? 1 : 0), x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-    const float ly = sy - (float)y0, lx = sx - (float)x0;
-    const float hy = 1.f - ly, hx = 1.f - lx;
-    const float v00 = ld_buf(rd, (unsigned)(y0 * Ws + x0)), v01 = ld_buf(rd, (unsigned)(y0 * Ws + x1));
-    const float v10 = ld_buf(rd, (unsigned)(y1 * Ws + x0)), v11 = ld_buf(rd, (unsigned)(y1 * Ws + x1));
-    return hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-}
-
-__device__ __forceinline__ float tap_sample(const float* __restrict__ img, const Tap& t) {
-#ifdef DMH_ABLATE_GATHER  // timing-only build: no gather loads (results are wrong)
-    return (float)t.o00 * t.w00 + (float)t.o01 * t.w01 + (float)t.o10 * t.w10 + (float)t.o11 * t.w11;
-#else
-    return img[t.o00] * t.w00 + img[t.o01] * t.w01 + img[t.o10] * t.w10 + img[t.o11] * t.w11;
-#endif
-}
-
-// SSIM window statistics with every factor scaled by 81 (mu = s/9): SSIM_n/SSIM_d is unchanged,
-// the five divisions by 9 disappear and one division is left (MD2/layers.py:243-253).
-struct SsimTerms {
-    float A1, A2, B1, B2;  // 81*(2 mu_x mu_y + C1), 81*(2 sigma_xy + C2), 81*(mu_x^2+mu_y^2+C1), 81*(sigma_x+sigma_y+C2)
+// ---------------------------------------------------------------------------------------------- projection
+struct CamW {  // wave-uniform constants of one (image, frame): D = A - I, translation column, m = P23 + eps
+    float d00, d01, d02, d10, d11, d12, d20, d21, d22, p03, p13, m;
 };
 
-__device__ __forceinline__ SsimTerms ssim_terms(float sx, float sy, float sxx, float syy, float sxy) {
-    const float sxsy = sx * sy, sx2 = sx * sx, sy2 = sy * sy;
-    SsimTerms t;
-    t.A1 = 2.f * sxsy + 81.f * C1;
-    t.A2 = 2.f * (9.f * sxy - sxsy) + 81.f * C2;
-    t.B1 = sx2 + sy2 + 81.f * C1;
-    t.B2 = (9.f * (sxx + syy) - sx2 - sy2) + 81.f * C2;
+__device__ __forceinline__ CamW load_cam_w(const float* __restrict__ K, const float* __restrict__ invK,
+                                           const float* __restrict__ T, int b) {
+    const float* k = K + (size_t)b * 16;
+    const float* ik = invK + (size_t)b * 16;
+    const float* t = T + (size_t)b * 16;
+    double P[3][4], A[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += (double)k[i * 4 + q] * (double)t[q * 4 + j];   // (K @ T)[:3,:]  layers.py:188
+            P[i][j] = acc;
+        }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            double acc = 0.0;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) acc += P[i][q] * (double)ik[q * 4 + j];                 // inv_K[:3,:3]  layers.py:164
+            A[i][j] = acc;
+        }
+    CamW c;
+    c.d00 = uni((float)(A[0][0] - 1.0));
+    c.d01 = uni((float)A[0][1]);
+    c.d02 = uni((float)A[0][2]);
+    c.d10 = uni((float)A[1][0]);
+    c.d11 = uni((float)(A[1][1] - 1.0));
+    c.d12 = uni((float)A[1][2]);
+    c.d20 = uni((float)A[2][0]);
+    c.d21 = uni((float)A[2][1]);
+    c.d22 = uni((float)(A[2][2] - 1.0));
+    c.p03 = uni((float)P[0][3]);
+    c.p13 = uni((float)P[1][3]);
+    c.m = uni((float)(P[2][3] + 1e-7));                                                       // layers.py:191 eps
+    return c;
+}
+
+struct LaneProj { float fx, qx, cx0, cy0, nx; };    // column-dependent part (constant down the strip)
+struct RowProj { float az, ex, ey, ny; };           // completed for one row
+
+__device__ __forceinline__ LaneProj lane_proj(const CamW& c, int xr) {
+    LaneProj p;
+    p.fx = (float)xr;
+    p.qx = fmaf(c.d20, p.fx, c.d22);
+    p.cx0 = fmaf(c.d00, p.fx, c.d02);
+    p.cy0 = fmaf(c.d10, p.fx, c.d12);
+    p.nx = fmaf(-p.fx, c.m, c.p03);
+    return p;
+}
+__device__ __forceinline__ RowProj row_proj(const CamW& c, const LaneProj& p, int yr) {
+    RowProj r;
+    const float fy = (float)yr;
+    const float q = fmaf(c.d21, fy, p.qx);
+    r.az = 1.f + q;
+    r.ex = fmaf(-p.fx, q, fmaf(c.d01, fy, p.cx0));
+    r.ey = fmaf(-fy, q, fmaf(c.d11, fy, p.cy0));
+    r.ny = fmaf(-fy, c.m, c.p13);
+    return r;
+}
+
+// sample coordinate p + d along one axis of n texels: border clamp of grid_sample(padding_mode="border",
+// align_corners=True) and clip_coordinates_set_grad (gradient only strictly inside (0, n-1)).
+__device__ __forceinline__ void split_coord(float d, int p, int n, int& p0, int& p1, float& t, bool& grad_ok) {
+    d = fminf(fmaxf(d, -(float)(p + 2)), (float)(n - p + 1));   // keeps the int conversion in range; beyond: clamped anyway
+    const float fl = floorf(d);
+    p0 = p + (int)fl;
+    t = d - fl;
+    grad_ok = true;
+    if (p0 < 0) {
+        p0 = 0;
+        t = 0.f;
+        grad_ok = false;
+    } else if (p0 >= n - 1) {
+        p0 = n - 1;
+        t = 0.f;
+        grad_ok = false;
+    }
+    if (p0 == 0 && t == 0.f) grad_ok = false;
+    p1 = min(p0 + 1, n - 1);
+}
+
+struct Tap {
+    unsigned o00, o01, o10, o11;   // byte offsets inside one colour plane
+    float tx, ty;
+    bool gx_ok, gy_ok;
+};
+
+__device__ __forceinline__ Tap make_tap(float dx, float dy, int x, int y, int W, int H) {
+    Tap t;
+    int x0, x1, y0, y1;
+    split_coord(dx, x, W, x0, x1, t.tx, t.gx_ok);
+    split_coord(dy, y, H, y0, y1, t.ty, t.gy_ok);
+    t.o00 = (unsigned)(y0 * W + x0) * 4u;
+    t.o01 = (unsigned)(y0 * W + x1) * 4u;
+    t.o10 = (unsigned)(y1 * W + x0) * 4u;
+    t.o11 = (unsigned)(y1 * W + x1) * 4u;
     return t;
 }
 
-__device__ __forceinline__ float ssim_val(float sx, float sy, float sxx, float syy, float sxy) {
-    const SsimTerms t = ssim_terms(sx, sy, sxx, syy, sxy);
-    const float r = (t.A1 * t.A2) * __builtin_amdgcn_rcpf(t.B1 * t.B2);  // 1-ulp reciprocal: << the SSIM conditioning noise
-    return fminf(fmaxf((1.f - r) * 0.5f, 0.f), 1.f);
-}
+// ---------------------------------------------------------------------------------------------- disparity rows
+// F.interpolate(disp, [H,W], mode="bilinear", align_corners=False) (MD2/trainer.py:481-482) along a strip: the
+// x geometry is a per-lane constant, the two source rows are cached (x-interpolated) until the row pair changes.
+struct DispGeo {
+    int Hs, Ws, f;        // f = H / Hs (exact power of two, checked on the host); 1 = same size
+    float rh;
+    int x0, x1;           // per lane
+    float lx;
+};
+struct DispRow { float dA, dB; int y0; };
 
-// compute_reprojection_loss (MD2/trainer.py:525-537) for the thread's 4 vertically adjacent pixels.
-// sp/st: LDS planes [3][rows][LD] of pred and target; (row0,col0) = LDS coords of the first window's corner.
-template <int LD, int PLANE>
-__device__ __forceinline__ void reproj4(const float* sp, const float* st, int row0, int col0, bool no_ssim,
-                                        float out[PXT]) {
-    float ss[PXT] = {0.f, 0.f, 0.f, 0.f}, l1[PXT] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float* P = sp + c * PLANE + row0 * LD + col0;
-        const float* Q = st + c * PLANE + row0 * LD + col0;
-        float hx[PXT + 2], hy[PXT + 2], hxx[PXT + 2], hyy[PXT + 2], hxy[PXT + 2];
-#pragma unroll
-        for (int r = 0; r < PXT + 2; ++r) {
-            const float x0 = P[r * LD], x1 = P[r * LD + 1], x2 = P[r * LD + 2];
-            const float y0 = Q[r * LD], y1 = Q[r * LD + 1], y2 = Q[r * LD + 2];
-            hx[r] = x0 + x1 + x2;
-            hy[r] = y0 + y1 + y2;
-            hxx[r] = x0 * x0 + x1 * x1 + x2 * x2;
-            hyy[r] = y0 * y0 + y1 * y1 + y2 * y2;
-            hxy[r] = x0 * y0 + x1 * y1 + x2 * y2;
-            if (r >= 1 && r <= PXT) l1[r - 1] += fabsf(y1 - x1);
-        }
-        if (!no_ssim) {
-#pragma unroll
-            for (int k = 0; k < PXT; ++k)
-                ss[k] += ssim_val(hx[k] + hx[k + 1] + hx[k + 2], hy[k] + hy[k + 1] + hy[k + 2],
-                                  hxx[k] + hxx[k + 1] + hxx[k + 2], hyy[k] + hyy[k + 1] + hyy[k + 2],
-                                  hxy[k] + hxy[k + 1] + hxy[k + 2]);
-        }
+__device__ __forceinline__ DispGeo disp_geo(int Hs, int Ws, int H, int W, int xr) {
+    DispGeo g;
+    g.Hs = Hs;
+    g.Ws = Ws;
+    g.f = H / Hs;
+    g.rh = (float)Hs / (float)H;
+    const float rw = (float)Ws / (float)W;
+    const float sx = fmaxf(rw * ((float)xr + 0.5f) - 0.5f, 0.f);
+    g.x0 = (int)sx;
+    g.x1 = g.x0 + (g.x0 < Ws - 1 ? 1 : 0);
+    g.lx = sx - (float)g.x0;
+    if (g.f == 1) {
+        g.x0 = g.x1 = xr;
+        g.lx = 0.f;
     }
-#pragma unroll
-    for (int k = 0; k < PXT; ++k)
-        out[k] = no_ssim ? l1[k] * (1.f / 3.f) : (0.85f / 3.f) * ss[k] + (0.15f / 3.f) * l1[k];
+    return g;
 }
 
-// Copy an image tile with halo HALO into LDS planes [3][HH][LD]; out-of-image slots use the
-// ReflectionPad2d(1) index map (MD2/layers.py:234,240-241).
-template <int HALO, int HW_, int HH_, int LD, int PLANE>
-__device__ __forceinline__ void load_tile(float* s, const float* __restrict__ img, int H, int W, int x0, int y0) {
-    for (int i = threadIdx.x; i < 3 * HH_ * HW_; i += NT) {
-        const int c = i / (HH_ * HW_);
-        const int rem = i - c * (HH_ * HW_);
-        const int r = rem / HW_, col = rem - r * HW_;
-        const int gy = reflect_idx(y0 - HALO + r, H), gx = reflect_idx(x0 - HALO + col, W);
-        s[c * PLANE + r * LD + col] = img[(c * H + gy) * W + gx];
+struct RowLerp { int y0, y1; float ly; };
+__device__ __forceinline__ RowLerp row_lerp(const DispGeo& g, int yr) {
+    RowLerp r;
+    const float sy = fmaxf(g.rh * ((float)yr + 0.5f) - 0.5f, 0.f);
+    r.y0 = uni((int)sy);
+    r.y1 = r.y0 + (r.y0 < g.Hs - 1 ? 1 : 0);
+    r.ly = sy - (float)r.y0;
+    return r;
+}
+
+__device__ __forceinline__ float disp_value(rsrc_t rd, const DispGeo& g, DispRow& c, int yr) {
+    if (g.f == 1) return ldb(rd, (unsigned)(yr * g.Ws + g.x0) * 4u, 0u);
+    const RowLerp r = row_lerp(g, yr);
+    if (r.y0 != c.y0) {
+        c.y0 = r.y0;
+        const float v00 = ldb(rd, (unsigned)(r.y0 * g.Ws + g.x0) * 4u, 0u), v01 = ldb(rd, (unsigned)(r.y0 * g.Ws + g.x1) * 4u, 0u);
+        const float v10 = ldb(rd, (unsigned)(r.y1 * g.Ws + g.x0) * 4u, 0u), v11 = ldb(rd, (unsigned)(r.y1 * g.Ws + g.x1) * 4u, 0u);
+        const float hx = 1.f - g.lx;
+        c.dA = hx * v00 + g.lx * v01;
+        c.dB = hx * v10 + g.lx * v11;
     }
+    return (1.f - r.ly) * c.dA + r.ly * c.dB;
 }
 
-// Warp the source view into an LDS tile with halo HALO (the (scale, frame) body of generate_images_pred).
-template <int HALO, int HW_, int HH_, int LD, int PLANE>
-__device__ __forceinline__ void warp_tile(float* s, const float* __restrict__ src, const float* __restrict__ disp,
-                                          const Cam& cam, int H, int W, int Hs, int Ws, int x0, int y0, float min_disp,
-                                          float dmul) {
-    const bool same = (Hs == H && Ws == W);
-    const float rh = (float)Hs / (float)H, rw = (float)Ws / (float)W;
-    const unsigned plane = (unsigned)(H * W) * 4u;
-    const rsrc_t rs = make_rsrc(src, 3u * plane);
-    const rsrc_t rd = make_rsrc(disp, (unsigned)(Hs * Ws) * 4u);
-    for (int i = threadIdx.x; i < HH_ * HW_; i += NT) {
-        const int r = i / HW_, col = i - r * HW_;
-        const int gy = reflect_idx(y0 - HALO + r, H), gx = reflect_idx(x0 - HALO + col, W);
-        const float d = disp_at_buf(rd, Hs, Ws, rh, rw, same, gy, gx);
-        const Proj p = project<true>(cam, d, gx, gy, H, W, min_disp, dmul);
-        const Tap t = make_tap(p.ix, p.iy, H, W);
-        s[0 * PLANE + r * LD + col] = tap_sample_buf(rs, 0u, t);
-        s[1 * PLANE + r * LD + col] = tap_sample_buf(rs, plane, t);
-        s[2 * PLANE + r * LD + col] = tap_sample_buf(rs, 2u * plane, t);
-    }
+// ---------------------------------------------------------------------------------------------- SSIM
+// Window statistics with every factor scaled by 81 (mu = S/9) and sums taken of (value - SHIFT):
+//   n = (2 mu_x mu_y + C1)(2 sigma_xy + C2),  d = (mu_x^2 + mu_y^2 + C1)(sigma_x + sigma_y + C2)   MD2/layers.py:243-253
+struct TgtWin { float sy, my, b1y, b2y; };   // target-side terms of one channel, shared by every stream
+
+__device__ __forceinline__ TgtWin tgt_win(float Sy, float Syy) {
+    TgtWin t;
+    t.sy = Sy;
+    t.my = K9S + Sy;
+    t.b1y = fmaf(t.my, t.my, K81C1);
+    t.b2y = fmaf(-Sy, Sy, fmaf(9.f, Syy, K81C2));
+    return t;
 }
 
-__device__ __forceinline__ void decode_block(const KArgs& k, int& tx0, int& ty0, int& b, int& blk) {
-    // XCD-aware mapping: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
-    // contiguous run of tiles (neighbouring tiles share halo rows and gather lines in that XCD's L2).
-    int id = blockIdx.x;
-    const int n = k.nblk;
-    if ((n & 7) == 0) id = (id & 7) * (n >> 3) + (id >> 3);
-    blk = id;
-    const int per_img = k.tiles_x * k.tiles_y;
-    b = id / per_img;
-    const int t = id - b * per_img;
-    ty0 = (t / k.tiles_x) * TH;
-    tx0 = (t - (t / k.tiles_x) * k.tiles_x) * TW;
+struct SsimTerms { float A1, A2, B1, B2, mx; };
+__device__ __forceinline__ SsimTerms ssim_terms(float Sx, float Sxx, float Sxy, const TgtWin& t) {
+    SsimTerms s;
+    s.mx = K9S + Sx;
+    s.A1 = fmaf(s.mx + s.mx, t.my, K81C1);
+    s.A2 = fmaf(2.f, fmaf(9.f, Sxy, -Sx * t.sy), K81C2);
+    s.B1 = fmaf(s.mx, s.mx, t.b1y);
+    s.B2 = fmaf(-Sx, Sx, fmaf(9.f, Sxx, t.b2y));
+    return s;
 }
+__device__ __forceinline__ float ssim_val(float Sx, float Sxx, float Sxy, const TgtWin& t) {
+    const SsimTerms s = ssim_terms(Sx, Sxx, Sxy, t);
+    const float r = (s.A1 * s.A2) * __builtin_amdgcn_rcpf(s.B1 * s.B2);   // 1-ulp reciprocal: << the SSIM conditioning noise
+    return fminf(fmaxf(fmaf(-0.5f, r, 0.5f), 0.f), 1.f);
+}
+
+// ---------------------------------------------------------------------------------------------- launch geometry
+struct KArgs {
+    dmh_photo_args a;
+    uint8_t* sel;
+    const uint8_t* csel;
+    float* to_opt[DMH_MAX_SCALES];
+    float* partials;
+    const float* gvec;
+    const float* fin;
+    float* g_disp[DMH_MAX_SCALES];
+    float* stage[DMH_MAX_SCALES];              // per-strip partial low-resolution gradients of the coarse scales
+    int sy_slots[DMH_MAX_SCALES], sx_slots[DMH_MAX_SCALES];
+    int tiles_x, tiles_y, ntiles, R;
+    float min_disp, dmul;                      // scaled_disp = min_disp + dmul * disp   MD2/layers.py:21-23
+};
+
+// Rows per strip: tall strips amortise the halo rows, but the launch should still be several waves per SIMD deep.
+__host__ inline int pick_rows(int B, int H, int W, int out_cols) {
+    const int tx = (W + out_cols - 1) / out_cols;
+    int R = 32;
+    while (R > 8 && (int64_t)B * tx * ((H + R - 1) / R) < 4096) R >>= 1;
+    return R;
+}
+
+// XCD-aware order: consecutive workgroup ids round-robin over the 8 XCDs, so hand each XCD a contiguous run of
+// strips (horizontally adjacent strips share their halo columns and gather lines in that XCD's L2).
+__device__ __forceinline__ int wave_item() {
+    int bid = blockIdx.x;
+    const int nb = gridDim.x;
+    if ((nb & 7) == 0) bid = (bid & 7) * (nb >> 3) + (bid >> 3);
+    return uni(bid * WPB + (int)(threadIdx.x >> 6));
+}
+
+template <int NSTR>
+struct FRow {   // row sums of one image row: target (y, y^2) and per stream (x, x^2, x y), three channels each
+    float ty[3], tyy[3], sx[NSTR][3], sxx[NSTR][3], sxy[NSTR][3];
+};
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int NF>
-__global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArgs k) {
-    __shared__ float s_tgt[3 * F_PLANE];
-    __shared__ float s_buf[3 * F_PLANE];
-    __shared__ Cam s_cam[DMH_MAX_FRAMES];
-    __shared__ float s_red[NT / WAVE];
-
+// NF source frames, SPP scales per pass (NF * (1 + SPP) streams of rolling row sums live in registers).
+template <int NF, int SPP>
+__global__ __launch_bounds__(NT) void photo_fwd_kernel(const KArgs k) {
+    constexpr int NSTR = NF * (1 + SPP);
     const dmh_photo_args& a = k.a;
-    const int H = a.H, W = a.W;
-    constexpr int F = NF;
-    int x0, y0, b, blk;
-    decode_block(k, x0, y0, b, blk);
-    const int tid = threadIdx.x, tx = tid & (TW - 1), tg = tid / TW;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int tile = wave_item();
+    if (tile >= k.ntiles) return;
+    const int H = a.H, W = a.W, NS = a.num_scales;
+    const int per_img = k.tiles_x * k.tiles_y;
+    const int b = tile / per_img, tt = tile - b * per_img, ty = tt / k.tiles_x, tx = tt - ty * k.tiles_x;
+    const int X0 = tx * FW_OUT, Y0 = ty * k.R;
+    const int col = X0 - 1 + lane;
+    const int xr = reflect_idx(col, W);
+    const bool out_lane = lane >= 1 && lane <= FW_OUT && col < W;
+    const int nrows = min(k.R, H - Y0) + 2;
+
+    const unsigned plane = (unsigned)(H * W) * 4u;
     const size_t img_off = (size_t)b * 3 * H * W;
-
-    if (tid < 21 * F) load_cam(&s_cam[tid / 21], a.K, a.inv_K, a.T[tid / 21], b, tid % 21);
-    load_tile<1, F_HW, F_HH, F_LD, F_PLANE>(s_tgt, a.target + img_off, H, W, x0, y0);
-    __syncthreads();
-    if (tid < 9 * F) compose_cam(&s_cam[tid / 9], tid % 9);
-
-    const int qx = x0 + tx;
-    const int qy0 = y0 + tg * PXT;
-    bool valid[PXT];
+    const rsrc_t rt = make_rsrc(a.target + img_off, 3u * plane);
+    rsrc_t rsrc[NF];
+    CamW cam[NF];
+    LaneProj lp[NF];
 #pragma unroll
-    for (int i = 0; i < PXT; ++i) valid[i] = (qx < W) && (qy0 + i < H);
-
-    // identity terms (same for every scale; the reference recomputes them 4x, MD2/trainer.py:608-621)
-    float ident[NF][PXT];
-    if (a.automask) {
-#pragma unroll
-        for (int f = 0; f < F; ++f) {
-            __syncthreads();
-            load_tile<1, F_HW, F_HH, F_LD, F_PLANE>(s_buf, a.source[f] + img_off, H, W, x0, y0);
-            __syncthreads();
-            reproj4<F_LD, F_PLANE>(s_buf, s_tgt, tg * PXT, tx, a.no_ssim != 0, ident[f]);
-        }
+    for (int f = 0; f < NF; ++f) {
+        rsrc[f] = make_rsrc(a.source[f] + img_off, 3u * plane);
+        cam[f] = load_cam_w(a.K, a.inv_K, a.T[f], b);
+        lp[f] = lane_proj(cam[f], xr);
     }
-
+    const bool automask = a.automask != 0, no_ssim = a.no_ssim != 0, md2 = a.variant == DMH_VARIANT_MD2;
+    const int nf_noise = md2 ? NF : 1;
+    const int npass = (NS + SPP - 1) / SPP;
     const Philox<7> rng(a.seed);
-    float acc1[DMH_MAX_SCALES], acc2[DMH_MAX_SCALES];
+
+    for (int s0 = 0, pass = 0; s0 < NS; s0 += SPP, ++pass) {
+        DispGeo dg[SPP];
+        DispRow dr[SPP];
+        rsrc_t rd[SPP];
 #pragma unroll
-    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
-        if (s >= a.num_scales) break;
-        float best[PXT];
-        int bestf[PXT];
-#pragma unroll
-        for (int i = 0; i < PXT; ++i) {
-            best[i] = 3.0e38f;
-            bestf[i] = 0;
+        for (int j = 0; j < SPP; ++j) {
+            const int s = min(s0 + j, NS - 1);
+            dg[j] = disp_geo(a.Hs[s], a.Ws[s], H, W, xr);
+            dr[j].y0 = -1;
+            dr[j].dA = dr[j].dB = 0.f;
+            rd[j] = make_rsrc(a.disp[s] + (size_t)b * a.Hs[s] * a.Ws[s], (unsigned)(a.Hs[s] * a.Ws[s]) * 4u);
         }
-        const float* disp = a.disp[s] + (size_t)b * a.Hs[s] * a.Ws[s];
+        FRow<NSTR> rowA, rowB;
+        float l1p[NSTR];       // L1 of the previous row (the centre row of the next window)
+        float acc1[SPP], acc2[SPP];
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
-            __syncthreads();
-            warp_tile<1, F_HW, F_HH, F_LD, F_PLANE>(s_buf, a.source[f] + img_off, disp, s_cam[f], H, W, a.Hs[s],
-                                                    a.Ws[s], x0, y0, k.min_disp, k.dmul);
-            __syncthreads();
-            float v[PXT];
-            reproj4<F_LD, F_PLANE>(s_buf, s_tgt, tg * PXT, tx, a.no_ssim != 0, v);
+        for (int j = 0; j < SPP; ++j) acc1[j] = acc2[j] = 0.f;
 #pragma unroll
-            for (int i = 0; i < PXT; ++i)
-                if (v[i] < best[i]) {
-                    best[i] = v[i];
-                    bestf[i] = f;
+        for (int i = 0; i < NSTR; ++i) l1p[i] = 0.f;
+
+        // One image row: `older` / `newer` are the row sums of the two rows above; the finished centre row is
+        // the one in between; the current row's sums replace `older`.
+        auto step = [&](const int kk, FRow<NSTR>& older, const FRow<NSTR>& newer) __attribute__((always_inline)) {
+            const int r = Y0 - 1 + kk;
+            const int yr = reflect_idx(r, H);
+            const unsigned rowoff = (unsigned)(yr * W + xr) * 4u;
+            const bool emit = kk >= 2;
+            const int qy = r - 1;
+            float tv[3];
+            TgtWin tw[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                tv[c] = ldb(rt, rowoff, plane * (unsigned)c) - SHIFT;
+                const float hy = hsum3(tv[c]), hyy = hsum3(tv[c] * tv[c]);
+                tw[c] = tgt_win(older.ty[c] + newer.ty[c] + hy, older.tyy[c] + newer.tyy[c] + hyy);
+                older.ty[c] = hy;
+                older.tyy[c] = hyy;
+            }
+            float val[NSTR];
+            // accumulate one stream: xv = this row's (shifted) values of the stream
+            auto stream = [&](const int st, const float (&xv)[3]) __attribute__((always_inline)) {
+                float ss = 0.f, l1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float hx = hsum3(xv[c]), hxx = hsum3(xv[c] * xv[c]), hxy = hsum3(xv[c] * tv[c]);
+                    if (emit && !no_ssim)
+                        ss += ssim_val(older.sx[st][c] + newer.sx[st][c] + hx, older.sxx[st][c] + newer.sxx[st][c] + hxx,
+                                       older.sxy[st][c] + newer.sxy[st][c] + hxy, tw[c]);
+                    older.sx[st][c] = hx;
+                    older.sxx[st][c] = hxx;
+                    older.sxy[st][c] = hxy;
+                    l1 += fabsf(tv[c] - xv[c]);
                 }
-        }
-        float s1 = 0.f, s2 = 0.f;
+                // compute_reprojection_loss (MD2/trainer.py:525-537) of the centre row: its L1 was formed one row ago
+                val[st] = no_ssim ? l1p[st] * (1.f / 3.f) : (0.85f / 3.f) * ss + (0.15f / 3.f) * l1p[st];
+                l1p[st] = l1;
+            };
+            if (automask) {
 #pragma unroll
-        for (int i = 0; i < PXT; ++i) {
-            if (!valid[i]) continue;
-            const int qy = qy0 + i;
-            const size_t pix = ((size_t)b * H + qy) * W + qx;
-            bool chosen = true;
-            float val = best[i];
-            if (a.automask) {
-                float idn = 3.0e38f;
-                const int nf = (a.variant == DMH_VARIANT_MD2) ? F : 1;
+                for (int f = 0; f < NF; ++f) {
+                    float xv[3];
 #pragma unroll
-                for (int f = 0; f < F; ++f) {
-                    float nz = 0.f;
-                    const int fi = (a.variant == DMH_VARIANT_MD2) ? f : 0;
-                    if (a.noise_mode == DMH_NOISE_TENSOR) {
-                        nz = a.noise[s][(((size_t)b * nf + fi) * H + qy) * W + qx];
-                    } else if (a.noise_mode == DMH_NOISE_PHILOX) {
-                        // one Philox call serves the thread's 4 pixels: two Box-Muller pairs (cos, sin) each
-                        const uint64_t ctr = a.offset + ((((uint64_t)s * a.B + b) * nf + fi) * H + qy0) * W + qx;
-                        const uint4 r = rng(ctr, 0x646d68ull);
-                        const float2 n01 = normal_pair_from_bits(r.x, r.y), n23 = normal_pair_from_bits(r.z, r.w);
-                        nz = (i == 0 ? n01.x : i == 1 ? n01.y : i == 2 ? n23.x : n23.y) * 0.00001f;
-                    }
-                    // MD2: noise per identity channel, then min over channels (trainer.py:642-654);
-                    // DH : min over frames first, one noise plane (DH/trainer.py:671,687-690)
-                    const float cand = ident[f][i] + ((a.variant == DMH_VARIANT_MD2) ? nz : 0.f);
-                    idn = fminf(idn, cand);
-                    if (a.variant != DMH_VARIANT_MD2 && f == F - 1) idn += nz;
-                }
-                if (a.variant == DMH_VARIANT_MD2) {
-                    chosen = best[i] < idn;  // torch.min keeps the first (identity) on ties
-                    val = chosen ? best[i] : idn;
-                } else {
-                    chosen = best[i] <= idn;  // argmin over [reprojection, identity]: first wins ties
-                    val = chosen ? best[i] : 0.f;
+                    for (int c = 0; c < 3; ++c) xv[c] = ldb(rsrc[f], rowoff, plane * (unsigned)c) - SHIFT;
+                    stream(f, xv);
                 }
             }
-            k.sel[s][pix] = chosen ? (float)(1 + bestf[i]) : 0.f;
-            if (k.to_opt[s]) k.to_opt[s][pix] = val;
-            s1 += val;
-            s2 += chosen ? 1.f : 0.f;
-        }
-        acc1[s] = s1;
-        acc2[s] = s2;
-    }
-    // one reduction for all scales at the end (keeps the scale loop free of extra barriers)
+            RowProj rp[NF];
 #pragma unroll
-    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
-        if (s >= a.num_scales) break;
-        const float t1 = block_sum<NT>(acc1[s], s_red);
-        const float t2 = block_sum<NT>(acc2[s], s_red);
-        if (tid == 0) {
-            k.partials[((size_t)s * k.nblk + blk) * 2 + 0] = t1;
-            k.partials[((size_t)s * k.nblk + blk) * 2 + 1] = t2;
+            for (int f = 0; f < NF; ++f) rp[f] = row_proj(cam[f], lp[f], yr);
+#pragma unroll
+            for (int j = 0; j < SPP; ++j) {
+                if (s0 + j >= NS) break;
+                const float d = disp_value(rd[j], dg[j], dr[j], yr);
+                const float sd = fmaf(k.dmul, d, k.min_disp);
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const float rden = fast_rcp(fmaf(sd, cam[f].m, rp[f].az));
+                    const float dx = fmaf(sd, lp[f].nx, rp[f].ex) * rden, dy = fmaf(sd, rp[f].ny, rp[f].ey) * rden;
+                    const Tap t = make_tap(dx, dy, xr, yr, W, H);
+                    const float gx = 1.f - t.tx, gy = 1.f - t.ty;
+                    const float w00 = gx * gy, w01 = t.tx * gy, w10 = gx * t.ty, w11 = t.tx * t.ty;
+                    float xv[3];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const unsigned po = plane * (unsigned)c;
+                        xv[c] = (ldb(rsrc[f], t.o00, po) * w00 + ldb(rsrc[f], t.o01, po) * w01 + ldb(rsrc[f], t.o10, po) * w10 +
+                                 ldb(rsrc[f], t.o11, po) * w11) - SHIFT;
+                    }
+                    stream(NF + j * NF + f, xv);
+                }
+            }
+            if (!emit) return;
+            // ---- per-pixel min / argmin for the centre row qy (MD2/trainer.py:640-660, DH/trainer.py:671-708)
+            const size_t pix = ((size_t)b * H + qy) * W + col;
+            float nz[4] = {0.f, 0.f, 0.f, 0.f};   // tie-break noise: slot j * NF + f of this pass
+            if (automask && a.noise_mode == DMH_NOISE_PHILOX) {
+                const uint4 rr = rng(a.offset + (uint64_t)pix * (uint64_t)npass + (uint64_t)pass, 0x646d68ull);
+                const float2 n01 = normal_pair_from_bits(rr.x, rr.y), n23 = normal_pair_from_bits(rr.z, rr.w);
+                nz[0] = n01.x * 0.00001f;
+                nz[1] = n01.y * 0.00001f;
+                nz[2] = n23.x * 0.00001f;
+                nz[3] = n23.y * 0.00001f;
+            }
+            unsigned bits = 0u;
+#pragma unroll
+            for (int j = 0; j < SPP; ++j) {
+                if (s0 + j >= NS) break;
+                const int s = s0 + j;
+                float best = 3.0e38f;
+                int bestf = 0;
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+                    const float v = val[NF + j * NF + f];
+                    if (v < best) {
+                        best = v;
+                        bestf = f;
+                    }
+                }
+                bool chosen = true;
+                float v = best;
+                if (automask) {
+                    float idn = 3.0e38f;
+#pragma unroll
+                    for (int f = 0; f < NF; ++f) {
+                        float z = 0.f;
+                        const int fi = md2 ? f : 0;
+                        if (a.noise_mode == DMH_NOISE_TENSOR) {
+                            if (out_lane) z = a.noise[s][(((size_t)b * nf_noise + fi) * H + qy) * W + col];
+                        } else if (a.noise_mode == DMH_NOISE_PHILOX) {
+                            z = nz[(j * NF + fi) & 3];
+                        }
+                        // MD2: noise per identity channel, then min over channels (trainer.py:642-654);
+                        // DH : min over frames first, one noise plane (DH/trainer.py:671,687-690)
+                        idn = fminf(idn, val[f] + (md2 ? z : 0.f));
+                        if (!md2 && f == NF - 1) idn += z;
+                    }
+                    if (md2) {
+                        chosen = best < idn;   // torch.min keeps the first (identity) on ties
+                        v = chosen ? best : idn;
+                    } else {
+                        chosen = best <= idn;  // argmin over [reprojection, identity]: first wins ties
+                        v = chosen ? best : 0.f;
+                    }
+                }
+                if (out_lane) {
+                    if (k.to_opt[s]) k.to_opt[s][pix] = v;
+                    acc1[j] += v;
+                    acc2[j] += chosen ? 1.f : 0.f;
+                    bits |= (chosen ? (unsigned)(1 + bestf) : 0u) << (2 * s);
+                }
+            }
+            if (out_lane) {
+                if (pass > 0) bits |= k.sel[pix];
+                k.sel[pix] = (uint8_t)bits;
+            }
+        };
+        for (int kk = 0; kk < nrows; kk += 2) {
+            step(kk, rowA, rowB);
+            if (kk + 1 < nrows) step(kk + 1, rowB, rowA);
+        }
+        // fixed-order wave sums -> one partial pair per (scale, strip)
+#pragma unroll
+        for (int j = 0; j < SPP; ++j) {
+            if (s0 + j >= NS) break;
+            const float t1 = wave_sum(acc1[j]), t2 = wave_sum(acc2[j]);
+            if (lane == 0) {
+                k.partials[((size_t)(s0 + j) * k.ntiles + tile) * 2 + 0] = t1;
+                k.partials[((size_t)(s0 + j) * k.ntiles + tile) * 2 + 1] = t2;
+            }
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-// gradient of one warped pixel back to the up-sampled disparity, given d loss / d warped (3 channels)
-template <bool FAST>
-__device__ __forceinline__ float warp_pixel_bwd(const float* __restrict__ src, const Cam& cam, float d, int x, int y,
-                                                int H, int W, float min_disp, float dmul, float g0, float g1,
-                                                float g2) {
-    const Proj p = project<FAST>(cam, d, x, y, H, W, min_disp, dmul);
-    const Tap t = make_tap(p.ix, p.iy, H, W);
-    float gix = 0.f, giy = 0.f;
-    const float gc[3] = {g0, g1, g2};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float* im = src + (size_t)c * H * W;
-        const float v00 = im[t.o00], v01 = im[t.o01], v10 = im[t.o10], v11 = im[t.o11];
-        gix += gc[c] * ((v01 - v00) * (1.f - t.fy) + (v11 - v10) * t.fy);
-        giy += gc[c] * ((v10 - v00) * (1.f - t.fx) + (v11 - v01) * t.fx);
-    }
-    // clip_coordinates_set_grad: zero outside the open interval (0, size-1)
-    if (!(p.ix > 0.f && p.ix < (float)(W - 1))) gix = 0.f;
-    if (!(p.iy > 0.f && p.iy < (float)(H - 1))) giy = 0.f;
-    const float g_depth = (gix * (p.ax - p.px * p.az) + giy * (p.ay - p.py * p.az)) * (FAST ? fast_rcp(p.den) : 1.0f / p.den);
-    return g_depth * (-(p.depth * p.depth)) * dmul;
-}
-
-// fused-kernel version of warp_pixel_bwd: buffer-resource gathers, fast projection
-__device__ __forceinline__ float warp_pixel_bwd_buf(rsrc_t rs, unsigned plane, const Cam& cam, float d, int x, int y,
-                                                    int H, int W, float min_disp, float dmul, float g0, float g1,
-                                                    float g2) {
-    const Proj p = project<true>(cam, d, x, y, H, W, min_disp, dmul);
-    const Tap t = make_tap(p.ix, p.iy, H, W);
-    float gix = 0.f, giy = 0.f;
-    const float gc[3] = {g0, g1, g2};
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const unsigned po = plane * (unsigned)c;
-        const float v00 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o00 * 4u, po, 0));
-        const float v01 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o01 * 4u, po, 0));
-        const float v10 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o10 * 4u, po, 0));
-        const float v11 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, t.o11 * 4u, po, 0));
-        gix += gc[c] * ((v01 - v00) * (1.f - t.fy) + (v11 - v10) * t.fy);
-        giy += gc[c] * ((v10 - v00) * (1.f - t.fx) + (v11 - v01) * t.fx);
-    }
-    if (!(p.ix > 0.f && p.ix < (float)(W - 1))) gix = 0.f;
-    if (!(p.iy > 0.f && p.iy < (float)(H - 1))) giy = 0.f;
-    const float g_depth = (gix * (p.ax - p.px * p.az) + giy * (p.ay - p.py * p.az)) * fast_rcp(p.den);
-    return g_depth * (-(p.depth * p.depth)) * dmul;
-}
+struct BRow {   // record of one processed row: its row sums, the coefficient row sums of the row above it, and what
+                // the chain two rows later needs of it
+    float hy[3], hyy[3], hx[3], hxx[3], hxy[3];
+    float ch[3][3];          // [channel][a0, ax, ay] horizontal sums (with the reflection fold)
+    float xv[3], yv[3], J[3];
+    unsigned sel;            // selection field of this row for the wave's scale
+};
 
 template <int NF>
-__global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArgs k) {
-    __shared__ float s_tgt[3 * B_PLANE];
-    __shared__ float s_wrp[3 * B_PLANE];
-    __shared__ float s_cf[3 * F_PLANE];  // a0, ax, ay coefficient fields on the halo-1 tile
-    __shared__ Cam s_cam[DMH_MAX_FRAMES];
-
+__global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
+    __shared__ float s_row[WPB][2][WAVE];     // horizontal up-sampling adjoint: g*(1-lx), g*lx of one row
     const dmh_photo_args& a = k.a;
-    const int H = a.H, W = a.W;
-    constexpr int F = NF;
-    int x0, y0, b, blk;
-    decode_block(k, x0, y0, b, blk);
-    const int tid = threadIdx.x, tx = tid & (TW - 1), tg = tid / TW;
+    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
+    const int item = wave_item();
+    if (item >= k.ntiles * a.num_scales) return;
+    const int s = item / k.ntiles, tile = item - s * k.ntiles;
+    const int H = a.H, W = a.W, B = a.B;
+    const int per_img = k.tiles_x * k.tiles_y;
+    const int b = tile / per_img, tt = tile - b * per_img, ty = tt / k.tiles_x, tx = tt - ty * k.tiles_x;
+    const int X0 = tx * BW_OUT, Y0 = ty * k.R;
+    const int col = X0 - 2 + lane;
+    const int xr = reflect_idx(col, W);
+    const bool col_in = col >= 0 && col < W;
+    const bool out_lane = lane >= 2 && lane < 2 + BW_OUT && col < W;
+    const int rows_out = min(k.R, H - Y0);
+    const int nrows = rows_out + 4;
+
+    const unsigned plane = (unsigned)(H * W) * 4u;
     const size_t img_off = (size_t)b * 3 * H * W;
+    const rsrc_t rt = make_rsrc(a.target + img_off, 3u * plane);
+    const rsrc_t rsel = make_rsrc(k.csel + (size_t)b * H * W, (unsigned)(H * W));
+    const bool no_ssim = a.no_ssim != 0;
+    float up = k.gvec[DMH_FIN_LOSS] / (float)a.num_scales + k.gvec[DMH_FIN_LOSS_S + s] + k.gvec[DMH_FIN_REPROJ_S + s];
+    up *= (a.variant == DMH_VARIANT_MD2) ? 1.0f / ((float)B * (float)H * (float)W) : 1.0f / (k.fin[DMH_FIN_COUNT_S + s] + 1e-7f);
+    up = uni(up);
+    const float l1w = up * (no_ssim ? (1.f / 3.f) : (0.15f / 3.f));
+    const float gs0 = up * (0.85f / 3.f);
+    const float mxl = (col == 1) ? 2.f : 1.f, mxr = (col == W - 2) ? 2.f : 1.f;   // reflection-pad adjoint
 
-    if (tid < 21 * F) load_cam(&s_cam[tid / 21], a.K, a.inv_K, a.T[tid / 21], b, tid % 21);
-    load_tile<2, B_HW, B_HH, B_LD, B_PLANE>(s_tgt, a.target + img_off, H, W, x0, y0);
-    __syncthreads();
-    if (tid < 9 * F) compose_cam(&s_cam[tid / 9], tid % 9);
+    const int Hs = a.Hs[s], Ws = a.Ws[s];
+    const DispGeo dg = disp_geo(Hs, Ws, H, W, xr);
+    const rsrc_t rd = make_rsrc(a.disp[s] + (size_t)b * Hs * Ws, (unsigned)(Hs * Ws) * 4u);
+    const bool same = dg.f == 1;
+    // geometry of this strip's block of low-resolution texels (coarse scales)
+    const DispGeo dgc = disp_geo(Hs, Ws, H, W, min(max(col, 0), W - 1));   // un-reflected column for the adjoint weights
+    const int jlo = row_lerp(dg, Y0).y0;
+    const float rw = (float)Ws / (float)W;
+    const int ilo = (int)fmaxf(rw * ((float)X0 + 0.5f) - 0.5f, 0.f);
+    const int SX = k.sx_slots[s], SY = k.sy_slots[s];
+    float* stage = same ? nullptr : k.stage[s] + (size_t)tile * SX * SY;
 
-    const int qx = x0 + tx, qy0 = y0 + tg * PXT;
-    const float mxl = (qx == 1) ? 2.f : 1.f, mxr = (qx == W - 2) ? 2.f : 1.f;  // reflection-pad adjoint
-
+    for (int f = 0; f < NF; ++f) {
+        const rsrc_t rs = make_rsrc(a.source[f] + img_off, 3u * plane);
+        const CamW cam = load_cam_w(a.K, a.inv_K, a.T[f], b);
+        const LaneProj lp = lane_proj(cam, xr);
+        const unsigned fsel = (unsigned)(1 + f);
+        DispRow dr;
+        dr.y0 = -1;
+        dr.dA = dr.dB = 0.f;
+        BRow recA, recB;
 #pragma unroll
-    for (int s = 0; s < DMH_MAX_SCALES; ++s) {
-        if (s >= a.num_scales) break;
-        float up = k.gvec[DMH_FIN_LOSS] / (float)a.num_scales + k.gvec[DMH_FIN_LOSS_S + s] +
-                   k.gvec[DMH_FIN_REPROJ_S + s];
-        up *= (a.variant == DMH_VARIANT_MD2) ? 1.0f / ((float)a.B * (float)H * (float)W)
-                                             : 1.0f / (k.fin[DMH_FIN_COUNT_S + s] + 1e-7f);
-        const float* disp = a.disp[s] + (size_t)b * a.Hs[s] * a.Ws[s];
-        const float* sel = k.csel[s] + (size_t)b * H * W;
-        const bool same = (a.Hs[s] == H && a.Ws[s] == W);
-        const float rh = (float)a.Hs[s] / (float)H, rw = (float)a.Ws[s] / (float)W;
-        float acc[PXT] = {0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) recA.ch[c][q] = recB.ch[c][q] = 0.f;
+        recA.sel = recB.sel = 0u;
+        float accA = 0.f, accB = 0.f;     // vertical up-sampling adjoint: low rows ja and ja + 1
+        int ja = jlo;
 
-        for (int f = 0; f < F; ++f) {
-            const float* src = a.source[f] + img_off;
-            __syncthreads();
-            warp_tile<2, B_HW, B_HH, B_LD, B_PLANE>(s_wrp, src, disp, s_cam[f], H, W, a.Hs[s], a.Ws[s], x0, y0,
-                                                    k.min_disp, k.dmul);
-            __syncthreads();
-            float gw[3][PXT];
-            const float fsel = (float)(1 + f);
+        auto flush = [&](const int j, const float v) __attribute__((always_inline)) {
+            const int slot = j - jlo;
+            if (slot < SY && lane < SX) {
+                float* p = stage + (size_t)slot * SX + lane;
+                *p = (f > 0) ? *p + v : v;
+            }
+        };
+
+        auto step = [&](const int kk, BRow& older, const BRow& newer) __attribute__((always_inline)) {
+            const int r = Y0 - 2 + kk;
+            const int yr = reflect_idx(r, H);
+            const unsigned rowoff = (unsigned)(yr * W + xr) * 4u;
+            BRow cur;
+            // (1) this row: target, warp, chain factors J_c = d warped_c / d disp
+            const float d = disp_value(rd, dg, dr, yr);
+            const float sd = fmaf(k.dmul, d, k.min_disp);
+            const RowProj rp = row_proj(cam, lp, yr);
+            const float rden = fast_rcp(fmaf(sd, cam.m, rp.az));
+            const float dx = fmaf(sd, lp.nx, rp.ex) * rden, dy = fmaf(sd, rp.ny, rp.ey) * rden;
+            const Tap t = make_tap(dx, dy, xr, yr, W, H);
+            const float rd2 = rden * rden * k.dmul;
+            const float jx = t.gx_ok ? fmaf(lp.nx, rp.az, -rp.ex * cam.m) * rd2 : 0.f;   // d ix / d disp
+            const float jy = t.gy_ok ? fmaf(rp.ny, rp.az, -rp.ey * cam.m) * rd2 : 0.f;   // d iy / d disp
+            const float gx = 1.f - t.tx, gy = 1.f - t.ty;
+            const float w00 = gx * gy, w01 = t.tx * gy, w10 = gx * t.ty, w11 = t.tx * t.ty;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                // (1) coefficient fields on the halo-1 tile: d v(px)/d x_q = a0 + ay*y_q + ax*x_q
-                for (int i = tid; i < F_HH * F_HW; i += NT) {
-                    const int r = i / F_HW, col = i - r * F_HW;
-                    const int py = y0 - 1 + r, px = x0 - 1 + col;
+                const unsigned po = plane * (unsigned)c;
+                const float v00 = ldb(rs, t.o00, po), v01 = ldb(rs, t.o01, po), v10 = ldb(rs, t.o10, po), v11 = ldb(rs, t.o11, po);
+                cur.xv[c] = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11) - SHIFT;
+                cur.yv[c] = ldb(rt, rowoff, po) - SHIFT;
+                const float dvx = (v01 - v00) * gy + (v11 - v10) * t.ty, dvy = (v10 - v00) * gx + (v11 - v01) * t.tx;
+                cur.J[c] = dvx * jx + dvy * jy;
+                // (2) row sums
+                cur.hx[c] = hsum3(cur.xv[c]);
+                cur.hxx[c] = hsum3(cur.xv[c] * cur.xv[c]);
+                cur.hxy[c] = hsum3(cur.xv[c] * cur.yv[c]);
+                cur.hy[c] = hsum3(cur.yv[c]);
+                cur.hyy[c] = hsum3(cur.yv[c] * cur.yv[c]);
+            }
+            // (3) coefficient fields of the row above (centre row rc): d v(p) / d x_q = a0 + ay*y_q + ax*x_q for every
+            //     pixel q of p's window, v = clamp((1 - n/d)/2)
+            const int rc = r - 1;
+            cur.sel = 0u;
+            if (kk >= 2) {
+                const bool p_in = col_in && rc >= 0 && rc < H;
+                unsigned selb = 0u;
+                if (p_in) selb = (__builtin_amdgcn_raw_buffer_load_b8(rsel, (unsigned)(rc * W + col), 0, 0) >> (2 * s)) & 3u;
+                cur.sel = selb;
+                const bool on = p_in && selb == fsel && !no_ssim;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float Sx = older.hx[c] + newer.hx[c] + cur.hx[c], Sxx = older.hxx[c] + newer.hxx[c] + cur.hxx[c];
+                    const float Sxy = older.hxy[c] + newer.hxy[c] + cur.hxy[c];
+                    const TgtWin tw = tgt_win(older.hy[c] + newer.hy[c] + cur.hy[c], older.hyy[c] + newer.hyy[c] + cur.hyy[c]);
+                    const SsimTerms q = ssim_terms(Sx, Sxx, Sxy, tw);
+                    const float invd = fast_rcp(q.B1 * q.B2);
+                    const float rr = (q.A1 * q.A2) * invd;
+                    const float v = fmaf(-0.5f, rr, 0.5f);
                     float a0 = 0.f, cax = 0.f, cay = 0.f;
-                    if (!a.no_ssim && py >= 0 && py < H && px >= 0 && px < W && sel[py * W + px] == fsel) {
-                        const float* P = s_wrp + c * B_PLANE + r * B_LD + col;
-                        const float* Q = s_tgt + c * B_PLANE + r * B_LD + col;
-                        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+                    if (on && v >= 0.f && v <= 1.f) {   // clamp passes the gradient on the closed interval
+                        const float gsd = gs0 * invd;
+                        a0 = -gsd * (fmaf(tw.my, q.A2, -q.A1 * tw.sy) - rr * fmaf(q.mx, q.B2, -q.B1 * Sx));
+                        cay = -9.f * gsd * q.A1;
+                        cax = 9.f * gsd * rr * q.B1;
+                    }
+                    cur.ch[c][0] = fmaf(mxl, lane_prev(a0), a0) + mxr * lane_next(a0);
+                    cur.ch[c][1] = fmaf(mxl, lane_prev(cax), cax) + mxr * lane_next(cax);
+                    cur.ch[c][2] = fmaf(mxl, lane_prev(cay), cay) + mxr * lane_next(cay);
+                }
+            } else {
 #pragma unroll
-                        for (int rr = 0; rr < 3; ++rr)
+                for (int c = 0; c < 3; ++c) cur.ch[c][0] = cur.ch[c][1] = cur.ch[c][2] = 0.f;
+            }
+            // (4) gradient of the row two above (rq): 3x3 box sums of the coefficient fields, then the chain
+            if (kk >= 4) {
+                const int rq = r - 2;
+                const float myt = (rq == 1) ? 2.f : 1.f, myb = (rq == H - 2) ? 2.f : 1.f;
+                float g = 0.f;
 #pragma unroll
-                            for (int cc = 0; cc < 3; ++cc) {
-                                const float xv = P[rr * B_LD + cc], yv = Q[rr * B_LD + cc];
-                                sx += xv;
-                                sy += yv;
-                                sxx += xv * xv;
-                                syy += yv * yv;
-                                sxy += xv * yv;
+                for (int c = 0; c < 3; ++c) {
+                    const float S0 = fmaf(myt, older.ch[c][0], newer.ch[c][0]) + myb * cur.ch[c][0];
+                    const float Sxc = fmaf(myt, older.ch[c][1], newer.ch[c][1]) + myb * cur.ch[c][1];
+                    const float Syc = fmaf(myt, older.ch[c][2], newer.ch[c][2]) + myb * cur.ch[c][2];
+                    float gw = fmaf(older.xv[c], Sxc, fmaf(older.yv[c], Syc, S0));
+                    if (newer.sel == fsel) {
+                        const float df = older.xv[c] - older.yv[c];
+                        gw += l1w * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+                    }
+                    g = fmaf(gw, older.J[c], g);
+                }
+                if (!out_lane) g = 0.f;
+                if (same) {
+                    if (out_lane) {
+                        float* p = k.g_disp[s] + ((size_t)b * H + rq) * W + col;
+                        *p = (f > 0) ? *p + g : g;
+                    }
+                } else {
+                    // (5) adjoint of the bilinear up-sampling.  Horizontal: lanes publish g*(1-lx), g*lx; low texel i
+                    //     gathers its 2f columns.  Vertical: two running rows, flushed when the row pair advances.
+                    float* sA = s_row[wv][0];
+                    float* sB = s_row[wv][1];
+                    __builtin_amdgcn_wave_barrier();
+                    sA[lane] = g * (1.f - dgc.lx);
+                    sB[lane] = g * dgc.lx;
+                    __builtin_amdgcn_wave_barrier();
+                    const int i = ilo + lane;
+                    float h = 0.f;
+                    if (lane < SX && i < Ws) {
+                        const int fz = dg.f;
+                        const int cbase = fz * i - (fz >> 1) - X0 + 2;
+                        for (int q = 0; q < 2 * fz; ++q) {
+                            const int idx = cbase + q;
+                            if ((unsigned)idx < (unsigned)WAVE) {
+                                const float va = sA[idx], vb = sB[idx];
+                                // q < f : columns whose x1 is i (x0 = i - 1); for i = 0 the left-clamped columns (x0 = 0)
+                                // q >= f: columns whose x0 is i; at the right edge x1 = x0, so their lx part lands here too
+                                h += (q < fz) ? (i == 0 ? va : vb) : (va + (i == Ws - 1 ? vb : 0.f));
                             }
-                        // d v/d x_q = a0 + ay*y_q + ax*x_q with v = clamp((1 - n/d)/2); in the 81-scaled terms
-                        //   a0 = -G (s_y (A2-A1) - r s_x (B2-B1)) / d',  ay = -9 G A1 / d',  ax = 9 G r B1 / d'
-                        const SsimTerms t = ssim_terms(sx, sy, sxx, syy, sxy);
-                        const float invd = fast_rcp(t.B1 * t.B2);
-                        const float rr_ = (t.A1 * t.A2) * invd;
-                        const float v = (1.f - rr_) * 0.5f;
-                        if (v >= 0.f && v <= 1.f) {  // clamp passes gradient on the closed interval
-                            const float gs = up * (0.85f / 3.f) * invd;
-                            a0 = -gs * (sy * (t.A2 - t.A1) - rr_ * sx * (t.B2 - t.B1));
-                            cay = -9.f * gs * t.A1;
-                            cax = 9.f * gs * rr_ * t.B1;
                         }
                     }
-                    s_cf[0 * F_PLANE + r * F_LD + col] = a0;
-                    s_cf[1 * F_PLANE + r * F_LD + col] = cax;
-                    s_cf[2 * F_PLANE + r * F_LD + col] = cay;
-                }
-                __syncthreads();
-                // (2) 3x3 box sums (with the reflection fold) for the thread's 4 pixels
-                float h0[PXT + 2], h1[PXT + 2], h2[PXT + 2];
-#pragma unroll
-                for (int r = 0; r < PXT + 2; ++r) {
-                    const float* c0 = s_cf + (tg * PXT + r) * F_LD + tx;
-                    h0[r] = mxl * c0[0] + c0[1] + mxr * c0[2];
-                    h1[r] = mxl * c0[F_PLANE] + c0[F_PLANE + 1] + mxr * c0[F_PLANE + 2];
-                    h2[r] = mxl * c0[2 * F_PLANE] + c0[2 * F_PLANE + 1] + mxr * c0[2 * F_PLANE + 2];
-                }
-#pragma unroll
-                for (int i = 0; i < PXT; ++i) {
-                    const int qy = qy0 + i;
-                    const float myt = (qy == 1) ? 2.f : 1.f, myb = (qy == H - 2) ? 2.f : 1.f;
-                    const float S0 = myt * h0[i] + h0[i + 1] + myb * h0[i + 2];
-                    const float Sx = myt * h1[i] + h1[i + 1] + myb * h1[i + 2];
-                    const float Sy = myt * h2[i] + h2[i + 1] + myb * h2[i + 2];
-                    const float xq = s_wrp[c * B_PLANE + (tg * PXT + i + 2) * B_LD + tx + 2];
-                    const float yq = s_tgt[c * B_PLANE + (tg * PXT + i + 2) * B_LD + tx + 2];
-                    float g = S0 + yq * Sy + xq * Sx;
-                    if (qx < W && qy < H && sel[qy * W + qx] == fsel) {
-                        const float l1w = a.no_ssim ? (1.f / 3.f) : (0.15f / 3.f);
-                        const float df = xq - yq;
-                        g += up * l1w * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
+                    const RowLerp rl = row_lerp(dg, rq);
+                    if (rl.y0 > ja) {
+                        flush(ja, accA);
+                        accA = accB;
+                        accB = 0.f;
+                        ja = rl.y0;
                     }
-                    gw[c][i] = g;
-                }
-                __syncthreads();
-            }
-            // (3) chain through the bilinear gather, the projective divide and disp_to_depth
-            const unsigned plane = (unsigned)(H * W) * 4u;
-            const rsrc_t rs = make_rsrc(src, 3u * plane);
-            const rsrc_t rd = make_rsrc(disp, (unsigned)(a.Hs[s] * a.Ws[s]) * 4u);
-#pragma unroll
-            for (int i = 0; i < PXT; ++i) {
-                const int qy = qy0 + i;
-                if (qx < W && qy < H) {
-                    const float d = disp_at_buf(rd, a.Hs[s], a.Ws[s], rh, rw, same, qy, qx);
-                    acc[i] += warp_pixel_bwd_buf(rs, plane, s_cam[f], d, qx, qy, H, W, k.min_disp, k.dmul, gw[0][i],
-                                                 gw[1][i], gw[2][i]);
+                    accA = fmaf(1.f - rl.ly, h, accA);
+                    if (rl.y1 > rl.y0) accB = fmaf(rl.ly, h, accB);
+                    else accA = fmaf(rl.ly, h, accA);
                 }
             }
+            older = cur;
+        };
+        for (int kk = 0; kk < nrows; kk += 2) {
+            step(kk, recA, recB);
+            if (kk + 1 < nrows) step(kk + 1, recB, recA);
         }
-#pragma unroll
-        for (int i = 0; i < PXT; ++i) {
-            const int qy = qy0 + i;
-            if (qx < W && qy < H) k.g_up[s][((size_t)b * H + qy) * W + qx] = acc[i];
+        if (!same) {
+            flush(ja, accA);
+            if (ja + 1 < Hs) flush(ja + 1, accB);
         }
     }
 }
 
-// ------------------------------------------------------------------------------------------------ upsample adjoint
-// g_disp[b,j,i] (+)= sum over the full-resolution pixels whose bilinear footprint touches (j,i).
-// Gather form: deterministic, no atomics.  One thread per low-resolution texel.
-__global__ __launch_bounds__(NT) void upsample_adjoint_kernel(const float* __restrict__ g_up, float* __restrict__ g_disp,
-                                                              int B, int H, int W, int Hs, int Ws, int accumulate) {
-    const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= B * Hs * Ws) return;
-    const int i = idx % Ws, j = (idx / Ws) % Hs, b = idx / (Ws * Hs);
-    const float rh = (float)Hs / (float)H, rw = (float)Ws / (float)W;
-    const int fy = (H + Hs - 1) / Hs, fx = (W + Ws - 1) / Ws;  // integer upsampling factors (>= true ratio)
-    const int ylo = max(0, fy * j - fy), yhi = min(H - 1, fy * j + 2 * fy);
-    const int xlo = max(0, fx * i - fx), xhi = min(W - 1, fx * i + 2 * fx);
-    const float* g = g_up + (size_t)b * H * W;
+// Coarse scales: add the (<= 4) overlapping strip blocks of every low-resolution texel in a fixed order.
+struct CArgs {
+    const float* stage[DMH_MAX_SCALES];
+    float* g_disp[DMH_MAX_SCALES];
+    int Hs[DMH_MAX_SCALES], Ws[DMH_MAX_SCALES], sy_slots[DMH_MAX_SCALES], sx_slots[DMH_MAX_SCALES];
+    int64_t base[DMH_MAX_SCALES + 1];   // first texel of each coarse scale in the flat index space
+    int num_scales, B, H, W, R, tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ void low_range(int n_full, int n_low, int lo_px, int hi_px, int& jlo, int& jhi) {
+    // low-resolution rows/columns touched by full-resolution pixels [lo_px, hi_px]
+    const float r = (float)n_low / (float)n_full;
+    const float a = fmaxf(r * ((float)lo_px + 0.5f) - 0.5f, 0.f), b = fmaxf(r * ((float)hi_px + 0.5f) - 0.5f, 0.f);
+    jlo = (int)a;
+    const int y0 = (int)b;
+    jhi = y0 + (y0 < n_low - 1 ? 1 : 0);
+}
+
+__global__ __launch_bounds__(NT) void photo_combine_kernel(const CArgs k) {
+    const int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (idx >= k.base[k.num_scales]) return;
+    int s = 0;
+#pragma unroll
+    for (int q = 1; q < DMH_MAX_SCALES; ++q)
+        if (q < k.num_scales && idx >= k.base[q]) s = q;
+    if (k.stage[s] == nullptr) return;
+    const int Hs = k.Hs[s], Ws = k.Ws[s], SX = k.sx_slots[s], SY = k.sy_slots[s];
+    const int64_t loc = idx - k.base[s];
+    const int i = (int)(loc % Ws), j = (int)((loc / Ws) % Hs), b = (int)(loc / ((int64_t)Ws * Hs));
+    const int fy = k.H / Hs, fx = k.W / Ws;
+    // full-resolution rows / columns that can reach texel (j, i)
+    const int ya = max(0, fy * j - (fy >> 1) - 1), yb = min(k.H - 1, fy * j + fy + (fy >> 1));
+    const int xa = max(0, fx * i - (fx >> 1) - 1), xb = min(k.W - 1, fx * i + fx + (fx >> 1));
     float acc = 0.f;
-    for (int y = ylo; y <= yhi; ++y) {
-        const float sy = fmaxf(rh * ((float)y + 0.5f) - 0.5f, 0.f);
-        const int y0 = (int)sy, y1 = y0 + (y0 < Hs - 1 ? 1 : 0);
-        const float ly = sy - (float)y0;
-        const float wy = (y0 == j ? 1.f - ly : 0.f) + (y1 == j ? ly : 0.f);
-        if (wy == 0.f) continue;
-        float row = 0.f;
-        for (int x = xlo; x <= xhi; ++x) {
-            const float sx = fmaxf(rw * ((float)x + 0.5f) - 0.5f, 0.f);
-            const int x0 = (int)sx, x1 = x0 + (x0 < Ws - 1 ? 1 : 0);
-            const float lx = sx - (float)x0;
-            const float wx = (x0 == i ? 1.f - lx : 0.f) + (x1 == i ? lx : 0.f);
-            row += wx * g[y * W + x];
+    for (int ty = ya / k.R; ty <= yb / k.R; ++ty) {
+        int jl, jh;
+        low_range(k.H, Hs, ty * k.R, min(ty * k.R + k.R, k.H) - 1, jl, jh);
+        if (j < jl || j > jh) continue;
+        for (int tx = xa / BW_OUT; tx <= xb / BW_OUT; ++tx) {
+            int il, ih;
+            low_range(k.W, Ws, tx * BW_OUT, min(tx * BW_OUT + BW_OUT, k.W) - 1, il, ih);
+            if (i < il || i > ih) continue;
+            const int64_t tile = ((int64_t)b * k.tiles_y + ty) * k.tiles_x + tx;
+            acc += k.stage[s][(tile * SY + (j - jl)) * SX + (i - il)];
         }
-        acc += wy * row;
     }
-    if (accumulate) acc += g_disp[idx];
-    g_disp[idx] = acc;
+    k.g_disp[s][loc] = acc;
 }
 
-// ------------------------------------------------------------------------------------------------ materialised views
-__global__ __launch_bounds__(NT) void warp_view_fwd_kernel(const float* __restrict__ source,
-                                                           const float* __restrict__ disp_all,
-                                                           const float* __restrict__ K, const float* __restrict__ invK,
-                                                           const float* __restrict__ T, int H, int W, int Hs, int Ws,
-                                                           float min_disp, float dmul, float* __restrict__ depth,
-                                                           float* __restrict__ sample, float* __restrict__ color) {
-    __shared__ Cam s_cam;
-    const int b = blockIdx.y;
-    if (threadIdx.x < 21) load_cam(&s_cam, K, invK, T, b, threadIdx.x);
-    __syncthreads();
-    const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= H * W) return;
-    const int y = idx / W, x = idx - y * W;
-    const bool same = (Hs == H && Ws == W);
-    const float d = disp_at(disp_all + (size_t)b * Hs * Ws, Hs, Ws, (float)Hs / (float)H, (float)Ws / (float)W, same,
-                            y, x);
-    const Proj p = project<false>(s_cam, d, x, y, H, W, min_disp, dmul);
-    const size_t pix = (size_t)b * H * W + idx;
-    if (depth) depth[pix] = p.depth;
-    if (sample) {
-        sample[pix * 2 + 0] = (p.px / (float)(W - 1) - 0.5f) * 2.f;
-        sample[pix * 2 + 1] = (p.py / (float)(H - 1) - 0.5f) * 2.f;
-    }
-    if (color) {
-        const Tap t = make_tap(p.ix, p.iy, H, W);
-        const float* src = source + (size_t)b * 3 * H * W;
-        color[((size_t)b * 3 + 0) * H * W + idx] = tap_sample(src, t);
-        color[((size_t)b * 3 + 1) * H * W + idx] = tap_sample(src + H * W, t);
-        color[((size_t)b * 3 + 2) * H * W + idx] = tap_sample(src + 2 * H * W, t);
-    }
+__global__ __launch_bounds__(NT) void unpack_sel_kernel(const uint8_t* __restrict__ sel, int64_t n, int scale,
+                                                        float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i < n) out[i] = (float)((sel[i] >> (2 * scale)) & 3u);
 }
 
-__global__ __launch_bounds__(NT) void warp_view_bwd_kernel(const float* __restrict__ source,
-                                                           const float* __restrict__ disp_all,
-                                                           const float* __restrict__ K, const float* __restrict__ invK,
-                                                           const float* __restrict__ T, int H, int W, int Hs, int Ws,
-                                                           float min_disp, float dmul,
-                                                           const float* __restrict__ grad_color,
-                                                           const float* __restrict__ grad_depth,
-                                                           float* __restrict__ g_up) {
-    __shared__ Cam s_cam;
-    const int b = blockIdx.y;
-    if (threadIdx.x < 21) load_cam(&s_cam, K, invK, T, b, threadIdx.x);
-    __syncthreads();
-    const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= H * W) return;
-    const int y = idx / W, x = idx - y * W;
-    const bool same = (Hs == H && Ws == W);
-    const float d = disp_at(disp_all + (size_t)b * Hs * Ws, Hs, Ws, (float)Hs / (float)H, (float)Ws / (float)W, same,
-                            y, x);
-    const size_t hw = (size_t)H * W;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-    if (grad_color) {
-        g0 = grad_color[((size_t)b * 3 + 0) * hw + idx];
-        g1 = grad_color[((size_t)b * 3 + 1) * hw + idx];
-        g2 = grad_color[((size_t)b * 3 + 2) * hw + idx];
-    }
-    float g = warp_pixel_bwd<false>(source + (size_t)b * 3 * hw, s_cam, d, x, y, H, W, min_disp, dmul, g0, g1, g2);
-    if (grad_depth) {
-        const float sd = min_disp + dmul * d;
-        g += grad_depth[(size_t)b * hw + idx] * (-1.0f / (sd * sd)) * dmul;
-    }
-    g_up[(size_t)b * hw + idx] = g;
-}
-
+// ---------------------------------------------------------------------------------------------- host side
 int check_photo(const dmh_photo_args* a) {
     DMH_REQUIRE(a != nullptr, "args is null");
     DMH_REQUIRE(a->B > 0 && a->H >= 3 && a->W >= 3, "need B>0, H>=3, W>=3");
-    DMH_REQUIRE(a->num_frames >= 1 && a->num_frames <= DMH_MAX_FRAMES, "num_frames out of range");
+    DMH_REQUIRE(a->num_frames >= 1 && a->num_frames <= DMH_MAX_FRAMES, "num_frames out of range (1..3)");
     DMH_REQUIRE(a->num_scales >= 1 && a->num_scales <= DMH_MAX_SCALES, "num_scales out of range");
     DMH_REQUIRE(a->target && a->K && a->inv_K, "null target/K/inv_K");
     DMH_REQUIRE(a->min_depth > 0.f && a->max_depth > a->min_depth, "bad depth range");
     DMH_REQUIRE(a->variant == DMH_VARIANT_MD2 || a->variant == DMH_VARIANT_DH, "unknown variant");
-    DMH_REQUIRE((int64_t)a->B * 3 * a->H * a->W < (int64_t)1 << 40, "tensor too large");
+    DMH_REQUIRE((int64_t)a->B * a->H * a->W < (int64_t)1 << 31 && (int64_t)3 * a->H * a->W < (int64_t)1 << 29, "tensor too large");
     for (int f = 0; f < a->num_frames; ++f) DMH_REQUIRE(a->source[f] && a->T[f], "null source/T");
     for (int s = 0; s < a->num_scales; ++s) {
         DMH_REQUIRE(a->disp[s] != nullptr, "null disp");
-        DMH_REQUIRE(a->Hs[s] >= 1 && a->Ws[s] >= 1 && a->Hs[s] <= a->H && a->Ws[s] <= a->W, "bad disp size");
+        const int Hs = a->Hs[s], Ws = a->Ws[s];
+        DMH_REQUIRE(Hs >= 1 && Ws >= 1 && Hs <= a->H && Ws <= a->W, "bad disp size");
+        const int f = a->H / Hs;
+        DMH_REQUIRE(f * Hs == a->H && f * Ws == a->W && (f & (f - 1)) == 0 && f <= 16,
+                    "disparity size must be the image size divided by 1, 2, 4, 8 or 16 (MD2/trainer.py:52-53 asserts multiples of 32)");
         if (a->noise_mode == DMH_NOISE_TENSOR) DMH_REQUIRE(a->noise[s] != nullptr, "null noise tensor");
     }
     DMH_REQUIRE(a->noise_mode >= DMH_NOISE_NONE && a->noise_mode <= DMH_NOISE_PHILOX, "bad noise_mode");
     return DMH_OK;
 }
 
-void fill_kargs(KArgs& k, const dmh_photo_args* a) {
+void fill_kargs(KArgs& k, const dmh_photo_args* a, int out_cols) {
     memset(&k, 0, sizeof(k));
     k.a = *a;
-    k.tiles_x = (a->W + TW - 1) / TW;
-    k.tiles_y = (a->H + TH - 1) / TH;
-    k.nblk = k.tiles_x * k.tiles_y * a->B;
+    k.R = pick_rows(a->B, a->H, a->W, out_cols);
+    k.tiles_x = (a->W + out_cols - 1) / out_cols;
+    k.tiles_y = (a->H + k.R - 1) / k.R;
+    k.ntiles = k.tiles_x * k.tiles_y * a->B;
     const double min_disp = 1.0 / (double)a->max_depth, max_disp = 1.0 / (double)a->min_depth;
     k.min_disp = (float)min_disp;
     k.dmul = (float)(max_disp - min_disp);
+}
+
+// staging block of one backward strip at scale s: low-resolution rows x columns it can touch
+void stage_slots(const dmh_photo_args* a, int R, int s, int& sy, int& sx) {
+    const int f = a->H / a->Hs[s];
+    sy = R / f + 2;
+    sx = BW_OUT / f + 2;
+    if (R % f) ++sy;
+    if (BW_OUT % f) ++sx;
 }
 
 }  // namespace
@@ -770,85 +829,104 @@ void fill_kargs(KArgs& k, const dmh_photo_args* a) {
 extern "C" {
 
 int64_t dmh_photo_partials_size(int B, int H, int W, int num_scales) {
-    const int64_t tiles = (int64_t)((W + TW - 1) / TW) * ((H + TH - 1) / TH) * B;
+    const int R = pick_rows(B, H, W, FW_OUT);
+    const int64_t tiles = (int64_t)((W + FW_OUT - 1) / FW_OUT) * ((H + R - 1) / R) * B;
     return tiles * 2 * num_scales;
 }
 
-int dmh_photo_loss_fwd(const dmh_photo_args* a, float* const sel[DMH_MAX_SCALES],
-                       float* const to_opt[DMH_MAX_SCALES], float* partials, void* stream) {
+int64_t dmh_photo_stage_size(const dmh_photo_args* a) {
+    if (!a || check_photo(a) != DMH_OK) return 0;
+    KArgs k;
+    fill_kargs(k, a, BW_OUT);
+    int64_t n = 1;   // never hand out a zero-sized workspace
+    for (int s = 0; s < a->num_scales; ++s) {
+        if (a->Hs[s] == a->H) continue;
+        int sy, sx;
+        stage_slots(a, k.R, s, sy, sx);
+        n += (int64_t)k.ntiles * sy * sx;
+    }
+    return n;
+}
+
+int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_opt[DMH_MAX_SCALES], float* partials,
+                       void* stream) {
     if (int rc = check_photo(a)) return rc;
     DMH_REQUIRE(sel != nullptr && partials != nullptr, "null outputs");
+    DMH_REQUIRE(a->num_frames <= 3, "the packed selection map holds 2 bits per scale: at most 3 source frames");
     KArgs k;
-    fill_kargs(k, a);
-    for (int s = 0; s < a->num_scales; ++s) {
-        DMH_REQUIRE(sel[s] != nullptr, "null sel[s]");
-        k.sel[s] = sel[s];
-        k.to_opt[s] = to_opt ? to_opt[s] : nullptr;
-    }
+    fill_kargs(k, a, FW_OUT);
+    k.sel = sel;
+    for (int s = 0; s < a->num_scales; ++s) k.to_opt[s] = to_opt ? to_opt[s] : nullptr;
     k.partials = partials;
+    const dim3 grid((k.ntiles + WPB - 1) / WPB), block(NT);
     switch (a->num_frames) {
-        case 1: hipLaunchKernelGGL(photo_fwd_kernel<1>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
-        case 2: hipLaunchKernelGGL(photo_fwd_kernel<2>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
-        case 3: hipLaunchKernelGGL(photo_fwd_kernel<3>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
-        default: hipLaunchKernelGGL(photo_fwd_kernel<4>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
+        case 1: hipLaunchKernelGGL((photo_fwd_kernel<1, 4>), grid, block, 0, (hipStream_t)stream, k); break;
+        case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, k); break;
+        default: hipLaunchKernelGGL((photo_fwd_kernel<3, 1>), grid, block, 0, (hipStream_t)stream, k); break;
     }
     return check_launch("dmh_photo_loss_fwd");
 }
 
-int dmh_photo_loss_bwd(const dmh_photo_args* a, const float* const sel[DMH_MAX_SCALES], const float* gvec,
-                       const float* fin, float* const g_up[DMH_MAX_SCALES], void* stream) {
+int dmh_photo_loss_bwd(const dmh_photo_args* a, const uint8_t* sel, const float* gvec, const float* fin, float* stage,
+                       float* const g_disp[DMH_MAX_SCALES], void* stream) {
     if (int rc = check_photo(a)) return rc;
-    DMH_REQUIRE(sel && gvec && fin && g_up, "null argument");
+    DMH_REQUIRE(sel && gvec && fin && stage && g_disp, "null argument");
+    DMH_REQUIRE(a->num_frames <= 3, "at most 3 source frames");
     KArgs k;
-    fill_kargs(k, a);
-    for (int s = 0; s < a->num_scales; ++s) {
-        DMH_REQUIRE(sel[s] != nullptr && g_up[s] != nullptr, "null sel[s]/g_up[s]");
-        k.csel[s] = sel[s];
-        k.g_up[s] = g_up[s];
-    }
+    fill_kargs(k, a, BW_OUT);
+    k.csel = sel;
     k.gvec = gvec;
     k.fin = fin;
-    switch (a->num_frames) {
-        case 1: hipLaunchKernelGGL(photo_bwd_kernel<1>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
-        case 2: hipLaunchKernelGGL(photo_bwd_kernel<2>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
-        case 3: hipLaunchKernelGGL(photo_bwd_kernel<3>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
-        default: hipLaunchKernelGGL(photo_bwd_kernel<4>, dim3(k.nblk), dim3(NT), 0, (hipStream_t)stream, k); break;
+    CArgs c;
+    memset(&c, 0, sizeof(c));
+    int64_t off = 0, texels = 0;
+    bool coarse = false;
+    for (int s = 0; s < a->num_scales; ++s) {
+        DMH_REQUIRE(g_disp[s] != nullptr, "null g_disp[s]");
+        k.g_disp[s] = g_disp[s];
+        c.g_disp[s] = g_disp[s];
+        c.Hs[s] = a->Hs[s];
+        c.Ws[s] = a->Ws[s];
+        c.base[s] = texels;
+        if (a->Hs[s] != a->H) {
+            stage_slots(a, k.R, s, k.sy_slots[s], k.sx_slots[s]);
+            k.stage[s] = stage + off;
+            c.stage[s] = k.stage[s];
+            c.sy_slots[s] = k.sy_slots[s];
+            c.sx_slots[s] = k.sx_slots[s];
+            off += (int64_t)k.ntiles * k.sy_slots[s] * k.sx_slots[s];
+            texels += (int64_t)a->B * a->Hs[s] * a->Ws[s];
+            coarse = true;
+        }
+        c.base[s + 1] = texels;
     }
-    return check_launch("dmh_photo_loss_bwd");
+    const int items = k.ntiles * a->num_scales;
+    const dim3 grid((items + WPB - 1) / WPB), block(NT);
+    switch (a->num_frames) {
+        case 1: hipLaunchKernelGGL(photo_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, k); break;
+        case 2: hipLaunchKernelGGL(photo_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, k); break;
+        default: hipLaunchKernelGGL(photo_bwd_kernel<3>, grid, block, 0, (hipStream_t)stream, k); break;
+    }
+    if (int rc = check_launch("dmh_photo_loss_bwd")) return rc;
+    if (coarse) {
+        c.num_scales = a->num_scales;
+        c.B = a->B;
+        c.H = a->H;
+        c.W = a->W;
+        c.R = k.R;
+        c.tiles_x = k.tiles_x;
+        c.tiles_y = k.tiles_y;
+        hipLaunchKernelGGL(photo_combine_kernel, dim3((unsigned)((texels + NT - 1) / NT)), block, 0, (hipStream_t)stream, c);
+        return check_launch("dmh_photo_loss_bwd (combine)");
+    }
+    return DMH_OK;
 }
 
-int dmh_upsample_bilinear_adjoint(const float* g_up, float* g_disp, int B, int H, int W, int Hs, int Ws,
-                                  int accumulate, void* stream) {
-    DMH_REQUIRE(g_up && g_disp, "null pointer");
-    DMH_REQUIRE(B > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && Hs <= H && Ws <= W, "bad sizes");
-    const int n = B * Hs * Ws;
-    hipLaunchKernelGGL(upsample_adjoint_kernel, dim3((n + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, g_up,
-                       g_disp, B, H, W, Hs, Ws, accumulate);
-    return check_launch("dmh_upsample_bilinear_adjoint");
-}
-
-int dmh_warp_view_fwd(const float* source, const float* disp, const float* K, const float* inv_K, const float* T,
-                      int B, int H, int W, int Hs, int Ws, float min_depth, float max_depth, float* depth,
-                      float* sample, float* color, void* stream) {
-    DMH_REQUIRE(source && disp && K && inv_K && T, "null input");
-    DMH_REQUIRE(B > 0 && H >= 2 && W >= 2 && Hs > 0 && Ws > 0 && Hs <= H && Ws <= W, "bad sizes");
-    DMH_REQUIRE(min_depth > 0.f && max_depth > min_depth, "bad depth range");
-    const double mn = 1.0 / (double)max_depth, mx = 1.0 / (double)min_depth;
-    hipLaunchKernelGGL(warp_view_fwd_kernel, dim3((H * W + NT - 1) / NT, B), dim3(NT), 0, (hipStream_t)stream, source,
-                       disp, K, inv_K, T, H, W, Hs, Ws, (float)mn, (float)(mx - mn), depth, sample, color);
-    return check_launch("dmh_warp_view_fwd");
-}
-
-int dmh_warp_view_bwd(const float* source, const float* disp, const float* K, const float* inv_K, const float* T,
-                      int B, int H, int W, int Hs, int Ws, float min_depth, float max_depth,
-                      const float* grad_color, const float* grad_depth, float* g_up, void* stream) {
-    DMH_REQUIRE(source && disp && K && inv_K && T && g_up, "null input");
-    DMH_REQUIRE(B > 0 && H >= 2 && W >= 2 && Hs > 0 && Ws > 0 && Hs <= H && Ws <= W, "bad sizes");
-    DMH_REQUIRE(min_depth > 0.f && max_depth > min_depth, "bad depth range");
-    const double mn = 1.0 / (double)max_depth, mx = 1.0 / (double)min_depth;
-    hipLaunchKernelGGL(warp_view_bwd_kernel, dim3((H * W + NT - 1) / NT, B), dim3(NT), 0, (hipStream_t)stream, source,
-                       disp, K, inv_K, T, H, W, Hs, Ws, (float)mn, (float)(mx - mn), grad_color, grad_depth, g_up);
-    return check_launch("dmh_warp_view_bwd");
+int dmh_unpack_selection(const uint8_t* sel, int64_t n, int scale, float* out, void* stream) {
+    DMH_REQUIRE(sel && out, "null pointer");
+    DMH_REQUIRE(n > 0 && scale >= 0 && scale < DMH_MAX_SCALES, "bad size / scale");
+    hipLaunchKernelGGL(unpack_sel_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, sel, n, scale, out);
+    return check_launch("dmh_unpack_selection");
 }
 
 }  // extern "C"

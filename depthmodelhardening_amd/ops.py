@@ -137,7 +137,7 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         dev = target.device
         a = _photo_args(cfg, target, sources, Ts, K, inv_K, disps, noises)
         sm = _smooth_args(disps, colors)
-        sel = [torch.empty((B, H, W), device=dev, dtype=torch.float32) for _ in range(NS)]
+        sel = torch.empty((B, H, W), device=dev, dtype=torch.uint8)    # 2 bits per scale: 0 identity, 1+f frame f
         to_opt = [torch.empty((B, H, W), device=dev, dtype=torch.float32) if cfg["want_to_opt"] else None
                   for _ in range(NS)]
         pp = torch.empty(lib.dmh_photo_partials_size(B, H, W, NS), device=dev, dtype=torch.float32)
@@ -145,14 +145,14 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         fin = torch.empty(N.FIN_SIZE, device=dev, dtype=torch.float32)
         sstats = torch.empty((NS, B, 2), device=dev, dtype=torch.float32)
         st = N.stream()
-        selp, optp = N.ptr_array(sel), N.ptr_array(to_opt)
-        N.check(_timed("photo_fwd", lambda: lib.dmh_photo_loss_fwd(C.byref(a), selp, optp, N.ptr(pp), st)))
+        optp = N.ptr_array(to_opt)
+        N.check(_timed("photo_fwd", lambda: lib.dmh_photo_loss_fwd(C.byref(a), N.ptr(sel), optp, N.ptr(pp), st)))
         N.check(lib.dmh_smooth_loss_fwd(C.byref(sm), N.ptr(sp), st))
         N.check(lib.dmh_loss_finalize(N.ptr(pp), N.ptr(sp), B, H, W, C.byref(sm), a.variant, cfg["smooth_wt"],
                                       N.ptr(fin), N.ptr(sstats), st))
         ctx.cfg = cfg
-        ctx.save_for_backward(target, K, inv_K, fin, sstats, *sources, *Ts, *colors, *disps, *sel)
-        outs = [fin] + sel + [t for t in to_opt if t is not None]
+        ctx.save_for_backward(target, K, inv_K, fin, sstats, sel, *sources, *Ts, *colors, *disps)
+        outs = [fin, sel] + [t for t in to_opt if t is not None]
         ctx.mark_non_differentiable(*outs[1:])
         return tuple(outs)
 
@@ -161,35 +161,50 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         cfg = ctx.cfg
         F, NS = cfg["F"], cfg["NS"]
         sv = ctx.saved_tensors
-        target, K, inv_K, fin, sstats = sv[:5]
-        sources, Ts = sv[5:5 + F], sv[5 + F:5 + 2 * F]
-        colors = sv[5 + 2 * F:5 + 2 * F + NS]
-        disps = sv[5 + 2 * F + NS:5 + 2 * F + 2 * NS]
-        sel = sv[5 + 2 * F + 2 * NS:5 + 2 * F + 3 * NS]
+        target, K, inv_K, fin, sstats, sel = sv[:6]
+        sources, Ts = sv[6:6 + F], sv[6 + F:6 + 2 * F]
+        colors = sv[6 + 2 * F:6 + 2 * F + NS]
+        disps = sv[6 + 2 * F + NS:6 + 2 * F + 2 * NS]
         lib = N.lib()
-        B, _, H, W = target.shape
         dev = target.device
         gvec = _c(g_fin.to(torch.float32))
         cfg_b = dict(cfg, noise_mode=N.NOISE_NONE)
         a = _photo_args(cfg_b, target, sources, Ts, K, inv_K, disps, ())
         sm = _smooth_args(disps, colors)
         st = N.stream()
-        g_up = [torch.empty((B, H, W), device=dev, dtype=torch.float32) for _ in range(NS)]
-        selp, gupp = N.ptr_array(sel), N.ptr_array(g_up)
-        N.check(_timed("photo_bwd", lambda: lib.dmh_photo_loss_bwd(C.byref(a), selp, N.ptr(gvec), N.ptr(fin), gupp, st)))
-        g_disp = []
-        for s, d in enumerate(disps):
-            Hs, Ws = d.shape[2], d.shape[3]
-            if (Hs, Ws) == (H, W):
-                g_disp.append(g_up[s].view(B, 1, H, W))
-            else:
-                g = torch.empty_like(d)
-                N.check(lib.dmh_upsample_bilinear_adjoint(N.ptr(g_up[s]), N.ptr(g), B, H, W, Hs, Ws, 0, st))
-                g_disp.append(g)
-        N.check(lib.dmh_smooth_loss_bwd(C.byref(sm), N.ptr(gvec), N.ptr(sstats), cfg["smooth_wt"],
-                                        N.ptr_array(g_disp), 1, st))
+        g_disp = [torch.empty_like(d) for d in disps]
+        stage = torch.empty(lib.dmh_photo_stage_size(C.byref(a)), device=dev, dtype=torch.float32)
+        gp = N.ptr_array(g_disp)
+        N.check(_timed("photo_bwd", lambda: lib.dmh_photo_loss_bwd(C.byref(a), N.ptr(sel), N.ptr(gvec), N.ptr(fin),
+                                                                  N.ptr(stage), gp, st)))
+        N.check(lib.dmh_smooth_loss_bwd(C.byref(sm), N.ptr(gvec), N.ptr(sstats), cfg["smooth_wt"], gp, 1, st))
         n_mid = 2 * F + NS + (NS if cfg["noise_mode"] == N.NOISE_TENSOR else 0)
         return (None, None, None, None) + (None,) * n_mid + tuple(g_disp)
+
+
+class SelectionMaps(object):
+    """The per-scale selection maps of the fused loss, unpacked on demand from the packed byte map the kernel writes
+    (2 bits per scale): ``maps[s]`` is a float [B,H,W] tensor, 0 where the identity term was chosen, 1 + f where the
+    reprojection of source frame f was (== outputs["identity_selection/s"] for one source frame,
+    MD2/trainer.py:656-658).  Nothing is materialised until a scale is asked for."""
+
+    def __init__(self, packed, num_scales):
+        self.packed, self.num_scales, self._cache = packed, num_scales, {}
+
+    def __len__(self):
+        return self.num_scales
+
+    def __getitem__(self, s):
+        if not 0 <= s < self.num_scales:
+            raise IndexError(s)
+        if s not in self._cache:
+            out = torch.empty(self.packed.shape, device=self.packed.device, dtype=torch.float32)
+            N.check(N.lib().dmh_unpack_selection(N.ptr(self.packed), self.packed.numel(), int(s), N.ptr(out), N.stream()))
+            self._cache[s] = out
+        return self._cache[s]
+
+    def __iter__(self):
+        return (self[s] for s in range(self.num_scales))
 
 
 def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_depth=0.1, max_depth=100.0,
@@ -200,12 +215,13 @@ def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_de
     target [B,3,H,W]; sources / Ts: one per non-target frame; disps[s] [B,1,H/2^s,W/2^s];
     colors[s] = inputs[("color",0,s)].  ``noise``: "philox" (in-kernel randn*1e-5, the reference's
     tie-break of MD2/trainer.py:642-645), None, or a list of NS already-scaled tensors.
-    Returns LossOut(fin, sel, to_opt): fin[FIN_*] is differentiable w.r.t. the disparities.
+    Returns LossOut(fin, sel, to_opt): fin[FIN_*] is differentiable w.r.t. the disparities; sel is a SelectionMaps
+    (sel[s] unpacks scale s on demand).
     """
     F, NS = len(sources), len(disps)
     N.ptr(target)   # rejects CPU tensors up front ("no CPU path") before any CUDA-only call below
-    if not (1 <= F <= N.MAX_FRAMES and 1 <= NS <= N.MAX_SCALES):
-        raise RuntimeError("photometric loss supports 1..4 source frames and 1..4 scales")
+    if not (1 <= F <= 3 and 1 <= NS <= N.MAX_SCALES):
+        raise RuntimeError("photometric loss supports 1..3 source frames and 1..4 scales")
     if variant not in ("md2", "dh"):
         raise RuntimeError("variant must be 'md2' or 'dh'")
     B, _, H, W = target.shape
@@ -223,8 +239,8 @@ def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_de
     args = (_c(target), _c(K), _c(inv_K)) + tuple(_c(s) for s in sources) + tuple(_c(t) for t in Ts) + \
         tuple(_c(c) for c in colors) + noises + tuple(_c(d) for d in disps)
     outs = _PhotoSmoothLoss.apply(cfg, *args)
-    fin, sel = outs[0], list(outs[1:1 + NS])
-    to_opt = list(outs[1 + NS:]) if want_to_opt else [None] * NS
+    fin, sel = outs[0], SelectionMaps(outs[1], NS)
+    to_opt = list(outs[2:]) if want_to_opt else [None] * NS
     return LossOut(fin, sel, to_opt)
 
 

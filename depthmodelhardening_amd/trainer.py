@@ -31,6 +31,32 @@ from .layers import SSIM
 from .my_utils import ori_H, ori_W
 
 
+class LazyOutputs(dict):
+    """The ``outputs`` dict of process_batch.  Entries registered with ``lazy(key, fn)`` are produced on first access:
+    the fused loss keeps its per-scale selection maps as one packed byte per pixel, and the float maps the reference
+    writes to outputs["identity_selection/{s}"] (MD2/trainer.py:656-658, read by its logger only) are unpacked when --
+    and only when -- somebody reads them."""
+
+    def __init__(self, *a, **kw):
+        super().__init__(*a, **kw)
+        self._lazy = {}
+
+    def lazy(self, key, fn):
+        self._lazy[key] = fn
+
+    def __missing__(self, key):
+        if key in self._lazy:
+            self[key] = self._lazy.pop(key)()
+            return dict.__getitem__(self, key)
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self._lazy
+
+    def get(self, key, default=None):
+        return self[key] if key in self else default
+
+
 class Trainer:
     def __init__(self, options, rank=0, world_size=1, device=None):
         self.opt = options
@@ -213,7 +239,7 @@ class Trainer:
         for key, ipt in inputs.items():
             inputs[key] = ipt.to(self.device)
         features = self.models["encoder"](inputs["color_aug", 0, 0])
-        outputs = self.models["depth"](features)
+        outputs = LazyOutputs(self.models["depth"](features))
         outputs["middle_features_aug"] = features
         if self.opt.contrastive_learning:
             outputs["middle_features_ben"] = self.models["encoder"](inputs["color_ben", 0, 0])
@@ -287,12 +313,19 @@ class Trainer:
             if self.opt.loss_variant == "dh":
                 losses["reproj_loss/{}".format(scale)] = out.fin[N.FIN_REPROJ_S + i]
             if not self.opt.disable_automasking:
-                sel = out.sel[i]
-                if len(frames) > 1 or self.opt.loss_variant == "dh":
-                    sel = (sel > 0).float()
-                    if self.opt.loss_variant == "dh":
-                        sel = 1 - sel                                 # DH/trainer.py:703
-                outputs["identity_selection/{}".format(scale)] = sel
+                def selection(i=i, multi=len(frames) > 1 or self.opt.loss_variant == "dh",
+                              dh=self.opt.loss_variant == "dh"):
+                    sel = out.sel[i]
+                    if multi:
+                        sel = (sel > 0).float()
+                        if dh:
+                            sel = 1 - sel                             # DH/trainer.py:703
+                    return sel
+                key = "identity_selection/{}".format(scale)
+                if isinstance(outputs, LazyOutputs):
+                    outputs.lazy(key, selection)
+                else:
+                    outputs[key] = selection()
         total_loss = total_loss + out.fin[N.FIN_LOSS]
         losses["loss"] = total_loss
         return losses

@@ -82,20 +82,26 @@ typedef struct dmh_photo_args {
 
 /* number of floats the photometric partial-sum workspace needs */
 int64_t dmh_photo_partials_size(int B, int H, int W, int num_scales);
+/* number of floats of the backward staging workspace (per-strip partial low-resolution gradients) */
+int64_t dmh_photo_stage_size(const dmh_photo_args* a);
 
-/* Forward.  sel[s]   : out [B,H,W] float, 0 = identity chosen, 1+f = reprojection of frame f chosen
- *                      (== outputs["identity_selection/s"] for one source frame, MD2/trainer.py:656-658)
+/* Forward.  sel      : out [B,H,W] uint8, the selection of every scale packed 2 bits per scale: bits [2s, 2s+1] =
+ *                      0 identity chosen, 1+f reprojection of source frame f chosen (== outputs["identity_selection/s"]
+ *                      for one source frame, MD2/trainer.py:656-658).  At most 3 source frames.
  *           to_opt[s]: out [B,H,W] per-pixel selected loss, or NULL
- *           partials : out, dmh_photo_partials_size floats                                      */
-int dmh_photo_loss_fwd(const dmh_photo_args* a, float* const sel[DMH_MAX_SCALES],
-                       float* const to_opt[DMH_MAX_SCALES], float* partials, void* stream);
-
-/* Backward (recompute).  gvec: [DMH_FIN_SIZE] upstream gradient of the fin vector; fin: the
- * finalized forward vector.  g_up[s]: out [B,H,W] gradient w.r.t. the UPSAMPLED disparity of
- * scale s (for Hs==H it IS the gradient of disp[s]).                                           */
-int dmh_photo_loss_bwd(const dmh_photo_args* a, const float* const sel[DMH_MAX_SCALES],
-                       const float* gvec, const float* fin, float* const g_up[DMH_MAX_SCALES],
+ *           partials : out, dmh_photo_partials_size floats
+ * disp[s] must be [B,1,H/f,W/f] with f in {1,2,4,8,16}.                                                     */
+int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_opt[DMH_MAX_SCALES], float* partials,
                        void* stream);
+
+/* Backward (recompute).  gvec: [DMH_FIN_SIZE] upstream gradient of the fin vector; fin: the finalized forward
+ * vector; stage: dmh_photo_stage_size floats of scratch.  g_disp[s]: out [B,1,Hs,Ws] gradient w.r.t. disp[s]
+ * (overwritten; the adjoint of the bilinear up-sampling, MD2/trainer.py:481-482, is applied in the kernel).   */
+int dmh_photo_loss_bwd(const dmh_photo_args* a, const uint8_t* sel, const float* gvec, const float* fin, float* stage,
+                       float* const g_disp[DMH_MAX_SCALES], void* stream);
+
+/* out[i] = field `scale` of the packed selection map as float (0 identity, 1+f frame f), n = B*H*W.          */
+int dmh_unpack_selection(const uint8_t* sel, int64_t n, int scale, float* out, void* stream);
 
 /* Adjoint of F.interpolate(disp,[H,W],bilinear,align_corners=False) (MD2/trainer.py:481-482):
  * g_disp [B,1,Hs,Ws] (+)= gather(g_up [B,H,W]).  accumulate != 0 adds to g_disp.             */

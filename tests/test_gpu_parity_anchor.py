@@ -1,0 +1,329 @@
+"""fp64-anchored parity of the fused loss (K1 + K2), the goldens the HIP path had never met, and the full-size
+shapes of BASELINE configs 3 and 4.  Everything goes through the C ABI (libdmh_hip.so).
+
+Why an fp64 anchor.  The loss gradient is discontinuous in its inputs at two kinds of points: the bilinear sampler's
+floor() (d warped / d coordinate jumps when the sample coordinate crosses a texel) and the per-pixel min/argmin.  fp32
+rounding of the coordinate (~1e-4 px at x ~ 500) puts ~1e-4 of the pixels on the other side of such a point in ANY
+fp32 implementation, the reference included, and each flip is an O(1) change of that pixel's gradient; a flipped
+full-resolution pixel reaches 4 texels of every coarser scale, so the fraction of affected texels grows like 4^s.
+Element-wise comparison of two fp32 implementations therefore cannot separate "conditioning" from "bug".  Against the
+SAME oracle evaluated in float64 it can: the fp32 oracle's own distance to fp64 is the size of the conditioning
+noise, and the HIP kernel has to stay within 1.5x of it, over ALL elements (no trimming, no tie exclusion), per scale,
+for both loss variants.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from tests.util import assert_close_frac, bad_frac, np_t, rel_l2, to_dev  # noqa: E402
+
+PIX_ATOL = 5e-5   # per-pixel SSIM conditioning (see tests/test_gpu_kernels.py)
+
+
+def _mods():
+    from depthmodelhardening_amd import _native as N, ops
+    from oracle import loss_ref, synth
+    return N, ops, loss_ref, synth
+
+
+def _oracle(loss_ref, synth, B, H, W, seed, dtype, variant, noise=None):
+    inputs, disps = synth.make_loss_case(B, H, W, seed, dtype=dtype)
+    outputs = {("disp", s): disps[s].clone().requires_grad_(True) for s in range(4)}
+    loss_ref.generate_images_pred(inputs, outputs)
+    nz = None if noise is None else {s: noise[s].to(dtype) for s in range(4)}
+    losses, maps = loss_ref.compute_losses(inputs, outputs, noise=nz, variant=variant)
+    losses["loss"].backward()
+    return inputs, disps, outputs, losses, maps
+
+
+def _hip(ops, inputs, disps, variant, noise=None, **kw):
+    d_in = to_dev(inputs)
+    dd = [d.cuda().requires_grad_(True) for d in disps]
+    out = ops.photometric_smooth_loss(
+        d_in[("color", 0, 0)], [d_in[("color", "s", 0)]], [d_in["stereo_T"]], d_in[("K", 0)], d_in[("inv_K", 0)], dd,
+        [d_in[("color", 0, s)] for s in range(4)], variant=variant,
+        noise=None if noise is None else [noise[s].cuda() for s in range(4)], want_to_opt=True, **kw)
+    return out, dd
+
+
+@pytest.mark.parametrize("variant", ["md2", "dh"])
+@pytest.mark.parametrize("shape", [(2, 192, 640), (3, 64, 200)])
+def test_gradients_within_fp32_conditioning_of_the_fp64_oracle(variant, shape):
+    """err(HIP vs fp64) <= 1.5 x err(fp32 oracle vs fp64): rel-L2 over all elements, and the count of elements beyond
+    1e-4 of the tensor's scale.  Pooled over three seeds so that a handful of flips on either side cannot decide it."""
+    N, ops, loss_ref, synth = _mods()
+    B, H, W = shape
+    num_h, num_o, den = np.zeros(4), np.zeros(4), np.zeros(4)
+    bad_h, bad_o, cnt = np.zeros(4), np.zeros(4), np.zeros(4)
+    loss_err_h = loss_err_o = 0.0
+    for seed in (22, 23, 24):
+        i64, d64, o64, l64, _ = _oracle(loss_ref, synth, B, H, W, seed, torch.float64, variant)
+        i32, d32, o32, l32, _ = _oracle(loss_ref, synth, B, H, W, seed, torch.float32, variant)
+        out, dd = _hip(ops, i32, d32, variant)
+        out.fin[N.FIN_LOSS].backward()
+        ref = l64["loss"].item()
+        loss_err_h = max(loss_err_h, abs(out.fin[N.FIN_LOSS].item() - ref) / abs(ref))
+        loss_err_o = max(loss_err_o, abs(l32["loss"].item() - ref) / abs(ref))
+        for s in range(4):
+            g64 = o64[("disp", s)].grad
+            g32 = o32[("disp", s)].grad.double()
+            gh = dd[s].grad.double().cpu()
+            assert torch.isfinite(gh).all()
+            num_h[s] += float((gh - g64).pow(2).sum())
+            num_o[s] += float((g32 - g64).pow(2).sum())
+            den[s] += float(g64.pow(2).sum())
+            tol = 1e-4 * g64.abs().max().item()
+            bad_h[s] += float(((gh - g64).abs() > tol + 1e-4 * g64.abs()).sum())
+            bad_o[s] += float(((g32 - g64).abs() > tol + 1e-4 * g64.abs()).sum())
+            cnt[s] += g64.numel()
+    for s in range(4):
+        e_h, e_o = (num_h[s] / den[s]) ** 0.5, (num_o[s] / den[s]) ** 0.5
+        print("%s %s scale %d: rel-L2 vs fp64  hip %.3g  oracle32 %.3g | bad elements hip %d oracle32 %d of %d" % (
+            variant, shape, s, e_h, e_o, bad_h[s], bad_o[s], cnt[s]))
+        assert e_h <= 1.5 * e_o + 1e-6, "scale %d: HIP rel-L2 %.3g vs fp32-oracle %.3g (both against fp64)" % (s, e_h, e_o)
+        assert bad_h[s] <= 1.5 * bad_o[s] + 1e-3 * cnt[s], (s, bad_h[s], bad_o[s], cnt[s])
+    # md2's mean(min) is continuous: the HIP loss is as close to fp64 as the fp32 oracle is (+1 ulp-ish floor).  dh's
+    # masked-sum / mask-count jumps by (value - mean)/count per flipped near-tie: floor of two flips.
+    floor = 2e-6 if variant == "md2" else 2.0 / (B * H * W)
+    assert loss_err_h <= 1.5 * loss_err_o + floor, (loss_err_h, loss_err_o)
+
+
+def test_scale0_gradient_outliers_are_rare_on_well_conditioned_elements():
+    """Where the fp32 oracle itself is within tolerance of fp64 (no flip in its neighbourhood), the HIP gradient at
+    scale 0 must be too, for all but 1e-3 of those elements (its own, independent flips), and the error that remains
+    after removing the oracle's ill-conditioned elements must still be of the conditioning size."""
+    N, ops, loss_ref, synth = _mods()
+    B, H, W, seed = 2, 192, 640, 22
+    i64, d64, o64, _, _ = _oracle(loss_ref, synth, B, H, W, seed, torch.float64, "md2")
+    i32, d32, o32, _, _ = _oracle(loss_ref, synth, B, H, W, seed, torch.float32, "md2")
+    out, dd = _hip(ops, i32, d32, "md2")
+    out.fin[N.FIN_LOSS].backward()
+    g64, g32, gh = o64[("disp", 0)].grad, o32[("disp", 0)].grad.double(), dd[0].grad.double().cpu()
+    tol = 1e-4 * g64.abs().max().item() + 1e-4 * g64.abs()
+    ok = (g32 - g64).abs() <= tol
+    assert ok.double().mean().item() > 0.99
+    frac = ((gh - g64).abs() > tol)[ok].double().mean().item()
+    assert frac <= 1e-3, frac
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 96, 21), (2, 192, 640, 22), (3, 64, 200, 9)])
+def test_smoothness_term_alone(shape):
+    """K2 by itself: fin[FIN_SMOOTH_S + s] against trainer.py:662-664 + layers.py:207-220 restated in fp64, and the
+    gradient that flows from that entry ONLY (the photometric kernel receives a zero upstream gradient)."""
+    N, ops, loss_ref, synth = _mods()
+    B, H, W, seed = shape
+    inputs, disps = synth.make_loss_case(B, H, W, seed)
+    out, dd = _hip(ops, inputs, disps, "md2")
+    fin = out.fin.detach().cpu()
+    for s in range(4):
+        d64 = disps[s].double().requires_grad_(True)
+        ref = loss_ref.normalised_smooth_loss(d64, inputs[("color", 0, s)].double())
+        ref.backward()
+        got = fin[N.FIN_SMOOTH_S + s].item()
+        assert abs(got - ref.item()) <= 2e-6 * abs(ref.item()), (s, got, ref.item())
+        for d in dd:
+            d.grad = None
+        out.fin[N.FIN_SMOOTH_S + s].backward(retain_graph=True)
+        for j in range(4):
+            g = dd[j].grad
+            if j != s:
+                assert g is None or float(g.abs().max()) == 0.0, "smoothness of scale %d leaked into scale %d" % (s, j)
+        # |dx| is non-differentiable only at exact ties of neighbouring disparities (none in a random field)
+        assert_close_frac(dd[s].grad, d64.grad, rtol=1e-4, atol=1e-5 * d64.grad.abs().max().item(), max_bad_frac=0.0,
+                          max_rel_l2=1e-5, name="smooth grad[%d]" % s)
+    # and the composition: loss/s = reprojection + 1e-3 * smooth / 2^s
+    for s in range(4):
+        want = fin[N.FIN_REPROJ_S + s].item() + 1e-3 * fin[N.FIN_SMOOTH_S + s].item() / (2 ** s)
+        assert abs(fin[N.FIN_LOSS_S + s].item() - want) <= 1e-6 * abs(want)
+
+
+def test_layers_golden_meets_the_hip_path(golden):
+    """tests/golden/layers_small.npz holds the reference's SSIM, get_smooth_loss, disp_to_depth, BackprojectDepth ->
+    Project3D outputs (MD2/layers.py); here the HIP kernels meet them directly (not via the CPU oracle)."""
+    N, ops, loss_ref, synth = _mods()
+    g = golden("layers_small")
+    x, y, disp = np_t(g["x"]).cuda(), np_t(g["y"]).cuda(), np_t(g["disp"]).cuda()
+    K, inv_K, T = np_t(g["K"]).cuda(), np_t(g["inv_K"]).cuda(), np_t(g["T"]).cuda()
+    B, _, H, W = x.shape
+    # depth + sampling grid: the stand-alone warp kernel keeps the reference's op order
+    depth, grid, _ = ops.warp_view(x, disp, K, inv_K, T, H, W)
+    assert_close_frac(depth, np_t(g["depth"]), rtol=1e-6, atol=0, name="depth vs layers.disp_to_depth")
+    assert_close_frac(grid, np_t(g["grid"]), rtol=1e-5, atol=2e-6, name="grid vs Project3D(BackprojectDepth)")
+    # SSIM map: identity pose (T = I) makes the fused kernel's warp the identity, so with auto-masking off
+    #   to_opt = 0.85 * mean_c SSIM(x, y) + 0.15 * mean_c |y - x|      (trainer.py:525-537)
+    # (disparity 0 -> depth 100 m, where Project3D's +1e-7 moves the coordinate by < 1e-7 px)
+    eye = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    far = torch.zeros_like(disp)
+    out = ops.photometric_smooth_loss(y, [x], [eye], K, inv_K, [far], [y], noise=None, automask=False, want_to_opt=True)
+    want = 0.85 * np_t(g["ssim"]).mean(1) + 0.15 * (np_t(g["y"]) - np_t(g["x"])).abs().mean(1)
+    assert_close_frac(out.to_opt[0], want, rtol=1e-4, atol=PIX_ATOL, name="0.85*SSIM+0.15*L1 vs layers.SSIM golden")
+    l1 = ops.photometric_smooth_loss(y, [x], [eye], K, inv_K, [far], [y], noise=None, automask=False, no_ssim=True,
+                                     want_to_opt=True)
+    ssim_hip = (out.to_opt[0] - 0.15 * l1.to_opt[0]) / 0.85
+    assert_close_frac(ssim_hip, np_t(g["ssim"]).mean(1), rtol=1e-4, atol=PIX_ATOL / 0.85, name="SSIM map")
+    # get_smooth_loss(disp, x) is the un-normalised form; K2 returns R_b / (mean_b + 1e-7) per image
+    raw = []
+    for b in range(B):
+        o = ops.photometric_smooth_loss(y[b:b + 1], [x[b:b + 1]], [eye[:1]], K[:1], inv_K[:1], [disp[b:b + 1]],
+                                        [x[b:b + 1]], noise=None)
+        raw.append(o.fin[N.FIN_SMOOTH_S].item() * (disp[b].double().mean().item() + 1e-7))
+    assert abs(np.mean(raw) - float(g["smooth"])) <= 5e-6 * abs(float(g["smooth"]))
+
+
+@pytest.mark.parametrize("variant,name", [("dh", "small"), ("dh", "cfg1"), ("md2", "small")])
+def test_loss_goldens_meet_the_hip_path(golden, variant, name):
+    """HIP against the numbers the reference's own generate_images_pred + compute_losses + backward produced
+    (DH/trainer.py:638-741 for dh; the md2 cfg1 file is covered in test_gpu_kernels.py)."""
+    N, ops, loss_ref, synth = _mods()
+    g = golden("loss_%s_%s" % (variant, name))
+    B, H, W, seed = [int(v) for v in g["shape"]]
+    inputs, disps = synth.make_loss_case(B, H, W, seed)
+    gen = torch.Generator().manual_seed(seed + 100)
+    noise = [torch.randn(B, 1, H, W, generator=gen) * 0.00001 for _ in range(4)]
+    # fp64 anchor for the gradient bound (the golden itself is an fp32 run of the reference)
+    _, _, o64, _, _ = _oracle(loss_ref, synth, B, H, W, seed, torch.float64, variant)
+    for tag, nz in (("nonoise", None), ("noise", noise)):
+        out, dd = _hip(ops, inputs, disps, variant, nz)
+        out.fin[N.FIN_LOSS].backward()
+        f = out.fin.detach().cpu()
+        # dh: one flipped near-tie moves masked-sum / count by (value - mean) / count
+        tol = 2e-5 if variant == "md2" else max(2e-5, 3.0 / (B * H * W))
+        assert abs(f[N.FIN_LOSS].item() - float(g[tag + "_loss"])) <= tol * abs(float(g[tag + "_loss"]))
+        for s in range(4):
+            ref = float(g["%s_loss_%d" % (tag, s)])
+            assert abs(f[N.FIN_LOSS_S + s].item() - ref) <= tol * abs(ref), (s, f[N.FIN_LOSS_S + s].item(), ref)
+            if variant == "dh":
+                ref = float(g["%s_reproj_loss_%d" % (tag, s)])
+                assert abs(f[N.FIN_REPROJ_S + s].item() - ref) <= tol * abs(ref)
+            sel_ref = np.unpackbits(g["%s_identity_selection_%d" % (tag, s)])[:B * H * W].reshape(B, H, W)
+            sel = out.sel[s].cpu().numpy()
+            sel = (sel == 0) if variant == "dh" else (sel > 0)       # DH stores 1 - mask (DH/trainer.py:703)
+            n_diff = int((sel != (sel_ref > 0)).sum())
+            assert n_diff <= max(2, 5e-4 * B * H * W), (s, n_diff)
+            key = "%s_grad_disp_%d" % (tag, s)
+            if key in g.files and tag == "nonoise":
+                g64 = o64[("disp", s)].grad
+                gref = np_t(g[key]).double()
+                e_h, e_r = rel_l2(dd[s].grad, g64), rel_l2(gref, g64)
+                assert e_h <= 1.5 * e_r + 3.0 * g64.abs().max().item() / g64.norm().item(), (s, e_h, e_r)
+        if name == "small" and tag == "nonoise":
+            d_in = to_dev(inputs)
+            for s in range(4):
+                depth, grid, col = ops.warp_view(d_in[("color", "s", 0)], disps[s].cuda(), d_in[("K", 0)],
+                                                 d_in[("inv_K", 0)], d_in["stereo_T"], H, W)
+                assert_close_frac(col, np_t(g["nonoise_warped_%d" % s]), rtol=1e-4, atol=2e-5, max_bad_frac=1e-3,
+                                  name="warped[%d] vs reference grid_sample" % s)
+                if s == 0:
+                    assert_close_frac(depth, np_t(g["nonoise_depth_0"]), rtol=1e-6, atol=0, name="depth_0")
+                    assert_close_frac(grid, np_t(g["nonoise_sample_0"]), rtol=1e-5, atol=2e-6, name="sample_0")
+
+
+def _full_size_inputs(synth, B, H, W, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    left = F.avg_pool2d(torch.rand(B, 3, H + 4, W + 4, device="cuda", generator=g), 5, 1).contiguous()
+    right = (0.9 * torch.roll(left, 8, 3) + 0.1 * F.avg_pool2d(torch.rand(B, 3, H + 4, W + 4, device="cuda", generator=g),
+                                                               5, 1)).contiguous()
+    K, inv_K = synth.make_intrinsics(B, H, W)
+    T = torch.eye(4, device="cuda").repeat(B, 1, 1)
+    T[0::2, 0, 3] = -0.1
+    T[1::2, 0, 3] = 0.1
+    colors = [left if s == 0 else F.avg_pool2d(left, 2 ** s).contiguous() for s in range(4)]
+    disps = [(0.02 + 0.2 * torch.rand(B, 1, H >> s, W >> s, device="cuda", generator=g)) for s in range(4)]
+    return left, right, K.cuda(), inv_K.cuda(), T, colors, disps
+
+
+def test_config4_shape_dh_variant_batch64():
+    """BASELINE config 4 loss shape: DepthHints normalisation, B = 64, 320x1024 -- size-independent properties
+    (bitwise determinism, linearity in the upstream gradient, masked-sum / count identity, count vs masks) and a
+    sampled comparison with the CPU oracle on two images of the batch."""
+    N, ops, loss_ref, synth = _mods()
+    B, H, W = 64, 320, 1024
+    left, right, K, inv_K, T, colors, disps = _full_size_inputs(synth, B, H, W, 7)
+    dl = [d.clone().requires_grad_(True) for d in disps]
+
+    def run(scale, noise=None):
+        for d in dl:
+            d.grad = None
+        o = ops.photometric_smooth_loss(left, [right], [T], K, inv_K, dl, colors, variant="dh", noise=noise,
+                                        want_to_opt=True)
+        (o.fin[N.FIN_LOSS] * scale).backward()
+        return o, [d.grad.clone() for d in dl]
+    o1, g1 = run(1.0)
+    o1b, g1b = run(1.0)
+    o3, g3 = run(3.0)
+    assert torch.equal(o1.fin, o1b.fin) and all(torch.equal(a, b) for a, b in zip(g1, g1b)), "not bitwise reproducible"
+    for a, b in zip(g1, g3):
+        assert torch.isfinite(a).all()
+        torch.testing.assert_close(b, 3 * a, rtol=1e-5, atol=1e-5 * a.abs().max().item())
+    f = o1.fin.detach().double().cpu()
+    for s in range(4):
+        chosen = o1.sel[s] > 0
+        cnt = float(chosen.sum())
+        assert abs(f[N.FIN_COUNT_S + s].item() - cnt) <= 1e-6 * cnt + 2
+        masked_sum = float(o1.to_opt[s].double().sum())                  # to_opt = reprojection * mask (DH :705-708)
+        assert abs(f[N.FIN_REPROJ_S + s].item() - masked_sum / (cnt + 1e-7)) <= 2e-5 * abs(f[N.FIN_REPROJ_S + s].item())
+        assert float(o1.to_opt[s][~chosen].abs().max()) == 0.0
+    # oracle on images 0 and 1 of the batch: DH's loss is a ratio of batch sums, so compare the per-pixel maps
+    sub = slice(0, 2)
+    inputs = {("color", 0, s): colors[s][sub].cpu() for s in range(4)}
+    inputs[("color", "s", 0)] = right[sub].cpu()
+    inputs[("K", 0)], inputs[("inv_K", 0)], inputs["stereo_T"] = K[sub].cpu(), inv_K[sub].cpu(), T[sub].cpu()
+    outputs = {("disp", s): disps[s][sub].cpu() for s in range(4)}
+    loss_ref.generate_images_pred(inputs, outputs)
+    _, maps = loss_ref.compute_losses(inputs, outputs, noise=None, variant="dh")
+    for s in range(4):
+        got, want = o1.to_opt[s][sub].cpu(), maps[s].reshape(2, H, W)
+        same = (got > 0) == (want > 0)
+        assert same.double().mean().item() > 1 - 5e-4
+        assert_close_frac(got[same], want[same], rtol=1e-4, atol=PIX_ATOL, max_bad_frac=1e-5, name="dh map[%d]" % s)
+
+
+def test_config3_shape_l0_supervised_full_size_step(tmp_path):
+    """BASELINE config 3 on one GPU: --adv_train --norm_type l_0 --supervised_adv at 320x1024, train batch 32, attack
+    batch 12, 10 (<= 20) L0 iterations.  One full iteration: finite losses with the reference's keys, weights and
+    patch updated, L0 budget respected, and the loss part reproducible bit for bit on the same batch."""
+    from depthmodelhardening_amd import _native as N
+    from depthmodelhardening_amd.options import MonodepthOptions
+    from depthmodelhardening_amd.trainer import Trainer
+    argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "320", "--width", "1024",
+            "--batch_size", "32", "--learning_rate", "1e-5", "--adv_train", "--norm_type", "l_0", "--supervised_adv",
+            "--weights_init", "scratch", "--log_dir", str(tmp_path), "--model_name", "cfg3", "--synthetic_len", "64"]
+    torch.manual_seed(11)
+    tr = Trainer(MonodepthOptions().parse(argv), device=torch.device("cuda"))
+    tr.set_train()
+    assert tr.bucket.numel == 14329236
+    w0 = tr.models["encoder"].encoder.layer1[0].conv1.weight.detach().clone()
+    p0 = tr.dataset.obj_img_adv.clone()
+    losses = tr.train_step()
+    torch.cuda.synchronize()
+    assert {"loss", "sup_loss", "loss/0", "loss/1", "loss/2", "loss/3"} <= set(losses)
+    for k, v in losses.items():
+        assert torch.isfinite(v).all(), k
+    assert float(losses["sup_loss"]) > 0
+    assert not torch.equal(tr.models["encoder"].encoder.layer1[0].conv1.weight, w0)
+    assert not torch.equal(tr.dataset.obj_img_adv, p0)
+    # L0 attack: the finalised patch differs from the benign object on a minority of texels (phy_obj_atk_l0.py:143-150)
+    changed = ((tr.dataset.obj_img_adv - tr.dataset.obj_img_ben).abs().sum(1) > 0).float().mean().item()
+    assert 0.0 < changed < 0.9, changed
+    assert tr.models["encoder"].training and tr.gt_model.training is False
+    # the loss path on a fixed batch: run-to-run bitwise equality and count consistency (selection maps vs fin)
+    inputs = tr.dataset.next_batch(32)
+    with torch.no_grad():
+        feats = tr.models["encoder"](inputs["color_aug", 0, 0])
+        disp = tr.models["depth"](feats)
+    outs = []
+    for _ in range(2):
+        o = {("disp", s): disp[("disp", s)].detach().clone().requires_grad_(True) for s in range(4)}
+        torch.manual_seed(5)                            # same Philox stream for the tie-break noise
+        ls = tr.compute_losses(inputs, o)
+        ls["loss"].backward()
+        outs.append((ls, o))
+    (la, oa), (lb, ob) = outs
+    assert torch.equal(la["loss"], lb["loss"])
+    for s in range(4):
+        assert torch.equal(oa[("disp", s)].grad, ob[("disp", s)].grad)
+        sel = oa["identity_selection/%d" % s]
+        assert sel.shape == (32, 320, 1024) and float(sel.min()) >= 0 and float(sel.max()) <= 1

@@ -74,8 +74,7 @@ def test_adversarial_train_steps(tmp_path, norm_type):
     tr.epoch = 0
     tr.save_model()
     folder = os.path.join(str(tmp_path), "t", "models", "weights_0")
-    assert sorted(os.listdir(folder)) == ["DepthModelWrapper.pth", "adam.pth", "contrastive_learning.pth", "depth.pth",
-                                          "encoder.pth"]
+    assert sorted(os.listdir(folder)) == ["adam.pth", "contrastive_learning.pth", "depth.pth", "encoder.pth"]
     enc = torch.load(os.path.join(folder, "encoder.pth"))
     assert enc["height"] == 64 and enc["width"] == 192 and enc["use_stereo"] is True
     tr2 = _trainer(tmp_path, ["--adv_train", "--norm_type", norm_type, "--supervised_adv", "--contrastive_learning",

@@ -12,7 +12,19 @@ def to_dev(x, dev="cuda"):
     return x
 
 
-def assert_close_frac(got, want, rtol=1e-4, atol=1e-6, max_bad_frac=0.0, name=""):
+def rel_l2(got, want):
+    """||got - want|| / ||want|| over ALL elements, in float64."""
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    d = want.norm().item()
+    return (got - want).norm().item() / d if d > 0 else (got - want).norm().item()
+
+
+def bad_frac(got, want, rtol, atol):
+    got, want = got.detach().double().cpu(), want.detach().double().cpu()
+    return ((got - want).abs() > (atol + rtol * want.abs())).double().mean().item()
+
+
+def assert_close_frac(got, want, rtol=1e-4, atol=1e-6, max_bad_frac=0.0, name="", max_rel_l2=None):
     """|got-want| <= atol + rtol*|want| for all but ``max_bad_frac`` of the elements, and the
     relative L2 error is below 10*rtol.  The outlier allowance exists for quantities whose
     derivative is discontinuous in the inputs (bilinear floor(), min/argmin ties)."""
@@ -27,6 +39,8 @@ def assert_close_frac(got, want, rtol=1e-4, atol=1e-6, max_bad_frac=0.0, name=""
     rel_l2 = (got - want).norm().item() / denom if denom > 0 else (got - want).norm().item()
     assert frac <= max_bad_frac, "%s: %.3g of elements out of tolerance (max err %.3g, rel-L2 %.3g)" % (
         name, frac, err.max().item(), rel_l2)
+    if max_rel_l2 is not None:     # untrimmed: every element counts, outliers included
+        assert rel_l2 <= max_rel_l2, "%s: rel-L2 over all elements %.3g > %.3g" % (name, rel_l2, max_rel_l2)
     # rel-L2 over the elements that are in tolerance (all of them when no outliers are allowed)
     good = ~bad
     dg = want[good].norm().item()
