@@ -29,11 +29,23 @@
 //
 // Reference semantics: MD2/trainer.py:472-537,589-660; MD2/layers.py:16-25,139-198,223-253;
 // DH/trainer.py:557-590,638-708.  (file:line relative to /root/reference/DepthNetworks/...)
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.hpp"
 
 using namespace dmh;
 
 namespace {
+
+// min waves per SIMD requested from the register allocator (tuning knobs)
+#ifndef DMH_FWD_WAVES
+#define DMH_FWD_WAVES 1
+#endif
+#ifndef DMH_BWD_WAVES
+#define DMH_BWD_WAVES 2
+#endif
 
 constexpr int NT = 256;            // 4 independent waves per workgroup, one strip tile each; no barriers
 constexpr int WPB = NT / WAVE;
@@ -182,14 +194,13 @@ __device__ __forceinline__ Tap make_tap(float dx, float dy, int x, int y, int W,
 
 // ---------------------------------------------------------------------------------------------- disparity rows
 // F.interpolate(disp, [H,W], mode="bilinear", align_corners=False) (MD2/trainer.py:481-482) along a strip: the
-// x geometry is a per-lane constant, the two source rows are cached (x-interpolated) until the row pair changes.
+// x geometry is a per-lane constant.
 struct DispGeo {
     int Hs, Ws, f;        // f = H / Hs (exact power of two, checked on the host); 1 = same size
     float rh;
     int x0, x1;           // per lane
     float lx;
 };
-struct DispRow { float dA, dB; int y0; };
 
 __device__ __forceinline__ DispGeo disp_geo(int Hs, int Ws, int H, int W, int xr) {
     DispGeo g;
@@ -219,7 +230,34 @@ __device__ __forceinline__ RowLerp row_lerp(const DispGeo& g, int yr) {
     return r;
 }
 
-__device__ __forceinline__ float disp_value(rsrc_t rd, const DispGeo& g, DispRow& c, int yr) {
+// Raw disparity texels of one image row, fetched one row ahead of their use (the projection -> gather chain of the
+// next row then starts from registers instead of from a memory round trip).
+struct DispPre { float v00, v01, v10, v11; };
+__device__ __forceinline__ DispPre disp_fetch(rsrc_t rd, const DispGeo& g, int yr) {
+    DispPre p;
+    if (g.f == 1) {
+        p.v00 = ldb(rd, (unsigned)(yr * g.Ws + g.x0) * 4u, 0u);
+        p.v01 = p.v10 = p.v11 = 0.f;
+        return p;
+    }
+    const RowLerp r = row_lerp(g, yr);
+    p.v00 = ldb(rd, (unsigned)(r.y0 * g.Ws + g.x0) * 4u, 0u);
+    p.v01 = ldb(rd, (unsigned)(r.y0 * g.Ws + g.x1) * 4u, 0u);
+    p.v10 = ldb(rd, (unsigned)(r.y1 * g.Ws + g.x0) * 4u, 0u);
+    p.v11 = ldb(rd, (unsigned)(r.y1 * g.Ws + g.x1) * 4u, 0u);
+    return p;
+}
+// same association as ATen's upsample_bilinear2d
+__device__ __forceinline__ float disp_finish(const DispPre& p, const DispGeo& g, int yr) {
+    if (g.f == 1) return p.v00;
+    const RowLerp r = row_lerp(g, yr);
+    const float hx = 1.f - g.lx;
+    return (1.f - r.ly) * (hx * p.v00 + g.lx * p.v01) + r.ly * (hx * p.v10 + g.lx * p.v11);
+}
+
+// Forward kernel: the x-interpolated source row pair is cached until the pair changes (a uniform branch).
+struct DispRow { float dA, dB; int y0; };
+__device__ __forceinline__ float disp_value_cached(rsrc_t rd, const DispGeo& g, DispRow& c, int yr) {
     if (g.f == 1) return ldb(rd, (unsigned)(yr * g.Ws + g.x0) * 4u, 0u);
     const RowLerp r = row_lerp(g, yr);
     if (r.y0 != c.y0) {
@@ -231,6 +269,17 @@ __device__ __forceinline__ float disp_value(rsrc_t rd, const DispGeo& g, DispRow
         c.dB = hx * v10 + g.lx * v11;
     }
     return (1.f - r.ly) * c.dA + r.ly * c.dB;
+}
+
+// Branch-free: the two source rows are re-read every image row (they sit in L1; a cached row pair would cost a
+// branch and register copies in the hot loop).  Same association as ATen's upsample_bilinear2d.
+__device__ __forceinline__ float disp_value(rsrc_t rd, const DispGeo& g, int yr) {
+    if (g.f == 1) return ldb(rd, (unsigned)(yr * g.Ws + g.x0) * 4u, 0u);
+    const RowLerp r = row_lerp(g, yr);
+    const float v00 = ldb(rd, (unsigned)(r.y0 * g.Ws + g.x0) * 4u, 0u), v01 = ldb(rd, (unsigned)(r.y0 * g.Ws + g.x1) * 4u, 0u);
+    const float v10 = ldb(rd, (unsigned)(r.y1 * g.Ws + g.x0) * 4u, 0u), v11 = ldb(rd, (unsigned)(r.y1 * g.Ws + g.x1) * 4u, 0u);
+    const float hx = 1.f - g.lx;
+    return (1.f - r.ly) * (hx * v00 + g.lx * v01) + r.ly * (hx * v10 + g.lx * v11);
 }
 
 // ---------------------------------------------------------------------------------------------- SSIM
@@ -282,6 +331,10 @@ struct KArgs {
 // Rows per strip: tall strips amortise the halo rows, but the launch should still be several waves per SIMD deep.
 __host__ inline int pick_rows(int B, int H, int W, int out_cols) {
     const int tx = (W + out_cols - 1) / out_cols;
+    if (const char* e = getenv("DMH_K1_ROWS")) {   // tuning knob (tools/kbench.py)
+        const int v = atoi(e);
+        if (v >= 2 && v <= 1024) return v;
+    }
     int R = 32;
     while (R > 8 && (int64_t)B * tx * ((H + R - 1) / R) < 4096) R >>= 1;
     return R;
@@ -304,7 +357,7 @@ struct FRow {   // row sums of one image row: target (y, y^2) and per stream (x,
 // ------------------------------------------------------------------------------------------------ forward
 // NF source frames, SPP scales per pass (NF * (1 + SPP) streams of rolling row sums live in registers).
 template <int NF, int SPP>
-__global__ __launch_bounds__(NT) void photo_fwd_kernel(const KArgs k) {
+__global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArgs k) {
     constexpr int NSTR = NF * (1 + SPP);
     const dmh_photo_args& a = k.a;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -408,7 +461,7 @@ __global__ __launch_bounds__(NT) void photo_fwd_kernel(const KArgs k) {
 #pragma unroll
             for (int j = 0; j < SPP; ++j) {
                 if (s0 + j >= NS) break;
-                const float d = disp_value(rd[j], dg[j], dr[j], yr);
+                const float d = disp_value_cached(rd[j], dg[j], dr[j], yr);
                 const float sd = fmaf(k.dmul, d, k.min_disp);
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
@@ -516,16 +569,17 @@ struct BRow {   // record of one processed row: its row sums, the coefficient ro
     float ch[3][3];          // [channel][a0, ax, ay] horizontal sums (with the reflection fold)
     float xv[3], yv[3], J[3];
     unsigned sel;            // selection field of this row for the wave's scale
+    // operands of THIS row, fetched while the previous row was processed
+    DispPre pd;
+    float ptv[3];
+    unsigned psel;           // selection byte of the row above (the coefficient row)
 };
 
-template <int NF>
-__global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
-    __shared__ float s_row[WPB][2][WAVE];     // horizontal up-sampling adjoint: g*(1-lx), g*lx of one row
+// SAME: the wave's scale has the image resolution (gradient written directly); otherwise the up-sampling adjoint runs.
+template <int NF, bool SAME>
+__device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, const int tile, float* sA, float* sB) {
     const dmh_photo_args& a = k.a;
-    const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x >> 6;
-    const int item = wave_item();
-    if (item >= k.ntiles * a.num_scales) return;
-    const int s = item / k.ntiles, tile = item - s * k.ntiles;
+    const int lane = threadIdx.x & (WAVE - 1);
     const int H = a.H, W = a.W, B = a.B;
     const int per_img = k.tiles_x * k.tiles_y;
     const int b = tile / per_img, tt = tile - b * per_img, ty = tt / k.tiles_x, tx = tt - ty * k.tiles_x;
@@ -534,8 +588,7 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
     const int xr = reflect_idx(col, W);
     const bool col_in = col >= 0 && col < W;
     const bool out_lane = lane >= 2 && lane < 2 + BW_OUT && col < W;
-    const int rows_out = min(k.R, H - Y0);
-    const int nrows = rows_out + 4;
+    const int nrows = min(k.R, H - Y0) + 4;
 
     const unsigned plane = (unsigned)(H * W) * 4u;
     const size_t img_off = (size_t)b * 3 * H * W;
@@ -546,35 +599,26 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
     up *= (a.variant == DMH_VARIANT_MD2) ? 1.0f / ((float)B * (float)H * (float)W) : 1.0f / (k.fin[DMH_FIN_COUNT_S + s] + 1e-7f);
     up = uni(up);
     const float l1w = up * (no_ssim ? (1.f / 3.f) : (0.15f / 3.f));
-    const float gs0 = up * (0.85f / 3.f);
+    const float gs0 = no_ssim ? 0.f : up * (0.85f / 3.f);
     const float mxl = (col == 1) ? 2.f : 1.f, mxr = (col == W - 2) ? 2.f : 1.f;   // reflection-pad adjoint
 
     const int Hs = a.Hs[s], Ws = a.Ws[s];
     const DispGeo dg = disp_geo(Hs, Ws, H, W, xr);
     const rsrc_t rd = make_rsrc(a.disp[s] + (size_t)b * Hs * Ws, (unsigned)(Hs * Ws) * 4u);
-    const bool same = dg.f == 1;
-    // geometry of this strip's block of low-resolution texels (coarse scales)
-    const DispGeo dgc = disp_geo(Hs, Ws, H, W, min(max(col, 0), W - 1));   // un-reflected column for the adjoint weights
+    // this strip's block of low-resolution texels (coarse scales)
     const int jlo = row_lerp(dg, Y0).y0;
     const float rw = (float)Ws / (float)W;
     const int ilo = (int)fmaxf(rw * ((float)X0 + 0.5f) - 0.5f, 0.f);
     const int SX = k.sx_slots[s], SY = k.sy_slots[s];
-    float* stage = same ? nullptr : k.stage[s] + (size_t)tile * SX * SY;
+    float* stage = SAME ? nullptr : k.stage[s] + (size_t)tile * SX * SY;
+    const unsigned sel_shift = 2u * (unsigned)s;
 
     for (int f = 0; f < NF; ++f) {
         const rsrc_t rs = make_rsrc(a.source[f] + img_off, 3u * plane);
         const CamW cam = load_cam_w(a.K, a.inv_K, a.T[f], b);
         const LaneProj lp = lane_proj(cam, xr);
         const unsigned fsel = (unsigned)(1 + f);
-        DispRow dr;
-        dr.y0 = -1;
-        dr.dA = dr.dB = 0.f;
-        BRow recA, recB;
-#pragma unroll
-        for (int c = 0; c < 3; ++c)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) recA.ch[c][q] = recB.ch[c][q] = 0.f;
-        recA.sel = recB.sel = 0u;
+        BRow recA, recB, recC;
         float accA = 0.f, accB = 0.f;     // vertical up-sampling adjoint: low rows ja and ja + 1
         int ja = jlo;
 
@@ -586,13 +630,26 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
             }
         };
 
-        auto step = [&](const int kk, BRow& older, const BRow& newer) __attribute__((always_inline)) {
+        // One image row r = Y0 - 2 + kk.  `cur` receives this row's record; `newer` / `older` are the records of the
+        // rows one / two above.  STAGE 0: rows only; 1: + coefficient fields of row r-1; 2: + gradient of row r-2.
+        auto prefetch = [&](const int kk, BRow& rec) __attribute__((always_inline)) {
             const int r = Y0 - 2 + kk;
             const int yr = reflect_idx(r, H);
             const unsigned rowoff = (unsigned)(yr * W + xr) * 4u;
-            BRow cur;
+            rec.pd = disp_fetch(rd, dg, yr);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) rec.ptv[c] = ldb(rt, rowoff, plane * (unsigned)c);
+            const int rc = r - 1;
+            const bool p_in = col_in && rc >= 0 && rc < H;
+            rec.psel = p_in ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsel, (unsigned)(rc * W + col), 0, 0) : 0u;
+        };
+        auto step = [&](const int kk, BRow& older, const BRow& newer, BRow& cur, auto stage_tag) __attribute__((always_inline)) {
+            constexpr int STAGE = decltype(stage_tag)::value;
+            const int r = Y0 - 2 + kk;
+            const int yr = reflect_idx(r, H);
             // (1) this row: target, warp, chain factors J_c = d warped_c / d disp
-            const float d = disp_value(rd, dg, dr, yr);
+            const float d = disp_finish(cur.pd, dg, yr);
+            prefetch(kk + 1, older);        // `older` is the record of the next row; its sums are still read below
             const float sd = fmaf(k.dmul, d, k.min_disp);
             const RowProj rp = row_proj(cam, lp, yr);
             const float rden = fast_rcp(fmaf(sd, cam.m, rp.az));
@@ -608,7 +665,7 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
                 const unsigned po = plane * (unsigned)c;
                 const float v00 = ldb(rs, t.o00, po), v01 = ldb(rs, t.o01, po), v10 = ldb(rs, t.o10, po), v11 = ldb(rs, t.o11, po);
                 cur.xv[c] = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11) - SHIFT;
-                cur.yv[c] = ldb(rt, rowoff, po) - SHIFT;
+                cur.yv[c] = cur.ptv[c] - SHIFT;
                 const float dvx = (v01 - v00) * gy + (v11 - v10) * t.ty, dvy = (v10 - v00) * gx + (v11 - v01) * t.tx;
                 cur.J[c] = dvx * jx + dvy * jy;
                 // (2) row sums
@@ -620,14 +677,11 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
             }
             // (3) coefficient fields of the row above (centre row rc): d v(p) / d x_q = a0 + ay*y_q + ax*x_q for every
             //     pixel q of p's window, v = clamp((1 - n/d)/2)
-            const int rc = r - 1;
             cur.sel = 0u;
-            if (kk >= 2) {
-                const bool p_in = col_in && rc >= 0 && rc < H;
-                unsigned selb = 0u;
-                if (p_in) selb = (__builtin_amdgcn_raw_buffer_load_b8(rsel, (unsigned)(rc * W + col), 0, 0) >> (2 * s)) & 3u;
+            if constexpr (STAGE >= 1) {
+                const unsigned selb = (cur.psel >> sel_shift) & 3u;     // 0 outside the image
                 cur.sel = selb;
-                const bool on = p_in && selb == fsel && !no_ssim;
+                const float gate = (selb == fsel) ? gs0 : 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float Sx = older.hx[c] + newer.hx[c] + cur.hx[c], Sxx = older.hxx[c] + newer.hxx[c] + cur.hxx[c];
@@ -637,13 +691,10 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
                     const float invd = fast_rcp(q.B1 * q.B2);
                     const float rr = (q.A1 * q.A2) * invd;
                     const float v = fmaf(-0.5f, rr, 0.5f);
-                    float a0 = 0.f, cax = 0.f, cay = 0.f;
-                    if (on && v >= 0.f && v <= 1.f) {   // clamp passes the gradient on the closed interval
-                        const float gsd = gs0 * invd;
-                        a0 = -gsd * (fmaf(tw.my, q.A2, -q.A1 * tw.sy) - rr * fmaf(q.mx, q.B2, -q.B1 * Sx));
-                        cay = -9.f * gsd * q.A1;
-                        cax = 9.f * gsd * rr * q.B1;
-                    }
+                    const float gsd = (v >= 0.f && v <= 1.f) ? gate * invd : 0.f;   // clamp passes the gradient on the closed interval
+                    const float a0 = -gsd * (fmaf(tw.my, q.A2, -q.A1 * tw.sy) - rr * fmaf(q.mx, q.B2, -q.B1 * Sx));
+                    const float cay = -9.f * gsd * q.A1;
+                    const float cax = 9.f * gsd * rr * q.B1;
                     cur.ch[c][0] = fmaf(mxl, lane_prev(a0), a0) + mxr * lane_next(a0);
                     cur.ch[c][1] = fmaf(mxl, lane_prev(cax), cax) + mxr * lane_next(cax);
                     cur.ch[c][2] = fmaf(mxl, lane_prev(cay), cay) + mxr * lane_next(cay);
@@ -653,24 +704,23 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
                 for (int c = 0; c < 3; ++c) cur.ch[c][0] = cur.ch[c][1] = cur.ch[c][2] = 0.f;
             }
             // (4) gradient of the row two above (rq): 3x3 box sums of the coefficient fields, then the chain
-            if (kk >= 4) {
+            if constexpr (STAGE >= 2) {
                 const int rq = r - 2;
                 const float myt = (rq == 1) ? 2.f : 1.f, myb = (rq == H - 2) ? 2.f : 1.f;
+                const float l1g = (newer.sel == fsel) ? l1w : 0.f;
                 float g = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float S0 = fmaf(myt, older.ch[c][0], newer.ch[c][0]) + myb * cur.ch[c][0];
                     const float Sxc = fmaf(myt, older.ch[c][1], newer.ch[c][1]) + myb * cur.ch[c][1];
                     const float Syc = fmaf(myt, older.ch[c][2], newer.ch[c][2]) + myb * cur.ch[c][2];
+                    const float df = older.xv[c] - older.yv[c];
                     float gw = fmaf(older.xv[c], Sxc, fmaf(older.yv[c], Syc, S0));
-                    if (newer.sel == fsel) {
-                        const float df = older.xv[c] - older.yv[c];
-                        gw += l1w * (df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f));
-                    }
+                    gw = fmaf(l1g, df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f), gw);
                     g = fmaf(gw, older.J[c], g);
                 }
                 if (!out_lane) g = 0.f;
-                if (same) {
+                if constexpr (SAME) {
                     if (out_lane) {
                         float* p = k.g_disp[s] + ((size_t)b * H + rq) * W + col;
                         *p = (f > 0) ? *p + g : g;
@@ -678,11 +728,9 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
                 } else {
                     // (5) adjoint of the bilinear up-sampling.  Horizontal: lanes publish g*(1-lx), g*lx; low texel i
                     //     gathers its 2f columns.  Vertical: two running rows, flushed when the row pair advances.
-                    float* sA = s_row[wv][0];
-                    float* sB = s_row[wv][1];
                     __builtin_amdgcn_wave_barrier();
-                    sA[lane] = g * (1.f - dgc.lx);
-                    sB[lane] = g * dgc.lx;
+                    sA[lane] = g * (1.f - dg.lx);
+                    sB[lane] = g * dg.lx;
                     __builtin_amdgcn_wave_barrier();
                     const int i = ilo + lane;
                     float h = 0.f;
@@ -711,17 +759,37 @@ __global__ __launch_bounds__(NT) void photo_bwd_kernel(const KArgs k) {
                     else accA = fmaf(rl.ly, h, accA);
                 }
             }
-            older = cur;
         };
-        for (int kk = 0; kk < nrows; kk += 2) {
-            step(kk, recA, recB);
-            if (kk + 1 < nrows) step(kk + 1, recB, recA);
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        using S2 = std::integral_constant<int, 2>;
+        // record of row kk lives in rec[kk % 3]: no copies between rows
+        prefetch(0, recA);
+        step(0, recB, recC, recA, S0());
+        step(1, recC, recA, recB, S0());
+        step(2, recA, recB, recC, S1());
+        step(3, recB, recC, recA, S1());
+        for (int kk = 4; kk < nrows; kk += 3) {
+            step(kk, recC, recA, recB, S2());
+            if (kk + 1 < nrows) step(kk + 1, recA, recB, recC, S2());
+            if (kk + 2 < nrows) step(kk + 2, recB, recC, recA, S2());
         }
-        if (!same) {
+        if constexpr (!SAME) {
             flush(ja, accA);
             if (ja + 1 < Hs) flush(ja + 1, accB);
         }
     }
+}
+
+template <int NF>
+__global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArgs k) {
+    __shared__ float s_row[WPB][2][WAVE];     // horizontal up-sampling adjoint: g*(1-lx), g*lx of one row
+    const int wv = threadIdx.x >> 6;
+    const int item = wave_item();
+    if (item >= k.ntiles * k.a.num_scales) return;
+    const int s = item / k.ntiles, tile = item - s * k.ntiles;
+    if (k.a.Hs[s] == k.a.H) photo_bwd_strip<NF, true>(k, s, tile, s_row[wv][0], s_row[wv][1]);
+    else photo_bwd_strip<NF, false>(k, s, tile, s_row[wv][0], s_row[wv][1]);
 }
 
 // Coarse scales: add the (<= 4) overlapping strip blocks of every low-resolution texel in a fixed order.

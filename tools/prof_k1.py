@@ -21,22 +21,20 @@ lib = N.lib()
 cfg = dict(F=1, NS=4, min_depth=0.1, max_depth=100.0, variant="md2", automask=True, no_ssim=False, smooth_wt=1e-3, want_to_opt=False, noise_mode=noise_mode, seed=1, offset=0)
 pa = ops._photo_args(cfg, left, [right], [T], K, inv_K, disps, ())
 sm = ops._smooth_args(disps, colors)
-sel = [torch.empty(B, H, W, device=dev) for _ in range(4)]
+sel = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
 pp = torch.empty(lib.dmh_photo_partials_size(B, H, W, 4), device=dev)
 sp = torch.empty(lib.dmh_smooth_partials_size(C.byref(sm)), device=dev)
 fin = torch.empty(N.FIN_SIZE, device=dev); sst = torch.empty(4, B, 2, device=dev)
 gvec = torch.zeros(N.FIN_SIZE, device=dev); gvec[0] = 1.0
-g_up = [torch.empty(B, H, W, device=dev) for _ in range(4)]
-g_disp = [g_up[0].view(B, 1, H, W)] + [torch.empty_like(d) for d in disps[1:]]
+g_disp = [torch.empty_like(d) for d in disps]
+stage = torch.empty(lib.dmh_photo_stage_size(C.byref(pa)), device=dev)
 st = N.stream()
-selp, nullp, gupp, gdp = N.ptr_array(sel), N.ptr_array([None] * 4), N.ptr_array(g_up), N.ptr_array(g_disp)
+nullp, gdp = N.ptr_array([None] * 4), N.ptr_array(g_disp)
 for _ in range(reps):
-    N.check(lib.dmh_photo_loss_fwd(C.byref(pa), selp, nullp, N.ptr(pp), st))
+    N.check(lib.dmh_photo_loss_fwd(C.byref(pa), N.ptr(sel), nullp, N.ptr(pp), st))
     N.check(lib.dmh_smooth_loss_fwd(C.byref(sm), N.ptr(sp), st))
     N.check(lib.dmh_loss_finalize(N.ptr(pp), N.ptr(sp), B, H, W, C.byref(sm), 0, 1e-3, N.ptr(fin), N.ptr(sst), st))
-    N.check(lib.dmh_photo_loss_bwd(C.byref(pa), selp, N.ptr(gvec), N.ptr(fin), gupp, st))
-    for s in range(1, 4):
-        N.check(lib.dmh_upsample_bilinear_adjoint(N.ptr(g_up[s]), N.ptr(g_disp[s]), B, H, W, H >> s, W >> s, 0, st))
+    N.check(lib.dmh_photo_loss_bwd(C.byref(pa), N.ptr(sel), N.ptr(gvec), N.ptr(fin), N.ptr(stage), gdp, st))
     N.check(lib.dmh_smooth_loss_bwd(C.byref(sm), N.ptr(gvec), N.ptr(sst), 1e-3, gdp, 1, st))
 torch.cuda.synchronize()
 print("loss", float(fin[0]))
