@@ -39,7 +39,8 @@ class SmoothArgs(C.Structure):
 class PasteArgs(C.Structure):
     _fields_ = [("scene", _fp), ("scene_bstride", C.c_int64), ("patch", _fp), ("pmask", _fp), ("coeffs", _fp),
                 ("N", C.c_int), ("SH", C.c_int), ("SW", C.c_int), ("PH", C.c_int), ("PW", C.c_int),
-                ("OH", C.c_int), ("OW", C.c_int), ("l_pad", C.c_int), ("t_pad", C.c_int), ("mode", C.c_int)]
+                ("OH", C.c_int), ("OW", C.c_int), ("l_pad", C.c_int), ("t_pad", C.c_int), ("mode", C.c_int),
+                ("flip", _fp)]
 
 
 _PtrArr = _fp * MAX_SCALES

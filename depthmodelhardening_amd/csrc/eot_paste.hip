@@ -99,7 +99,9 @@ __global__ __launch_bounds__(NT) void paste_fwd_kernel(const dmh_paste_args a, f
     const int n = blockIdx.y;
     const int idx = blockIdx.x * NT + threadIdx.x;
     if (idx >= a.OH * a.OW) return;
-    const int oy = idx / a.OW, ox = idx - oy * a.OW;
+    const int oy = idx / a.OW;
+    int ox = idx - oy * a.OW;
+    if (a.flip && a.flip[n]) ox = a.OW - 1 - ox;   // compute the mirrored source pixel, store at idx
     const Homog m = load_homog(a.coeffs + n * 8, a.SW, a.SH);
     const RTap r = resize_tap(oy, ox, a.SH, a.SW, a.OH, a.OW);
     const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW;
@@ -151,7 +153,9 @@ __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, c
     const int n = blockIdx.y;
     const int idx = blockIdx.x * NT + threadIdx.x;
     if (idx >= a.OH * a.OW) return;
-    const int oy = idx / a.OW, ox = idx - oy * a.OW;
+    const int oy = idx / a.OW;
+    int ox = idx - oy * a.OW;
+    if (a.flip && a.flip[n]) ox = a.OW - 1 - ox;
     const Homog m = load_homog(a.coeffs + n * 8, a.SW, a.SH);
     const RTap r = resize_tap(oy, ox, a.SH, a.SW, a.OH, a.OW);
     const size_t ohw = (size_t)a.OH * a.OW, phw = (size_t)a.PH * a.PW;

@@ -331,12 +331,13 @@ struct KArgs {
 // Rows per strip: tall strips amortise the halo rows, but the launch should still be several waves per SIMD deep.
 __host__ inline int pick_rows(int B, int H, int W, int out_cols) {
     const int tx = (W + out_cols - 1) / out_cols;
+    const int64_t want = out_cols == FW_OUT ? 8192 : 4096;   // forward strips are 1 wave each, backward strips 1 per scale
     if (const char* e = getenv("DMH_K1_ROWS")) {   // tuning knob (tools/kbench.py)
         const int v = atoi(e);
         if (v >= 2 && v <= 1024) return v;
     }
     int R = 32;
-    while (R > 8 && (int64_t)B * tx * ((H + R - 1) / R) < 4096) R >>= 1;
+    while (R > 8 && (int64_t)B * tx * ((H + R - 1) / R) < want) R >>= 1;
     return R;
 }
 
@@ -787,7 +788,9 @@ __global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArg
     const int wv = threadIdx.x >> 6;
     const int item = wave_item();
     if (item >= k.ntiles * k.a.num_scales) return;
-    const int s = item / k.ntiles, tile = item - s * k.ntiles;
+    // scale fastest: the waves of one workgroup take the scales of ONE strip and share its target / source / selection
+    // lines in L1 and L2 (the opposite order re-fetched them per scale: 1.8x the algorithmic traffic, profiles/README.md)
+    const int tile = item / k.a.num_scales, s = item - tile * k.a.num_scales;
     if (k.a.Hs[s] == k.a.H) photo_bwd_strip<NF, true>(k, s, tile, s_row[wv][0], s_row[wv][1]);
     else photo_bwd_strip<NF, false>(k, s, tile, s_row[wv][0], s_row[wv][1]);
 }
@@ -928,7 +931,9 @@ int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_op
     k.partials = partials;
     const dim3 grid((k.ntiles + WPB - 1) / WPB), block(NT);
     switch (a->num_frames) {
-        case 1: hipLaunchKernelGGL((photo_fwd_kernel<1, 4>), grid, block, 0, (hipStream_t)stream, k); break;
+        // one source frame: two passes of two scales (3 streams, ~160 VGPRs, 3 waves/SIMD) beat one pass of four (5 streams,
+        // 229 VGPRs, 2 waves/SIMD) by 10 % although the identity and target sums are formed twice (profiles/README.md)
+        case 1: hipLaunchKernelGGL((photo_fwd_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, k); break;
         case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, k); break;
         default: hipLaunchKernelGGL((photo_fwd_kernel<3, 1>), grid, block, 0, (hipStream_t)stream, k); break;
     }

@@ -8,10 +8,13 @@ Stands in for ``KITTIRAWDataset``/``MonoDataset`` (MD2/datasets/mono_dataset.py:
   update_adv_obj(scene_imgs)                                mono_dataset.py:178-184
 
 ``next_batch`` is the GPU-side version of ``prep_adv_data`` (mono_dataset.py:186-265, SURVEY.md section 8f
-rank 1): the adversarial object is pasted into the left view, the benign one into the right view and into
+rank 1): the adversarial object is pasted into frame 0, the benign one into the opposite stereo view and into
 ``color_ben``, by three K3 launches for the whole batch instead of 3 CPU perspective warps + PIL round
-trips per sample inside DataLoader workers.  The freshly attacked patch is used immediately (the
-reference behaves that way with num_workers=0; with workers its forked copies lag by an epoch).
+trips per sample inside DataLoader workers; camera side ("l"/"r") and do_flip are per-sample draws as in
+``__getitem__``.  By default the freshly attacked patch is used immediately (the reference behaves that way with
+num_workers=0); ``reference_stale_patch`` reproduces what its forked workers do (patch as of the epoch start,
+SURVEY 3.1).  Not reproduced: the PIL 8-bit round trip and LANCZOS pyramids of ``preprocess`` (the paste resizes
+bilinearly in the same pass; scales > 0 are 2^s box means) and ColorJitter.
 """
 import random
 
@@ -56,6 +59,12 @@ class SyntheticKITTIDataset(object):
         self.is_adv_train = False
         self.load_ben_color = False
         self.half_no_synthesis = False
+        # KITTI split lines carry both camera sides and training flips half of the items (mono_dataset.py:287-304);
+        # both are per-sample draws here.  Trainer switches them with --no_flip_sides (off = the round-1 behaviour).
+        self.both_sides = True
+        self.flip_augmentation = True
+        self.reference_stale_patch = False
+        self._epoch_patch = None
         self.K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
         stereo_T = np.eye(4, dtype=np.float32)
         stereo_T[0, 3] = -1 * 1 * 0.54   # side "l", mono_dataset.py:112-117
@@ -101,34 +110,91 @@ class SyntheticKITTIDataset(object):
         idx = to_device_async([self.rng.randrange(self.pool_size) for _ in range(n)], self.device, torch.int64)
         return self.raw_left.index_select(0, idx)
 
+    def begin_epoch(self):
+        """Epoch boundary.  With ``reference_stale_patch`` the synthesis keeps pasting the patch as it stood here until
+        the next epoch: the reference's DataLoader workers are forked when ``enumerate(self.train_loader)`` creates the
+        iterator (MD2/trainer.py:297) and never see the per-iteration ``update_adv_obj`` of the main process
+        (SURVEY.md section 3.1)."""
+        if self.is_adv_train:
+            self._epoch_patch = self.obj_img_adv.clone()
+
+    def draw_batch_geometry(self, batch_size):
+        """Per-sample draws of one batch, in the order ``__getitem__`` makes them (mono_dataset.py:287-288, :297-304,
+        then :190-215 inside prep_adv_data): side of the split line, do_flip, synthesis on/off (half_no_synthesis),
+        (z0, alpha)."""
+        geo = {"side": [], "flip": [], "synth": [], "z0": [], "alpha": []}
+        for _ in range(batch_size):
+            geo["flip"].append(self.rng.random() > 0.5 if self.flip_augmentation else False)
+            geo["side"].append(self.rng.choice("lr") if self.both_sides else "l")
+            geo["synth"].append(not self.half_no_synthesis or self.rng.random() > 0.5)
+            geo["z0"].append(self.rng.choice(self.adv_trans.dist_range) if self.is_adv_train else 0.0)
+            geo["alpha"].append(self.rng.choice(self.adv_trans.angle_range) if self.is_adv_train else 0)
+        return geo
+
+    def synthesize(self, raw_l, raw_r, geo, out_size):
+        """GPU-side ``prep_adv_data`` (mono_dataset.py:186-265) for a whole batch: frame 0 gets the adversarial object,
+        the opposite stereo view and ``color_ben`` the benign one; with ``side == "r"`` frame 0 is the right image and
+        the frame-0 geometry goes through ``project_w_trans(stereo_T)`` (:205-211), with ``do_flip`` the projected
+        object and mask are mirrored onto the mirrored frame (:222-225).  Three K3 launches.
+        Returns (color_aug_0, color_aug_s, color_ben_0, objmask_0)."""
+        dev = self.device
+        n = raw_l.shape[0]
+        is_l = torch.tensor([s == "l" for s in geo["side"]], device=dev).view(n, 1, 1, 1)
+        frame0 = torch.where(is_l, raw_l, raw_r)
+        frame_s = torch.where(is_l, raw_r, raw_l)
+        K, T = self.adv_K, self.stereo_T
+        far = np.array([1, 0, 1e7, 0, 1, 1e7, 0, 0], dtype=np.float32)      # object lands outside the frame: no synthesis
+        c0_adv = self.adv_trans.coeffs_for(geo["z0"], geo["alpha"], K=K)
+        c0_adv_T = self.adv_trans.coeffs_for(geo["z0"], geo["alpha"], K=K, T=T)
+        cs_ben = self.ben_trans.coeffs_for(geo["z0"], geo["alpha"], K=K)
+        cs_ben_T = self.ben_trans.coeffs_for(geo["z0"], geo["alpha"], K=K, T=T)
+        c0, cs = np.empty((n, 8), dtype=np.float32), np.empty((n, 8), dtype=np.float32)
+        for i in range(n):
+            left = geo["side"][i] == "l"
+            c0[i] = (c0_adv[i] if left else c0_adv_T[i]) if geo["synth"][i] else far
+            cs[i] = (cs_ben_T[i] if left else cs_ben[i]) if geo["synth"][i] else far
+        c0, cs = to_device_async(c0, dev), to_device_async(cs, dev)
+        flip = to_device_async([int(f) for f in geo["flip"]], dev, torch.int32) if any(geo["flip"]) else None
+        patch = self._epoch_patch if (self.reference_stale_patch and self._epoch_patch is not None) else self.obj_img_adv
+        lp, tp = self.adv_trans.l_pad, self.adv_trans.t_pad
+        with torch.no_grad():
+            aug0, _ = ops.eot_paste(frame0, patch, self.obj_mask, c0, lp, tp, out_size, flip)
+            aug_s, _ = ops.eot_paste(frame_s, self.obj_img_ben, self.obj_mask, cs, lp, tp, out_size, flip)
+            ben0, mask0 = ops.eot_paste(frame0, self.obj_img_ben, self.obj_mask, c0, lp, tp, out_size, flip)
+        return aug0, aug_s, ben0, mask0
+
     def next_batch(self, batch_size):
         dev, H, W = self.device, self.height, self.width
         idx = to_device_async([self.rng.randrange(self.pool_size) for _ in range(batch_size)], dev, torch.int64)
         raw_l, raw_r = self.raw_left.index_select(0, idx), self.raw_right.index_select(0, idx)
+        geo = self.draw_batch_geometry(batch_size)
         inputs = {}
         if self.is_adv_train:
-            z0 = [self.rng.choice(self.adv_trans.dist_range) for _ in range(batch_size)]
-            al = [self.rng.choice(self.adv_trans.angle_range) for _ in range(batch_size)]
-            c_l = to_device_async(self.adv_trans.coeffs_for(z0, al, K=self.adv_K), dev)
-            c_r = to_device_async(self.ben_trans.coeffs_for(z0, al, K=self.adv_K, T=self.stereo_T), dev)
-            lp, tp = self.adv_trans.l_pad, self.adv_trans.t_pad
-            with torch.no_grad():
-                left_adv, objmask = ops.eot_paste(raw_l, self.obj_img_adv, self.obj_mask, c_l, lp, tp, (H, W))
-                right_ben, _ = ops.eot_paste(raw_r, self.obj_img_ben, self.obj_mask, c_r, lp, tp, (H, W))
-                left_ben, _ = ops.eot_paste(raw_l, self.obj_img_ben, self.obj_mask, c_l, lp, tp, (H, W))
-            inputs[("color_aug", 0, 0)] = left_adv
-            inputs[("color_ben", 0, 0)] = left_ben
-            inputs[("color_objmask", 0, 0)] = objmask.expand(-1, 3, -1, -1)
-            inputs[("objdepth", 0, 0)] = to_device_async(z0, dev, torch.float32).view(batch_size, 1)
-            left, right = left_ben, right_ben     # inputs[("color",0,-1)] = color_ben, mono_dataset.py:257-258
+            aug0, aug_s, ben0, mask0 = self.synthesize(raw_l, raw_r, geo, (H, W))
+            inputs[("color_aug", 0, 0)] = aug0
+            inputs[("color_ben", 0, 0)] = ben0
+            if not self.half_no_synthesis:      # mono_dataset.py:248-250
+                inputs[("color_objmask", 0, 0)] = mask0.expand(-1, 3, -1, -1)
+                inputs[("objdepth", 0, 0)] = to_device_async(geo["z0"], dev, torch.float32).view(batch_size, 1)
+            left, right = ben0, aug_s           # inputs[("color",0,-1)] = color_ben, ("color","s",-1) = color_aug("s"), :252-253
         else:
-            left = F.interpolate(raw_l, [H, W], mode="bilinear", align_corners=False)
-            right = F.interpolate(raw_r, [H, W], mode="bilinear", align_corners=False)
+            is_l = torch.tensor([s == "l" for s in geo["side"]], device=dev).view(batch_size, 1, 1, 1)
+            left = F.interpolate(torch.where(is_l, raw_l, raw_r), [H, W], mode="bilinear", align_corners=False)
+            right = F.interpolate(torch.where(is_l, raw_r, raw_l), [H, W], mode="bilinear", align_corners=False)
+            if any(geo["flip"]):
+                fl = torch.tensor(geo["flip"], device=dev).view(batch_size, 1, 1, 1)
+                left, right = torch.where(fl, left.flip(3), left), torch.where(fl, right.flip(3), right)
             inputs[("color_aug", 0, 0)] = left
         for s in range(self.num_scales):
             inputs[("color", 0, s)] = left if s == 0 else F.avg_pool2d(left, 2 ** s)
             inputs[("color", "s", s)] = right if s == 0 else F.avg_pool2d(right, 2 ** s)
         inputs.update(self._camera(batch_size))
+        # stereo_T[0,3] = side_sign * baseline_sign * 0.1 (mono_dataset.py:367-373)
+        sign = [(-1.0 if sd == "l" else 1.0) * (-1.0 if fl else 1.0) for sd, fl in zip(geo["side"], geo["flip"])]
+        if any(v != -1.0 for v in sign):
+            T = inputs["stereo_T"].clone()
+            T[:, 0, 3] = to_device_async([0.1 * v for v in sign], dev, torch.float32)
+            inputs["stereo_T"] = T
         return inputs
 
     def _camera(self, batch_size):

@@ -289,8 +289,12 @@ def warp_view(source, disp, K, inv_K, T, H, W, min_depth=0.1, max_depth=100.0):
                            float(max_depth))
 
 
-def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_COMPOSITE):
+def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_COMPOSITE, flip=None):
     a = N.PasteArgs()
+    if flip is not None:
+        if flip.dtype != torch.int32 or flip.numel() != coeffs.shape[0]:
+            raise RuntimeError("eot_paste: flip must be an int32 tensor with one entry per sample")
+        a.flip = N.ptr(flip)
     n = coeffs.shape[0]
     a.mode = mode
     if scene.shape[0] not in (1, n) or scene.shape[1] != 3:
@@ -310,14 +314,15 @@ def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_
 
 class _EotPaste(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode):
+    def forward(ctx, scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, flip=None):
         lib = N.lib()
-        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode)
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, flip)
         adv = torch.empty((a.N, 3, OH, OW), device=scene.device, dtype=torch.float32)
         mask_out = torch.empty((a.N, 1, OH, OW), device=scene.device, dtype=torch.float32)
         N.check(lib.dmh_eot_paste_fwd(C.byref(a), N.ptr(adv), N.ptr(mask_out), N.stream()))
         ctx.save_for_backward(scene, patch, pmask, coeffs)
         ctx.geo = (l_pad, t_pad, OH, OW, mode)
+        ctx.flip = flip
         ctx.mark_non_differentiable(mask_out)
         return adv, mask_out
 
@@ -326,17 +331,18 @@ class _EotPaste(torch.autograd.Function):
         scene, patch, pmask, coeffs = ctx.saved_tensors
         l_pad, t_pad, OH, OW, mode = ctx.geo
         lib = N.lib()
-        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode)
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, ctx.flip)
         g_patch = torch.zeros_like(patch)
         N.check(lib.dmh_eot_paste_bwd(C.byref(a), N.ptr(_c(g_adv)), N.ptr(g_patch), N.stream()))
-        return None, g_patch, None, None, None, None, None, None, None
+        return None, g_patch, None, None, None, None, None, None, None, None
 
 
-def eot_paste(scene, patch, pmask, coeffs, l_pad, t_pad, out_size):
+def eot_paste(scene, patch, pmask, coeffs, l_pad, t_pad, out_size, flip=None):
     """Pad -> perspective(patch, mask) -> composite -> Resize, fused (physicalTrans.py:107-166 +
-    phy_obj_atk.py:87-90).  Returns (adv [N,3,OH,OW], mask_out [N,1,OH,OW]); differentiable w.r.t. patch."""
+    phy_obj_atk.py:87-90).  Returns (adv [N,3,OH,OW], mask_out [N,1,OH,OW]); differentiable w.r.t. patch.
+    ``flip`` (int32 [N], optional): samples to mirror horizontally (mono_dataset.py:222-225 on an un-flipped scene)."""
     return _EotPaste.apply(_c(scene), _c(patch), _c(pmask), _c(coeffs), int(l_pad), int(t_pad), int(out_size[0]),
-                           int(out_size[1]), N.PASTE_COMPOSITE)
+                           int(out_size[1]), N.PASTE_COMPOSITE, flip)
 
 
 def perspective_warp(patch, pmask, coeffs, l_pad, t_pad, frame_size):

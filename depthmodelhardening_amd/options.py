@@ -91,6 +91,11 @@ class MonodepthOptions:
                        help="strict reference order: wait for the gradient all-reduce + Adam before the next attack")
         p.add_argument("--materialize_warps", action="store_true",
                        help="generate_images_pred also writes depth/sample/color tensors (the fused loss never reads them)")
+        p.add_argument("--reference_stale_patch", action="store_true",
+                       help="paste the adversarial patch as of the epoch start, as the reference's forked DataLoader workers "
+                            "do (SURVEY.md section 3.1); default: the freshly attacked patch (its num_workers=0 behaviour)")
+        p.add_argument("--no_flip_sides", action="store_true",
+                       help="synthetic data: always camera side 'l' and no horizontal flips")
         p.add_argument("--max_steps", type=int, default=0, help="stop after this many iterations (0 = full epochs)")
         self.parser = p
 

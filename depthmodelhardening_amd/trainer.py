@@ -121,6 +121,8 @@ class Trainer:
                                       "12-13); use --dataset synthetic")
         self.dataset = SyntheticKITTIDataset(self.opt.height, self.opt.width, self.opt.frame_ids, 4,
                                              self.opt.synthetic_len, self.device, seed=self.opt.seed + rank)
+        self.dataset.both_sides = self.dataset.flip_augmentation = not self.opt.no_flip_sides
+        self.dataset.reference_stale_patch = bool(self.opt.reference_stale_patch)
         self.num_total_steps = len(self.dataset) // self.opt.batch_size * self.opt.num_epochs
 
         if self.opt.adv_train:
@@ -192,6 +194,18 @@ class Trainer:
             self._apply_pending_update()
         return losses
 
+    def warm_kernels(self):
+        """One local iteration without collectives or an optimiser step: the first pass through every convolution
+        makes MIOpen compile its kernels into the per-user cache (minutes on a fresh box).  bench.py lets rank 0 do
+        that alone before the other ranks start, so that N ranks do not build the same kernels concurrently."""
+        if self.opt.adv_train:
+            self.dataset.update_adv_obj(self.dataset.next_scenes(self.adv_args["batch_size"]))
+        inputs = self.dataset.next_batch(self.opt.batch_size)
+        _, losses = self.process_batch(inputs)
+        self.bucket.zero()
+        losses["loss"].backward()
+        self.bucket.zero()
+
     def _apply_pending_update(self):
         if getattr(self, "_pending", False):
             self.bucket.finish_all_reduce()
@@ -200,6 +214,7 @@ class Trainer:
 
     def run_epoch(self):
         self.set_train()
+        self.dataset.begin_epoch()     # where the reference's DataLoader forks its workers (--reference_stale_patch)
         steps = len(self.dataset) // self.opt.batch_size
         for batch_idx in range(steps):
             before_op_time = time.time()

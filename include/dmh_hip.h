@@ -163,6 +163,9 @@ typedef struct dmh_paste_args {
     int N, SH, SW, PH, PW, OH, OW;
     int l_pad, t_pad; /* physicalTrans.py:110-113 */
     int mode;         /* DMH_PASTE_COMPOSITE or DMH_PASTE_WARP_ONLY */
+    const int32_t* flip; /* [N] or NULL: != 0 mirrors sample n horizontally (do_flip of MD2/datasets/mono_dataset.py:288,
+                          :222-225: the loader flips the frame, prep_adv_data flips the projected object and mask; the
+                          scene passed here is the UN-flipped frame and the whole composite is written mirrored) */
 } dmh_paste_args;
 
 /* adv [N,3,OH,OW], mask_out [N,1,OH,OW] (either may be NULL) */

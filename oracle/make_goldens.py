@@ -308,6 +308,111 @@ def gold_attacks(ta):
              delta_absmax=(adv - clean).abs().amax())
 
 
+# --------------------------------------------------------------------------- add-ons (a-14, a-15, f-1, f-2)
+def gold_simsiam(contrastive):
+    """MD2/contrastive.py:6-93 on fixed features: loss, feature gradients, per-parameter gradient sums (train mode)."""
+    torch.manual_seed(51)
+    net = contrastive.SimSiam()
+    net.train()
+    g = torch.Generator().manual_seed(52)
+    f_adv = [torch.rand(4, 512, 3, 5, generator=g).requires_grad_(True)]
+    f_ben = [(f_adv[0].detach() + 0.3 * torch.rand(4, 512, 3, 5, generator=g)).requires_grad_(True)]
+    loss = net(f_adv, f_ben)
+    loss.backward()
+    names, gsum, wsum = [], [], []
+    for n, p in net.named_parameters():
+        names.append(n)
+        gsum.append(float(p.grad.double().abs().sum()))
+        wsum.append(float(p.detach().double().abs().sum()))
+    save("simsiam", seeds=np.array([51, 52]), loss=loss.detach(), g_adv=f_adv[0].grad[:, ::8], g_ben=f_ben[0].grad[:, ::8],
+         param_names=np.array(names), param_grad_abssum=np.array(gsum), param_abssum=np.array(wsum),
+         running_mean_0=net.projector[1].running_mean.clone())
+
+
+def gold_sup_loss(trainer_mod, layers):
+    """MD2/trainer.py:546-577 with --adv_train --supervised_adv --contrastive_learning --no_original_train: the add-on
+    losses alone (sup_loss = MSE(gt_model(color_ben), disp_0); contras_loss = SimSiam(features_aug, features_ben))."""
+    import contrastive
+    B, H, W = 2, 32, 96
+    g = torch.Generator().manual_seed(61)
+    color_ben = kitti_like(B, 3, H, W, g)
+    disp = (torch.rand(B, 1, H, W, generator=g) * 0.3 + 0.01).requires_grad_(True)
+    torch.manual_seed(62)
+    simsiam = contrastive.SimSiam()
+    simsiam.train()
+    feats_aug = [torch.rand(B, 512, 1, 3, generator=g).requires_grad_(True)]
+    feats_ben = [torch.rand(B, 512, 1, 3, generator=g).requires_grad_(True)]
+    opt = SimpleNamespace(adv_train=True, supervised_adv=True, contrastive_learning=True, no_original_train=True,
+                          gt_depth=False, min_depth=0.1, max_depth=100.0)
+    self = SimpleNamespace(opt=opt, gt_model=TinyDepthNet(seed=5).eval(), sup_loss_creteria=nn.MSELoss(),
+                           models={"contrastive_learning": simsiam})
+    inputs = {("color_ben", 0, 0): color_ben}
+    outputs = {("disp", 0): disp, "middle_features_aug": feats_aug, "middle_features_ben": feats_ben}
+    losses = trainer_mod.Trainer.compute_losses(self, inputs, outputs)
+    losses["loss"].backward()
+    save("addon_losses", shape=np.array([B, H, W, 61, 62]), sup_loss=losses["sup_loss"].detach(),
+         contras_loss=losses["contras_loss"].detach(), loss=losses["loss"].detach(), g_disp=disp.grad,
+         g_feat_aug=feats_aug[0].grad)
+
+
+def gold_compute_errors(evaluate_depth, layers):
+    """MD2/evaluate_depth.py:57-99 both branches, fed through the depth conversion of :193-194."""
+    g = torch.Generator().manual_seed(71)
+    disp_gt = torch.rand(2, 1, 40, 72, generator=g) * 0.6 + 0.005
+    disp_atk = (disp_gt * (0.6 + 0.8 * torch.rand(2, 1, 40, 72, generator=g))).clamp(1e-4, 1.0)
+    disp_atk[0, 0, :3] *= -1.0       # the reference takes |disp|
+    mask = (torch.rand(2, 1, 40, 72, generator=g) > 0.7).float()
+    S, lo, hi = evaluate_depth.STEREO_SCALE_FACTOR, evaluate_depth.MIN_DEPTH, evaluate_depth.MAX_DEPTH
+    gt_depth = torch.clamp(layers.disp_to_depth(torch.abs(disp_gt), 0.1, 100)[1] * S, max=hi, min=lo)
+    atk_depth = torch.clamp(layers.disp_to_depth(torch.abs(disp_atk), 0.1, 100)[1] * S, max=hi, min=lo)
+    e_all = evaluate_depth.compute_errors(gt_depth.numpy(), atk_depth.numpy(), mask=None)
+    e_msk = evaluate_depth.compute_errors(gt_depth.numpy(), atk_depth.numpy(), mask=mask.numpy())
+    save("compute_errors", seed=np.array(71), disp_gt=disp_gt, disp_atk=disp_atk, mask=mask, gt_depth=gt_depth,
+         atk_depth=atk_depth, errors_all=np.array(e_all, dtype=np.float64), errors_masked=np.array(e_msk, dtype=np.float64))
+
+
+def gold_prep_adv_data(mono_dataset, PhysicalTrans, calib_path):
+    """MD2/datasets/mono_dataset.py:186-265 (prep_adv_data) run unbound on tensors (ToTensor / ToPILImage are the
+    identity stand-ins, so the PIL 8-bit round trip is not part of the fixture), both camera sides, with and without
+    do_flip, torchvision's perspective = oracle/tv082.py ("parity unpinned")."""
+    obj, mask = make_object()
+    g = torch.Generator().manual_seed(81)
+    obj_adv = (obj + 0.1 * (torch.rand(obj.shape, generator=g) - 0.5)).clamp(0, 1)
+    raw_l, raw_r = kitti_like(1, 3, 375, 1242, g)[0], kitti_like(1, 3, 375, 1242, g)[0]
+    dist_range = list(np.arange(5, 10, 0.2))
+    adv_K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+    adv_K[0, :] *= 1242
+    adv_K[1, :] *= 375
+    stereo_T = np.eye(4, dtype=np.float32)
+    stereo_T[0, 3] = -0.54
+    ident = lambda x: x  # noqa: E731
+    keep = {"seed": np.array(81)}
+    for side in ("l", "r"):
+        for do_flip in (False, True):
+            self = SimpleNamespace(to_tensor=ident, to_pilimage=ident, ori_H=375, ori_W=1242, resize_trans=ident,
+                                   half_no_synthesis=False, adv_K=adv_K, stereo_T=stereo_T,
+                                   ben_trans=PhysicalTrans(obj, mask, {"path": calib_path}, (1, 3, 375, 1242), dist_range=dist_range),
+                                   adv_trans=PhysicalTrans(obj_adv, mask, {"path": calib_path}, (1, 3, 375, 1242), dist_range=dist_range))
+            # get_color has already flipped the frames when do_flip is set (mono_dataset.py:297-304)
+            f0, fs = (raw_l, raw_r) if side == "l" else (raw_r, raw_l)
+            if do_flip:
+                f0, fs = torch.flip(f0, [2]), torch.flip(fs, [2])
+            inputs = {("color", 0, -1): f0, ("color", "s", -1): fs}
+            _seed_all(90 + (side == "r") * 2 + int(do_flip))
+            out = mono_dataset.MonoDataset.prep_adv_data(self, inputs, side, do_flip, load_ben_color=True)
+            tag = "%s%d_" % (side, int(do_flip))
+            sub = (slice(None), slice(100, 330, 6), slice(300, 1000, 5))
+            keep[tag + "z0"] = np.array(float(out[("objdepth", 0, 0)].reshape(-1)[0]))
+            keep[tag + "aug0"] = out[("color_aug", 0, -1)][sub]
+            keep[tag + "aug_s"] = out[("color_aug", "s", -1)][sub]
+            keep[tag + "ben0"] = out[("color_ben", 0, -1)][sub]
+            keep[tag + "mask0"] = out[("color_objmask", 0, -1)][sub]
+            keep[tag + "aug0_sum"] = out[("color_aug", 0, -1)].double().sum()
+            keep[tag + "mask0_sum"] = out[("color_objmask", 0, -1)][0].double().sum()
+            assert out[("color", 0, -1)] is out[("color_ben", 0, -1)] and out[("color", "s", -1)] is out[("color_aug", "s", -1)]
+    save("prep_adv_data", **keep)
+
+
 def main():
     install_shims()
     tmp = tempfile.mkdtemp(prefix="kitti_obj_")
@@ -328,6 +433,13 @@ def main():
     gold_geometry(physicalTrans.PhysicalTrans, calib)
     import torchattacks as ta
     gold_attacks(ta)
+    import contrastive
+    gold_simsiam(contrastive)
+    gold_sup_loss(md2_trainer, layers)
+    import evaluate_depth
+    gold_compute_errors(evaluate_depth, layers)
+    import datasets.mono_dataset as mono_dataset
+    gold_prep_adv_data(mono_dataset, physicalTrans.PhysicalTrans, calib)
 
     # DepthHints variant: same module names, so import it in a scrubbed namespace
     for m in ["trainer", "layers", "datasets", "networks", "utils", "kitti_utils", "options", "evaluate_depth",

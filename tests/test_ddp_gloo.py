@@ -72,3 +72,52 @@ def test_bucket_single_process_is_a_noop():
     before = b.flat.clone()
     b.all_reduce()
     assert torch.equal(before, b.flat) and b.numel == sum(p.numel() for p in m.parameters())
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(repo, "bench.py")] + args, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus N` (no torchrun): the parent spawns N rank processes before anything touches a GPU,
+    they rendezvous on 127.0.0.1, reduce max-over-ranks, and rank 0's single JSON line comes back through the parent.
+    --device cpu runs that plumbing over gloo with no kernels."""
+    import json
+    r = _run_bench(["--gpus", "2", "--device", "cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]     # gloo prints a connection banner on stdout
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["max_over_ranks"] == 2.0
+
+
+def test_bench_refuses_a_world_size_that_does_not_match_gpus():
+    """Under a torchrun-style environment with the wrong world size bench.py exits non-zero instead of measuring one rank
+    and reporting it as N."""
+    r = _run_bench(["--gpus", "4", "--device", "cpu"], {"WORLD_SIZE": "1", "RANK": "0", "DMH_BENCH_CHILD": "1"})
+    assert r.returncode != 0 and "--gpus 4" in (r.stderr + r.stdout)
+
+
+def test_average_buffers_two_ranks():
+    ret = mp.Manager().dict()
+    mp.spawn(_buffers_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert torch.allclose(ret[0], torch.tensor([1.5, 1.5])) and torch.equal(ret[0], ret[1])
+
+
+def _buffers_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from depthmodelhardening_amd.ddp import average_buffers, init_distributed
+    init_distributed("cpu")
+    bn = nn.BatchNorm2d(2)
+    bn.running_mean.fill_(float(rank + 1))
+    average_buffers([bn])
+    ret[rank] = bn.running_mean.clone()
+    dist.barrier()
+    dist.destroy_process_group()

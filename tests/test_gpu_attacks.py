@@ -194,3 +194,109 @@ def test_physicaltrans_project_surface_vs_oracle():
     _, _, zs, als = pt.project(batch_size=12)
     random.seed(9)
     assert zs == random.sample(pt.dist_range, 12) and als == random.sample(pt.angle_range, 12)
+
+
+# ------------------------------------------------------------------------------------------ add-on fixtures (a-14, a-15, f-1, f-2)
+def test_masked_depth_errors_match_reference_compute_errors(golden):
+    """K8 against the numbers MD2/evaluate_depth.py:57-99 (both branches) produced, fed from the same disparities through
+    the depth conversion of :193-194."""
+    from depthmodelhardening_amd import ops
+    g = golden("compute_errors")
+    dg, da, m = (torch.from_numpy(g[k]).cuda() for k in ("disp_gt", "disp_atk", "mask"))
+    got_all = ops.masked_depth_errors(dg, da, None).double().cpu().numpy()
+    got_msk = ops.masked_depth_errors(dg, da, m).double().cpu().numpy()
+    np.testing.assert_allclose(got_all, g["errors_all"], rtol=2e-5)
+    np.testing.assert_allclose(got_msk, g["errors_masked"], rtol=2e-5)
+
+
+def _synth_dataset(H, W):
+    from depthmodelhardening_amd.datasets import SyntheticKITTIDataset
+    from oracle.synth import TinyDepthNet, make_object
+    dev = torch.device("cuda")
+    ds = SyntheticKITTIDataset(H, W, [0, "s"], 4, 64, dev, seed=5, pool=4)
+    obj, mask = make_object()
+    args = {"norm_type": "l_inf", "epsilon": 0.1, "alpha": 0.02, "step": 2, "batch_size": 2, "load_ben_color": True,
+            "color_aug": False, "half_no_synthesis": False}
+    ds.set_adv_train(TinyDepthNet(seed=5).to(dev), obj.to(dev), mask.to(dev), args)
+    return ds, obj, mask
+
+
+@pytest.mark.parametrize("side", ["l", "r"])
+@pytest.mark.parametrize("do_flip", [False, True])
+def test_gpu_sample_synthesis_matches_reference_prep_adv_data(golden, side, do_flip):
+    """The GPU-side prep_adv_data (three K3 launches) against what the reference's MonoDataset.prep_adv_data produced
+    for the same frames, patches and (z0, alpha): both camera sides, with and without do_flip, at 375x1242 (the
+    reference pastes at that size; resizing afterwards is PIL's, out of scope)."""
+    from tests.test_oracle_golden import prep_case
+    g = golden("prep_adv_data")
+    ds, _, _ = _synth_dataset(375, 1242)
+    obj, obj_adv, mask, raw_l, raw_r, z0, alpha = prep_case(side, do_flip)
+    ds.obj_img_adv = obj_adv.cuda()
+    ds.adv_trans.reset_img(ds.obj_img_adv, ds.obj_mask)
+    geo = {"side": [side], "flip": [do_flip], "synth": [True], "z0": [z0], "alpha": [alpha]}
+    aug0, aug_s, ben0, mask0 = ds.synthesize(raw_l[None].cuda(), raw_r[None].cuda(), geo, (375, 1242))
+    tag = "%s%d_" % (side, int(do_flip))
+    sub = (0, slice(None), slice(100, 330, 6), slice(300, 1000, 5))
+    for got, key in ((aug0, "aug0"), (aug_s, "aug_s"), (ben0, "ben0"), (mask0.expand(-1, 3, -1, -1), "mask0")):
+        assert_close_frac(got[sub], torch.from_numpy(g[tag + key]), rtol=1e-4, atol=2e-5, max_bad_frac=1e-4, name=tag + key)
+    ref_sum = float(g[tag + "aug0_sum"])
+    assert abs(float(aug0.double().sum()) - ref_sum) <= 2e-6 * ref_sum
+    assert abs(float(mask0.double().sum()) - float(g[tag + "mask0_sum"])) <= 1e-4 * float(g[tag + "mask0_sum"])
+
+
+def test_next_batch_semantics_sides_flips_and_stale_patch():
+    """next_batch: stereo_T sign = side_sign * baseline_sign * 0.1 (mono_dataset.py:367-373), color = color_ben,
+    color("s") = color_aug("s") (:252-253), half_no_synthesis skips the paste, and --reference_stale_patch keeps the
+    epoch-start patch (the reference's forked workers never see update_adv_obj)."""
+    ds, obj, mask = _synth_dataset(64, 192)
+    b = ds.next_batch(16)
+    T = b["stereo_T"][:, 0, 3].cpu()
+    assert set(torch.unique(T).tolist()) <= {-0.1, 0.1} and (T > 0).any() and (T < 0).any()
+    assert b[("color", 0, 0)] is b[("color_ben", 0, 0)]
+    assert b[("color_aug", 0, 0)].shape == (16, 3, 64, 192) and b[("color_objmask", 0, 0)].shape == (16, 3, 64, 192)
+    assert float(b[("color_objmask", 0, 0)].max()) > 0.9 and b[("objdepth", 0, 0)].shape == (16, 1)
+    # the adversarial patch differs from the benign one only inside the object mask
+    diff = (b[("color_aug", 0, 0)] - b[("color_ben", 0, 0)]).abs().sum(1)
+    ds.obj_img_adv = (ds.obj_img_ben * 0.5).contiguous()
+    ds.adv_trans.reset_img(ds.obj_img_adv, ds.obj_mask)
+    assert float(diff.max()) == 0.0          # nothing attacked yet: adv == ben
+    # stale patch: begin_epoch snapshots; later updates do not reach the synthesis until the next begin_epoch
+    ds.reference_stale_patch = True
+    ds.begin_epoch()                                   # snapshot = 0.5 * benign
+    ds.obj_img_adv = (ds.obj_img_ben * 0.25).contiguous()
+    ds.adv_trans.reset_img(ds.obj_img_adv, ds.obj_mask)
+    geo = {"side": ["l"], "flip": [False], "synth": [True], "z0": [6.0], "alpha": [0]}
+    raw = ds.raw_left[:1]
+    stale, _, ben, m = ds.synthesize(raw, ds.raw_right[:1], geo, (64, 192))
+    ds.reference_stale_patch = False
+    fresh, _, _, _ = ds.synthesize(raw, ds.raw_right[:1], geo, (64, 192))
+    inside = m[0, 0] > 0.99
+    assert inside.any()
+    ratio_stale = (stale[0, :, inside] / ben[0, :, inside]).mean().item()
+    ratio_fresh = (fresh[0, :, inside] / ben[0, :, inside]).mean().item()
+    assert abs(ratio_stale - 0.5) < 0.02 and abs(ratio_fresh - 0.25) < 0.02
+    # half_no_synthesis: un-synthesised samples are the plain frames
+    geo2 = {"side": ["l", "l"], "flip": [False, False], "synth": [True, False], "z0": [6.0, 6.0], "alpha": [0, 0]}
+    a2, _, b2, m2 = ds.synthesize(ds.raw_left[:2], ds.raw_right[:2], geo2, (64, 192))
+    assert float(m2[1].max()) == 0.0 and torch.equal(a2[1], b2[1]) and float(m2[0].max()) > 0.9
+
+
+def test_update_adv_obj_equals_the_oracle_attack():
+    """dataset.update_adv_obj keeps the 4th return of the attack (mono_dataset.py:178-184): same start, same scenes and
+    the same (z0, alpha) draws -> the oracle's Phy_obj_atk patch (>= 99.5 % of texels identical; a sign() step on a ~0
+    gradient may move a texel), and adv_trans is re-pointed at it."""
+    from oracle import attack_ref
+    from oracle.synth import TinyDepthNet, kitti_like
+    ds, obj, mask = _synth_dataset(64, 192)
+    scenes = kitti_like(2, 3, 375, 1242, torch.Generator().manual_seed(3))
+    noise = (torch.rand(obj.shape, generator=torch.Generator().manual_seed(9)) * 2 - 1) * 0.1
+    random.seed(77)
+    _, _, _, ref_patch = attack_ref.phy_obj_atk(TinyDepthNet(seed=5), obj, mask, scenes, 2, eps=0.1, alpha=0.02, steps=2,
+                                                dist_range=attack_ref.TRAIN_DIST_RANGE, start_noise=noise)
+    ds.depth_atk.random_start_noise = noise
+    random.seed(77)
+    ds.update_adv_obj(scenes.cuda())
+    got = ds.obj_img_adv.cpu()
+    same = ((got - ref_patch).abs() < 1e-5).float().mean().item()
+    assert same >= 0.995, same
+    assert not torch.equal(got, obj) and ds.adv_trans.obj_img is ds.obj_img_adv

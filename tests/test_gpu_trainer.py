@@ -546,3 +546,57 @@ def test_trainer_val_reports_attack_metrics(tmp_path):
     err = tr.val()
     assert err.shape == (8,) and torch.isfinite(torch.from_numpy(err)).all()
     assert tr.models["encoder"].training
+
+
+def test_addon_losses_match_reference_golden(tmp_path, golden):
+    """Trainer.compute_losses with --adv_train --supervised_adv --contrastive_learning --no_original_train against the
+    numbers MD2/trainer.py:546-577 + MD2/contrastive.py:62-93 produced for the same tensors (tests/golden/addon_losses.npz)."""
+    import numpy as np
+    from oracle.synth import TinyDepthNet
+    from tests.test_oracle_golden import addon_case
+    g = golden("addon_losses")
+    tr = _trainer(tmp_path, ["--adv_train", "--supervised_adv", "--contrastive_learning", "--no_original_train"])
+    color_ben, disp, simsiam_ref, feats_aug, feats_ben = addon_case()
+    tr.gt_model = TinyDepthNet(seed=5).cuda().eval()
+    tr.models["contrastive_learning"].load_state_dict(simsiam_ref.state_dict())
+    tr.models["contrastive_learning"].train()
+    d = disp.detach().cuda().requires_grad_(True)
+    fa = [feats_aug[0].detach().cuda().requires_grad_(True)]
+    fb = [feats_ben[0].detach().cuda()]
+    inputs = {("color_ben", 0, 0): color_ben.cuda()}
+    outputs = {("disp", 0): d, "middle_features_aug": fa, "middle_features_ben": fb}
+    losses = tr.compute_losses(inputs, outputs)
+    assert set(losses) == {"sup_loss", "contras_loss", "loss"}
+    losses["loss"].backward()
+    for k in ("sup_loss", "contras_loss", "loss"):
+        ref = float(g[k])
+        assert abs(float(losses[k]) - ref) <= 2e-5 * abs(ref), (k, float(losses[k]), ref)
+    assert_close_frac(d.grad, torch.from_numpy(np.asarray(g["g_disp"])), rtol=1e-4, atol=1e-9, name="d sup_loss / d disp")
+    assert_close_frac(fa[0].grad, torch.from_numpy(np.asarray(g["g_feat_aug"])), rtol=1e-3, atol=1e-7, name="d contras / d feat")
+
+
+def test_eval_mode_with_trainable_batchnorm_takes_the_module_path():
+    """Fine-tuning with frozen statistics (encoder.eval(), grad on, outside frozen_weights()): BatchNorm weight / bias
+    must receive their gradients exactly as nn.BatchNorm2d gives them; inside an attack scope the fused path is taken
+    and the parameters get none."""
+    from depthmodelhardening_amd import networks, ops
+    torch.manual_seed(2)
+    enc = networks.ResnetEncoder(18, False).cuda().eval()
+    x = torch.rand(2, 3, 64, 96, device="cuda")
+    assert not enc.encoder.fused_eval_ok((x - 0.45) / 0.225)
+    feats = enc(x)
+    feats[-1].square().mean().backward()
+    g_bn = enc.encoder.layer1[0].bn1.weight.grad
+    assert g_bn is not None and float(g_bn.abs().sum()) > 0
+    ref = networks.ResnetEncoder(18, False).cuda().eval()
+    ref.load_state_dict(enc.state_dict())
+    ref.encoder.fuse_eval_bn = False
+    ref(x)[-1].square().mean().backward()
+    torch.testing.assert_close(g_bn, ref.encoder.layer1[0].bn1.weight.grad, rtol=1e-3, atol=1e-7)
+    for p in enc.parameters():
+        p.grad = None
+    with ops.frozen_weights():
+        assert enc.encoder.fused_eval_ok((x - 0.45) / 0.225)
+        xi = x.clone().requires_grad_(True)
+        enc(xi)[-1].square().mean().backward()
+    assert xi.grad is not None and enc.encoder.layer1[0].bn1.weight.grad is None

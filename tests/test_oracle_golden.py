@@ -183,3 +183,114 @@ def test_network_kernel_formulations_match_torch_nn():
     mean, var = conv_ref.bn_train_stats(xb)
     np.testing.assert_allclose(mean, xb.mean((0, 2, 3)), rtol=1e-13)
     np.testing.assert_allclose(var, xb.var((0, 2, 3)), rtol=1e-11)
+
+
+# ------------------------------------------------------------------------------------------ add-ons (a-14, a-15, f-1, f-2)
+def test_compute_errors_and_eval_depth(golden):
+    """oracle/eval_ref.py and the product's host-side compute_errors against MD2/evaluate_depth.py:57-99,193-194."""
+    from depthmodelhardening_amd import evaluate_depth as prod
+    from oracle import eval_ref
+    g = golden("compute_errors")
+    gt = eval_ref.disp_to_eval_depth(g["disp_gt"])
+    atk = eval_ref.disp_to_eval_depth(g["disp_atk"])
+    np.testing.assert_allclose(gt, g["gt_depth"], rtol=2e-6)
+    np.testing.assert_allclose(atk, g["atk_depth"], rtol=2e-6)
+    for fn in (eval_ref.compute_errors, prod.compute_errors):
+        np.testing.assert_allclose(np.array(fn(g["gt_depth"], g["atk_depth"]), dtype=np.float64), g["errors_all"], rtol=2e-6)
+        np.testing.assert_allclose(np.array(fn(g["gt_depth"], g["atk_depth"], g["mask"]), dtype=np.float64),
+                                   g["errors_masked"], rtol=2e-6)
+
+
+def _simsiam_case(cls):
+    torch.manual_seed(51)
+    net = cls()
+    net.train()
+    gen = torch.Generator().manual_seed(52)
+    f_adv = [torch.rand(4, 512, 3, 5, generator=gen).requires_grad_(True)]
+    f_ben = [(f_adv[0].detach() + 0.3 * torch.rand(4, 512, 3, 5, generator=gen)).requires_grad_(True)]
+    loss = net(f_adv, f_ben)
+    loss.backward()
+    return net, loss, f_adv[0].grad, f_ben[0].grad
+
+
+@pytest.mark.parametrize("which", ["oracle", "product"])
+def test_simsiam(golden, which):
+    """MD2/contrastive.py:62-93 forward/backward on fixed features (train-mode BatchNorm1d): oracle restatement and the
+    product module (plain PyTorch, same construction order => same initial weights from the same seed)."""
+    from depthmodelhardening_amd.contrastive import SimSiam
+    from oracle.dataset_ref import SimSiamRef
+    g = golden("simsiam")
+    net, loss, ga, gb = _simsiam_case(SimSiamRef if which == "oracle" else SimSiam)
+    names = [n for n, _ in net.named_parameters()]
+    assert names == [str(n) for n in g["param_names"]]
+    wsum = np.array([float(p.detach().double().abs().sum()) for _, p in net.named_parameters()])
+    np.testing.assert_allclose(wsum, g["param_abssum"], rtol=1e-6)            # same initial weights
+    torch.testing.assert_close(loss.detach(), t(g["loss"]), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(ga[:, ::8], t(g["g_adv"]), rtol=1e-4, atol=1e-9)
+    torch.testing.assert_close(gb[:, ::8], t(g["g_ben"]), rtol=1e-4, atol=1e-9)
+    gsum = np.array([float(p.grad.double().abs().sum()) for _, p in net.named_parameters()])
+    np.testing.assert_allclose(gsum, g["param_grad_abssum"], rtol=1e-4)
+    torch.testing.assert_close(net.projector[1].running_mean, t(g["running_mean_0"]), rtol=1e-5, atol=1e-8)
+
+
+def addon_case():
+    """Inputs of tests/golden/addon_losses.npz, regenerated from its seeds (same draw order as oracle/make_goldens.py)."""
+    from oracle.dataset_ref import SimSiamRef
+    B, H, W = 2, 32, 96
+    gen = torch.Generator().manual_seed(61)
+    color_ben = kitti_like(B, 3, H, W, gen)
+    disp = (torch.rand(B, 1, H, W, generator=gen) * 0.3 + 0.01).requires_grad_(True)
+    torch.manual_seed(62)
+    simsiam = SimSiamRef()
+    simsiam.train()
+    feats_aug = [torch.rand(B, 512, 1, 3, generator=gen).requires_grad_(True)]
+    feats_ben = [torch.rand(B, 512, 1, 3, generator=gen).requires_grad_(True)]
+    return color_ben, disp, simsiam, feats_aug, feats_ben
+
+
+def test_addon_losses(golden):
+    """sup_loss + contras_loss of MD2/trainer.py:546-577 (--supervised_adv --contrastive_learning --no_original_train)."""
+    from oracle.dataset_ref import addon_losses
+    g = golden("addon_losses")
+    color_ben, disp, simsiam, feats_aug, feats_ben = addon_case()
+    sup, con, total = addon_losses(TinyDepthNet(seed=5).eval(), simsiam, color_ben, disp, feats_aug, feats_ben)
+    total.backward()
+    torch.testing.assert_close(sup.detach(), t(g["sup_loss"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(con.detach(), t(g["contras_loss"]), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(total.detach(), t(g["loss"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(disp.grad, t(g["g_disp"]), rtol=1e-5, atol=1e-10)
+    torch.testing.assert_close(feats_aug[0].grad, t(g["g_feat_aug"]), rtol=1e-4, atol=1e-9)
+
+
+def prep_case(side, do_flip):
+    """Frames, patches and the (z0, alpha) draw of one tests/golden/prep_adv_data.npz case."""
+    obj, mask = make_object()
+    gen = torch.Generator().manual_seed(81)
+    obj_adv = (obj + 0.1 * (torch.rand(obj.shape, generator=gen) - 0.5)).clamp(0, 1)
+    raw_l, raw_r = kitti_like(1, 3, 375, 1242, gen)[0], kitti_like(1, 3, 375, 1242, gen)[0]
+    random.seed(90 + (side == "r") * 2 + int(do_flip))
+    z0 = random.sample(attack_ref.TRAIN_DIST_RANGE, 1)[0]
+    alpha = random.sample(attack_ref.ANGLE_RANGE, 1)[0]
+    return obj, obj_adv, mask, raw_l, raw_r, z0, alpha
+
+
+@pytest.mark.parametrize("side", ["l", "r"])
+@pytest.mark.parametrize("do_flip", [False, True])
+def test_prep_adv_data(golden, side, do_flip):
+    """oracle/dataset_ref.prep_adv_data against the reference's MonoDataset.prep_adv_data (mono_dataset.py:186-265)."""
+    from oracle import dataset_ref
+    g = golden("prep_adv_data")
+    obj, obj_adv, mask, raw_l, raw_r, z0, alpha = prep_case(side, do_flip)
+    tag = "%s%d_" % (side, int(do_flip))
+    assert abs(z0 - float(g[tag + "z0"])) < 1e-6          # objdepth is a FloatTensor (mono_dataset.py:250)
+    f0, fs = (raw_l, raw_r) if side == "l" else (raw_r, raw_l)
+    if do_flip:
+        f0, fs = torch.flip(f0, [2]), torch.flip(fs, [2])
+    adv_trans = attack_ref.PhysicalTransRef(obj_adv, mask, dist_range=attack_ref.TRAIN_DIST_RANGE)
+    ben_trans = attack_ref.PhysicalTransRef(obj, mask, dist_range=attack_ref.TRAIN_DIST_RANGE)
+    out = dataset_ref.prep_adv_data(f0, fs, side, do_flip, adv_trans, ben_trans, z0, alpha)
+    sub = (slice(None), slice(100, 330, 6), slice(300, 1000, 5))
+    for key, name in (("aug0", "color_aug_0"), ("aug_s", "color_aug_s"), ("ben0", "color_ben_0"), ("mask0", "objmask_0")):
+        torch.testing.assert_close(out[name][sub], t(g[tag + key]), rtol=1e-6, atol=1e-7)
+    assert abs(float(out["color_aug_0"].double().sum()) - float(g[tag + "aug0_sum"])) <= 1e-7 * float(g[tag + "aug0_sum"])
+    assert float(g[tag + "mask0_sum"]) > 100.0      # the object is in the frame

@@ -1,8 +1,7 @@
 set -u
 export TMPDIR=/tmp
-OUT=gpurun_out/prof_k1a
+OUT=gpurun_out/prof_k1b
 mkdir -p $OUT
-for v in b3 b4; do echo VARIANT $v; DMH_HIP_LIB=$PWD/depthmodelhardening_amd/lib/libdmh_hip_$v.so timeout -k 10 200 python tools/kbench.py --iters 30 | grep -E "photo_fwd_ms|photo_bwd_ms"; done
 K1="python3 tools/prof_k1.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $K1 5 > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_a -- $K1 2 > $OUT/pmc_a.log 2>&1
