@@ -570,7 +570,9 @@ def test_addon_losses_match_reference_golden(tmp_path, golden):
     losses["loss"].backward()
     for k in ("sup_loss", "contras_loss", "loss"):
         ref = float(g[k])
-        assert abs(float(losses[k]) - ref) <= 2e-5 * abs(ref), (k, float(losses[k]), ref)
+        # contras_loss is a mean cosine in [-1, 1] that happens to be ~0.009 here (BatchNorm1d over a batch of 2 maps
+        # every feature to +-1): 5e-6 absolute is fp32 noise of the GEMM accumulation order, not 1e-4 of a ~1 quantity
+        assert abs(float(losses[k]) - ref) <= 2e-5 * abs(ref) + (5e-6 if k != "sup_loss" else 0.0), (k, float(losses[k]), ref)
     assert_close_frac(d.grad, torch.from_numpy(np.asarray(g["g_disp"])), rtol=1e-4, atol=1e-9, name="d sup_loss / d disp")
     assert_close_frac(fa[0].grad, torch.from_numpy(np.asarray(g["g_feat_aug"])), rtol=1e-3, atol=1e-7, name="d contras / d feat")
 
