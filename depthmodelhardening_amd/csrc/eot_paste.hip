@@ -10,8 +10,8 @@
 //   Resize       = F.interpolate(bilinear, align_corners=False), no antialias
 //
 // HBM-bound: the scene (5.6 MB/sample) is read once, the 1.2 MB patch+mask stay L2-resident, the
-// output (5.2 MB/sample) is written once with 64-lane coalesced rows.  The backward scatters
-// d loss / d adv into the single shared patch with float atomics (only pixels under the mask).
+// output (5.2 MB/sample) is written once with 64-lane coalesced rows.  The backward is a gather per patch
+// texel over the inverse homography: deterministic, no atomics.
 #include "common.hpp"
 
 using namespace dmh;
@@ -138,49 +138,95 @@ __global__ __launch_bounds__(NT) void paste_fwd_kernel(const dmh_paste_args a, f
         mask_out[(size_t)n * ohw + idx] = hy * (hx * mm[0][0] + r.lx * mm[0][1]) + r.ly * (hx * mm[1][0] + r.lx * mm[1][1]);
 }
 
-__device__ __forceinline__ void patch_scatter(float* __restrict__ g, const PTap& t, int PW, int PH, float v) {
-    const bool xa = t.x0 >= 0, xb = t.x0 + 1 < PW, ya = t.y0 >= 0, yb = t.y0 + 1 < PH;
-    float* r0 = g + t.y0 * PW + t.x0;
-    const float gx = 1.f - t.fx, gy = 1.f - t.fy;
-    if (xa && ya) atomicAdd(r0, v * (gx * gy));
-    if (xb && ya) atomicAdd(r0 + 1, v * (t.fx * gy));
-    if (xa && yb) atomicAdd(r0 + PW, v * (gx * t.fy));
-    if (xb && yb) atomicAdd(r0 + PW + 1, v * (t.fx * t.fy));
-}
-
+// ---------------------------------------------------------------------------------------------- backward
+// Deterministic gather: one thread per patch texel (v, u) collects, sample by sample and pixel by pixel in a fixed
+// order, what the forward pass spread over it -- no float atomics, no zero-initialised output, run-to-run bitwise
+// identical (an attack is a chain of sign() steps: bit-reproducible gradients make it replayable).
+//   forward:  adv[n,c,oy,ox] = sum_{Y in {y0,y1}, X in {x0,x1}} wy wx [ scene (1 - mk) + o mk ](Y, X),
+//             o(Y,X) = bilinear(patch, S_n(X, Y)),  mk = bilinear(mask, S_n(X, Y))          (S_n: the homography)
+//   backward: g_patch[c,v,u] = sum_n sum_{(X,Y): texel (v,u) is a tap of S_n(X,Y)} tent * mk(Y,X) * G_n,c(Y,X),
+//             G_n,c(Y,X)     = sum_{(oy,ox): (Y,X) is a resize tap of (oy,ox)} wy wx g_adv[n,c,oy,ox]
+// The composite pixels (X, Y) that can reach a texel are those inside the image, under the inverse homography, of
+// the 2x2-texel square around it: a handful (the object is 0.4-0.9 scene pixels per texel at 5-10 m).
 __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, const float* __restrict__ g_adv,
                                                        float* __restrict__ g_patch) {
-    const int n = blockIdx.y;
     const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= a.OH * a.OW) return;
-    const int oy = idx / a.OW;
-    int ox = idx - oy * a.OW;
-    if (a.flip && a.flip[n]) ox = a.OW - 1 - ox;
-    const Homog m = load_homog(a.coeffs + n * 8, a.SW, a.SH);
-    const RTap r = resize_tap(oy, ox, a.SH, a.SW, a.OH, a.OW);
+    if (idx >= a.PH * a.PW) return;
+    const int v = idx / a.PW, u = idx - v * a.PW;
+    const float Uc = (float)(u + a.l_pad) + 0.5f, Vc = (float)(v + a.t_pad) + 0.5f;   // texel centre, padded frame
     const size_t ohw = (size_t)a.OH * a.OW, phw = (size_t)a.PH * a.PW;
-    const int Ys[2] = {r.y0, r.y1}, Xs[2] = {r.x0, r.x1};
-    const float wy[2] = {1.f - r.ly, r.ly}, wx[2] = {1.f - r.lx, r.lx};
-    float g[3];
-    bool loaded = false;
+    const float rh = (float)a.SH / (float)a.OH, rw = (float)a.SW / (float)a.OW;
+    const float irh = (float)a.OH / (float)a.SH, irw = (float)a.OW / (float)a.SW;
+    const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    for (int n = 0; n < a.N; ++n) {
+        const float* c = a.coeffs + n * 8;
+        const Homog m = load_homog(c, a.SW, a.SH);
+        // adjugate of M = [[c0,c1,c2],[c3,c4,c5],[c6,c7,1]] (source = M * scene, pixel-centre coordinates)
+        const float i00 = c[4] - c[5] * c[7], i01 = c[2] * c[7] - c[1], i02 = c[1] * c[5] - c[2] * c[4];
+        const float i10 = c[5] * c[6] - c[3], i11 = c[0] - c[2] * c[6], i12 = c[2] * c[3] - c[0] * c[5];
+        const float i20 = c[3] * c[7] - c[4] * c[6], i21 = c[1] * c[6] - c[0] * c[7], i22 = c[0] * c[4] - c[1] * c[3];
+        float xmin = 3.0e38f, xmax = -3.0e38f, ymin = 3.0e38f, ymax = -3.0e38f;
+        bool ok = true;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float w = wy[j] * wx[i];
-            if (w == 0.f) continue;
-            const PTap t = patch_tap(m, Xs[i], Ys[j], a.l_pad, a.t_pad, a.PW, a.PH);
-            if (!t.any) continue;
-            const float mk = a.mode == DMH_PASTE_WARP_ONLY ? 1.f : patch_sample(a.pmask, t, a.PW, a.PH);
-            if (mk == 0.f) continue;
-            if (!loaded) {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) g[c] = g_adv[((size_t)n * 3 + c) * ohw + idx];
-                loaded = true;
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) patch_scatter(g_patch + c * phw, t, a.PW, a.PH, g[c] * w * mk);
+        for (int q = 0; q < 4; ++q) {
+            const float px = Uc + ((q & 1) ? 1.f : -1.f), py = Vc + ((q & 2) ? 1.f : -1.f);
+            const float w = i20 * px + i21 * py + i22;   // adjugate: the common factor det(M) cancels in the ratios
+            const float xs = (i00 * px + i01 * py + i02) / w, ys = (i10 * px + i11 * py + i12) / w;
+            ok = ok && (xs == xs) && (ys == ys) && (c[6] * xs + c[7] * ys + 1.0f > 0.f);   // finite, in front of the horizon
+            xmin = fminf(xmin, xs);
+            xmax = fmaxf(xmax, xs);
+            ymin = fminf(ymin, ys);
+            ymax = fmaxf(ymax, ys);
         }
+        if (!ok) continue;
+        // candidates: pixel centres X + 0.5 inside the box (weights vanish at its border, so rounding there is harmless)
+        const int Xlo = max(0, (int)ceilf(xmin - 0.5f - 1e-3f)), Xhi = min(a.SW - 1, (int)floorf(xmax - 0.5f + 1e-3f));
+        const int Ylo = max(0, (int)ceilf(ymin - 0.5f - 1e-3f)), Yhi = min(a.SH - 1, (int)floorf(ymax - 0.5f + 1e-3f));
+        if (Xhi - Xlo > 64 || Yhi - Ylo > 64) continue;            // degenerate projection (object filling the frame)
+        const bool flip = a.flip && a.flip[n];
+        const float* g0 = g_adv + (size_t)n * 3 * ohw;
+        for (int Y = Ylo; Y <= Yhi; ++Y)
+            for (int X = Xlo; X <= Xhi; ++X) {
+                const PTap t = patch_tap(m, X, Y, a.l_pad, a.t_pad, a.PW, a.PH);
+                if (!t.any) continue;
+                const float wu = (u == t.x0) ? 1.f - t.fx : (u == t.x0 + 1 ? t.fx : 0.f);
+                const float wv = (v == t.y0) ? 1.f - t.fy : (v == t.y0 + 1 ? t.fy : 0.f);
+                float w = wu * wv;
+                if (w == 0.f) continue;
+                if (!warp_only) w *= patch_sample(a.pmask, t, a.PW, a.PH);
+                if (w == 0.f) continue;
+                // adjoint of the resize: output pixels whose bilinear taps include (Y, X)
+                const int oylo = max(0, (int)floorf(((float)Y - 0.5f) * irh - 0.5f)), oyhi = min(a.OH - 1, (int)ceilf(((float)Y + 1.5f) * irh - 0.5f));
+                const int oxlo = max(0, (int)floorf(((float)X - 0.5f) * irw - 0.5f)), oxhi = min(a.OW - 1, (int)ceilf(((float)X + 1.5f) * irw - 0.5f));
+                float G0 = 0.f, G1 = 0.f, G2 = 0.f;
+                for (int oy = oylo; oy <= oyhi; ++oy) {
+                    const float sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+                    const int y0 = (int)sy, y1 = y0 + (y0 < a.SH - 1 ? 1 : 0);
+                    const float ly = sy - (float)y0;
+                    const float wyy = (y0 == Y ? 1.f - ly : 0.f) + (y1 == Y ? ly : 0.f);
+                    if (wyy == 0.f) continue;
+                    for (int ox = oxlo; ox <= oxhi; ++ox) {
+                        const float sx = fmaxf(rw * ((float)ox + 0.5f) - 0.5f, 0.f);
+                        const int x0 = (int)sx, x1 = x0 + (x0 < a.SW - 1 ? 1 : 0);
+                        const float lx = sx - (float)x0;
+                        const float wxx = (x0 == X ? 1.f - lx : 0.f) + (x1 == X ? lx : 0.f);
+                        if (wxx == 0.f) continue;
+                        const size_t o = (size_t)oy * a.OW + (flip ? a.OW - 1 - ox : ox);
+                        const float ww = wyy * wxx;
+                        G0 = fmaf(ww, g0[o], G0);
+                        G1 = fmaf(ww, g0[ohw + o], G1);
+                        G2 = fmaf(ww, g0[2 * ohw + o], G2);
+                    }
+                }
+                acc0 = fmaf(w, G0, acc0);
+                acc1 = fmaf(w, G1, acc1);
+                acc2 = fmaf(w, G2, acc2);
+            }
+    }
+    g_patch[idx] = acc0;
+    g_patch[phw + idx] = acc1;
+    g_patch[2 * phw + idx] = acc2;
 }
 
 int check_paste(const dmh_paste_args* a) {
@@ -209,8 +255,8 @@ int dmh_eot_paste_fwd(const dmh_paste_args* a, float* adv, float* mask_out, void
 int dmh_eot_paste_bwd(const dmh_paste_args* a, const float* g_adv, float* g_patch, void* stream) {
     if (int rc = check_paste(a)) return rc;
     DMH_REQUIRE(g_adv && g_patch, "null gradient buffers");
-    hipLaunchKernelGGL(paste_bwd_kernel, dim3((a->OH * a->OW + NT - 1) / NT, a->N), dim3(NT), 0, (hipStream_t)stream,
-                       *a, g_adv, g_patch);
+    hipLaunchKernelGGL(paste_bwd_kernel, dim3((a->PH * a->PW + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, *a, g_adv,
+                       g_patch);
     return check_launch("dmh_eot_paste_bwd");
 }
 

@@ -332,7 +332,7 @@ class _EotPaste(torch.autograd.Function):
         l_pad, t_pad, OH, OW, mode = ctx.geo
         lib = N.lib()
         a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, ctx.flip)
-        g_patch = torch.zeros_like(patch)
+        g_patch = torch.empty_like(patch)
         N.check(lib.dmh_eot_paste_bwd(C.byref(a), N.ptr(_c(g_adv)), N.ptr(g_patch), N.stream()))
         return None, g_patch, None, None, None, None, None, None, None, None
 

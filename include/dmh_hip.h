@@ -170,7 +170,8 @@ typedef struct dmh_paste_args {
 
 /* adv [N,3,OH,OW], mask_out [N,1,OH,OW] (either may be NULL) */
 int dmh_eot_paste_fwd(const dmh_paste_args* a, float* adv, float* mask_out, void* stream);
-/* g_patch [1,3,PH,PW] must be zeroed by the caller; accumulated with float atomics. */
+/* g_patch [1,3,PH,PW] is overwritten (gather per patch texel over the inverse homography: no atomics, bitwise
+ * reproducible; the caller does not have to zero it). */
 int dmh_eot_paste_bwd(const dmh_paste_args* a, const float* g_adv, float* g_patch, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -300,3 +300,34 @@ def test_update_adv_obj_equals_the_oracle_attack():
     same = ((got - ref_patch).abs() < 1e-5).float().mean().item()
     assert same >= 0.995, same
     assert not torch.equal(got, obj) and ds.adv_trans.obj_img is ds.obj_img_adv
+
+
+def test_attack_is_bitwise_reproducible():
+    """A full 3-step Phy_obj_atk run twice from the same seeds: every returned tensor identical bit for bit (K3's
+    backward is a gather, K6 / K4 have fixed reduction orders; nothing on the attack path uses float atomics)."""
+    ta, attack_ref, synth, obj, mask = _setup()
+    scenes = synth.kitti_like(3, 3, 375, 1242, torch.Generator().manual_seed(12)).cuda()
+    model = synth.TinyDepthNet(seed=6).cuda()
+    outs = []
+    for _ in range(2):
+        atk = ta.Phy_obj_atk(model, obj.cuda(), mask.cuda(), eps=0.1, alpha=0.02, steps=3, dist_range=list(np.arange(5, 10, 0.2)))
+        _seed_all(31)
+        outs.append(atk(scenes, 3))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # and the gradient kernel itself, on a large upstream gradient
+    from depthmodelhardening_amd import ops
+    pt = attack_ref.PhysicalTransRef(obj, mask, dist_range=attack_ref.TRAIN_DIST_RANGE)
+    from oracle import tv082
+    start = [list(map(float, p)) for p in pt.pos_obj_img_start]
+    coeffs = torch.tensor([tv082.get_perspective_coeffs(start, [list(map(float, p)) for p in pt.obj_pos_on_image(z, al)])
+                           for z, al in ((5.0, -30), (7.4, 10), (9.8, 25))], dtype=torch.float32).cuda()
+    l_pad, t_pad = pt.pos_obj_img_start[0]
+    gadv = (torch.rand(3, 3, 320, 1024, generator=torch.Generator().manual_seed(2)) - 0.5).cuda()
+    grads = []
+    for _ in range(2):
+        p = obj.cuda().requires_grad_(True)
+        adv, _ = ops.eot_paste(scenes, p, mask.cuda(), coeffs, l_pad, t_pad, (320, 1024))
+        (adv * gadv).sum().backward()
+        grads.append(p.grad.clone())
+    assert torch.equal(grads[0], grads[1]) and float(grads[0].abs().sum()) > 0
