@@ -138,6 +138,119 @@ __global__ __launch_bounds__(NT) void paste_fwd_kernel(const dmh_paste_args a, f
         mask_out[(size_t)n * ohw + idx] = hy * (hx * mm[0][0] + r.lx * mm[0][1]) + r.ly * (hx * mm[1][0] + r.lx * mm[1][1]);
 }
 
+// Four output pixels of one row per thread (OW % 4 == 0): the row taps are formed once, groups whose source
+// footprint lies outside the object's bounding box skip the homography and the patch altogether (87 % of a frame at
+// 5-10 m) and reduce to the plain bilinear resize of the scene, results leave as 16-byte stores.  With `flip` the
+// thread computes the mirrored group and stores it reversed.
+__global__ __launch_bounds__(NT) void paste_fwd4_kernel(const dmh_paste_args a, float* __restrict__ adv,
+                                                        float* __restrict__ mask_out) {
+    const int n = blockIdx.y;
+    const int gpr = a.OW >> 2;                       // groups per row
+    const int gid = blockIdx.x * NT + threadIdx.x;
+    if (gid >= a.OH * gpr) return;
+    const int oy = gid / gpr, gx = gid - oy * gpr;
+    const bool flip = a.flip && a.flip[n];
+    const int ox0 = (flip ? gpr - 1 - gx : gx) << 2;   // first source column of the group that is computed
+    const float* c = a.coeffs + n * 8;
+    const Homog m = load_homog(c, a.SW, a.SH);
+    const float rh = (float)a.SH / (float)a.OH, rw = (float)a.SW / (float)a.OW;
+    const float sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, y1 = y0 + (y0 < a.SH - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    // object bounding box in the scene: image of the patch rectangle (one texel of margin) under the inverse homography
+    float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
+    bool box_ok = true;
+    {
+        const float i00 = c[4] - c[5] * c[7], i01 = c[2] * c[7] - c[1], i02 = c[1] * c[5] - c[2] * c[4];
+        const float i10 = c[5] * c[6] - c[3], i11 = c[0] - c[2] * c[6], i12 = c[2] * c[3] - c[0] * c[5];
+        const float i20 = c[3] * c[7] - c[4] * c[6], i21 = c[1] * c[6] - c[0] * c[7], i22 = c[0] * c[4] - c[1] * c[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float px = (float)a.l_pad + ((q & 1) ? (float)a.PW + 1.f : -1.f);
+            const float py = (float)a.t_pad + ((q & 2) ? (float)a.PH + 1.f : -1.f);
+            const float w = i20 * px + i21 * py + i22;
+            const float xs = (i00 * px + i01 * py + i02) / w, ys = (i10 * px + i11 * py + i12) / w;
+            box_ok = box_ok && (xs == xs) && (ys == ys) && (c[6] * xs + c[7] * ys + 1.0f > 0.f);
+            bx0 = fminf(bx0, xs);
+            bx1 = fmaxf(bx1, xs);
+            by0 = fminf(by0, ys);
+            by1 = fmaxf(by1, ys);
+        }
+    }
+    const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW, ohw = (size_t)a.OH * a.OW;
+    const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
+    const float* sc = warp_only ? nullptr : a.scene + (size_t)n * a.scene_bstride;
+    // source columns of the group
+    int x0[4], x1[4];
+    float lx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float sx = fmaxf(rw * ((float)(ox0 + i) + 0.5f) - 0.5f, 0.f);
+        x0[i] = (int)sx;
+        x1[i] = x0[i] + (x0[i] < a.SW - 1 ? 1 : 0);
+        lx[i] = sx - (float)x0[i];
+    }
+    // pixel centres (X + 0.5, Y + 0.5) of the footprint against the box
+    const bool outside = box_ok && ((float)x1[3] + 0.5f < bx0 || (float)x0[0] + 0.5f > bx1 || (float)y1 + 0.5f < by0 ||
+                                    (float)y0 + 0.5f > by1);
+    float res[3][4], mres[4];
+    if (outside) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) mres[i] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float* r0 = sc + ch * shw + (size_t)y0 * a.SW;
+            const float* r1 = sc + ch * shw + (size_t)y1 * a.SW;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float hx = 1.f - lx[i];
+                res[ch][i] = warp_only ? 0.f : hy * (hx * r0[x0[i]] + lx[i] * r0[x1[i]]) + ly * (hx * r1[x0[i]] + lx[i] * r1[x1[i]]);
+            }
+        }
+    } else {
+        const int Ys[2] = {y0, y1};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int Xs[2] = {x0[i], x1[i]};
+            float comp[2][2][3], mm[2][2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int Y = Ys[j], X = Xs[q];
+                    const size_t so = (size_t)Y * a.SW + X;
+                    const PTap t = patch_tap(m, X, Y, a.l_pad, a.t_pad, a.PW, a.PH);
+                    float mk = 0.f;
+                    if (t.any) mk = patch_sample(a.pmask, t, a.PW, a.PH);
+                    mm[j][q] = mk;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        float o = 0.f;
+                        if (t.any) o = patch_sample(a.patch + ch * phw, t, a.PW, a.PH);
+                        comp[j][q][ch] = warp_only ? o : sc[ch * shw + so] * (1.f - mk) + o * mk;  // phy_obj_atk.py:88
+                    }
+                }
+            const float hx = 1.f - lx[i];
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                res[ch][i] = hy * (hx * comp[0][0][ch] + lx[i] * comp[0][1][ch]) + ly * (hx * comp[1][0][ch] + lx[i] * comp[1][1][ch]);
+            mres[i] = hy * (hx * mm[0][0] + lx[i] * mm[0][1]) + ly * (hx * mm[1][0] + lx[i] * mm[1][1]);
+        }
+    }
+    const size_t o = (size_t)oy * a.OW + ((size_t)gx << 2);
+    if (adv) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float4 v = flip ? make_float4(res[ch][3], res[ch][2], res[ch][1], res[ch][0])
+                                  : make_float4(res[ch][0], res[ch][1], res[ch][2], res[ch][3]);
+            *reinterpret_cast<float4*>(adv + ((size_t)n * 3 + ch) * ohw + o) = v;
+        }
+    }
+    if (mask_out)
+        *reinterpret_cast<float4*>(mask_out + (size_t)n * ohw + o) =
+            flip ? make_float4(mres[3], mres[2], mres[1], mres[0]) : make_float4(mres[0], mres[1], mres[2], mres[3]);
+}
+
 // ---------------------------------------------------------------------------------------------- backward
 // Deterministic gather: one thread per patch texel (v, u) collects, sample by sample and pixel by pixel in a fixed
 // order, what the forward pass spread over it -- no float atomics, no zero-initialised output, run-to-run bitwise
@@ -247,8 +360,14 @@ extern "C" {
 int dmh_eot_paste_fwd(const dmh_paste_args* a, float* adv, float* mask_out, void* stream) {
     if (int rc = check_paste(a)) return rc;
     DMH_REQUIRE(adv || mask_out, "no output requested");
-    hipLaunchKernelGGL(paste_fwd_kernel, dim3((a->OH * a->OW + NT - 1) / NT, a->N), dim3(NT), 0, (hipStream_t)stream,
-                       *a, adv, mask_out);
+    const bool vec4 = (a->OW % 4) == 0 && ((uintptr_t)adv % 16) == 0 && ((uintptr_t)mask_out % 16) == 0 &&
+                      (a->mode == DMH_PASTE_WARP_ONLY || a->scene != nullptr);
+    if (vec4)
+        hipLaunchKernelGGL(paste_fwd4_kernel, dim3((a->OH * (a->OW / 4) + NT - 1) / NT, a->N), dim3(NT), 0, (hipStream_t)stream,
+                           *a, adv, mask_out);
+    else
+        hipLaunchKernelGGL(paste_fwd_kernel, dim3((a->OH * a->OW + NT - 1) / NT, a->N), dim3(NT), 0, (hipStream_t)stream,
+                           *a, adv, mask_out);
     return check_launch("dmh_eot_paste_fwd");
 }
 

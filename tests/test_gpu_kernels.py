@@ -451,3 +451,25 @@ def test_full_size_properties():
     o = ops.photometric_smooth_loss(left, [right], [T], K, inv_K, [d.detach() for d in disps], colors, noise=None)
     for s in range(4):
         assert abs(float(o.fin[N.FIN_COUNT_S + s]) - float((o.sel[s] > 0).sum())) <= 2.0
+
+
+@pytest.mark.parametrize("out_size", [(320, 1024), (375, 1242), (64, 190)])
+def test_eot_paste_flip_is_the_mirrored_paste(out_size):
+    """flip[n] != 0: the whole composite of sample n is written mirrored (mono_dataset.py:222-225 on an un-flipped frame);
+    both the 4-pixel-per-thread kernel (OW % 4 == 0) and the generic one; gradients follow."""
+    N, ops, _, attack_ref, synth, tv082 = _mods()
+    obj, mask, scenes, pt, z0, al, coeffs, l_pad, t_pad = _paste_case(attack_ref, synth, tv082, 3, 5)
+    flip = torch.tensor([1, 0, 1], dtype=torch.int32).cuda()
+    p0 = obj.cuda().requires_grad_(True)
+    a0, m0 = ops.eot_paste(scenes.cuda(), p0, mask.cuda(), coeffs.cuda(), l_pad, t_pad, out_size)
+    p1 = obj.cuda().requires_grad_(True)
+    a1, m1 = ops.eot_paste(scenes.cuda(), p1, mask.cuda(), coeffs.cuda(), l_pad, t_pad, out_size, flip)
+    for n in range(3):
+        want_a, want_m = (a0[n].flip(2), m0[n].flip(2)) if int(flip[n]) else (a0[n], m0[n])
+        assert torch.equal(a1[n], want_a) and torch.equal(m1[n], want_m)
+    gadv = torch.rand(a0.shape, generator=torch.Generator().manual_seed(1)).cuda() - 0.5
+    (a0 * gadv).sum().backward()
+    gflip = gadv.clone()
+    gflip[0], gflip[2] = gadv[0].flip(2), gadv[2].flip(2)
+    (a1 * gflip).sum().backward()
+    assert torch.equal(p0.grad, p1.grad)
