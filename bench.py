@@ -30,9 +30,13 @@ sys.path.insert(0, REPO)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak of MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290
 
-# HBM bytes per launch measured with rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE in KiB, the gfx950 correction of
-# MI355X_MICROARCH.md section HBM) for the profiled shape; see profiles/README.md.  Keyed by (B, H, W).
-MEASURED_TRAFFIC = {(32, 320, 1024): {"photo_fwd": None, "photo_bwd": None, "source": "profiles/r02_k1k2_pmc.csv"}}
+# HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate passes) for the profiled
+# shape, keyed by (B, H, W); see profiles/README.md.  FETCH_SIZE is taken 1:1: these kernels read one dword per lane,
+# and the x2 correction of MI355X_MICROARCH.md section HBM is for 16-byte-per-lane streaming reads only ("other access
+# widths are uncalibrated: calibrate on a known byte count in your own access pattern") -- calibrated on
+# smooth_fwd_kernel, which reads its 222.9 MB exactly once and reports FETCH_SIZE = 198.8 MB.  The backward reports
+# fewer bytes than its algorithmic reads because the images are still in the 256 MB Infinity Cache from the forward.
+MEASURED_TRAFFIC = {(32, 320, 1024): {"photo_fwd": 328.6e6, "photo_bwd": 219.0e6, "source": "profiles/r02_k1k2_pmc.csv"}}
 
 
 def k1_bytes(B, H, W, scales=4):

@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G = "gpurun_out/prof_%s/" % tag
 os.makedirs("profiles", exist_ok=True)
 
@@ -49,11 +49,35 @@ with open("profiles/%s_k1k2_pmc.csv" % tag, "w") as f:
     w.writerow(["Kernel", "VGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"] + cols)
     for k, v in tabs.items():
         w.writerow([k] + list(v["_meta"]) + [round(v.get(c, 0)) for c in cols])
+# FETCH_SIZE calibration for THIS access pattern (one dword per lane, coalesced rows): smooth_fwd_kernel reads the
+# disparity and colour pyramids exactly once = 16 B per low-resolution pixel (MI355X_MICROARCH.md: "other access widths
+# are uncalibrated: calibrate on a known byte count in your own access pattern"); the x2 of the guide applies to
+# 16-byte-per-lane streaming reads only.
 for k, v in tabs.items():
-    if "photo" in k:
-        rd, wr = 2 * v.get("FETCH_SIZE", 0) * 1024, v.get("WRITE_SIZE", 0) * 1024
-        print("%-50s HBM traffic = 2*FETCH_SIZE + WRITE_SIZE = %.1f + %.1f = %.1f MB per launch" % (
+    if "photo" in k or "smooth" in k:
+        rd, wr = v.get("FETCH_SIZE", 0) * 1024, v.get("WRITE_SIZE", 0) * 1024
+        print("%-50s FETCH_SIZE %.1f MB + WRITE_SIZE %.1f MB = %.1f MB per launch (dword loads: FETCH_SIZE taken 1:1)" % (
             k[:50], rd / 1e6, wr / 1e6, (rd + wr) / 1e6))
+
+ks3 = first(G + "k3_trace/*/*_kernel_stats.csv")
+if ks3:
+    shutil.copy(ks3, "profiles/%s_k3_kernel_stats.csv" % tag)
+tabs3 = {}
+for d in ["k3_pmc_a", "k3_fetch", "k3_write"]:
+    t, meta = pmc(d)
+    for k, v in t.items():
+        if "paste_" in k:
+            tabs3.setdefault(k, {}).update(v)
+            tabs3[k]["_meta"] = meta[k]
+if tabs3:
+    cols = sorted({c for v in tabs3.values() for c in v if c != "_meta"})
+    with open("profiles/%s_k3_pmc.csv" % tag, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel", "VGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"] + cols)
+        for k, v in tabs3.items():
+            w.writerow([k] + list(v["_meta"]) + [round(v.get(c, 0)) for c in cols])
+            print("%-50s FETCH_SIZE %.1f MB WRITE_SIZE %.1f MB" % (k[:50], v.get("FETCH_SIZE", 0) * 1024 / 1e6,
+                                                                  v.get("WRITE_SIZE", 0) * 1024 / 1e6))
 
 ks10 = first(G + "k10_trace/*/*_kernel_stats.csv")
 if ks10:
