@@ -44,13 +44,44 @@ def make_attack(model_rob, attack, device, steps=atk_step, eps=atk_eps, alpha=at
     return Phy_obj_atk(model_rob, obj_tensor, mask_tensor, eps=eps, alpha=alpha, steps=steps)
 
 
+MAX_OBJ_BATCH = 12      # physicalTrans.py:150,155 draw (z0, alpha) WITHOUT replacement from 25 / 13 values: at most 13 scenes
+
+
 def attack_scenes(depth_atk, attack, scene_img, batch_size, eval=False):
-    """-> (adversarial [B,3,320,1024], benign [B,3,320,1024], object mask or None)."""
+    """-> (adversarial [B,3,320,1024], benign [B,3,320,1024], object mask or None).
+
+    The object attack cannot take more than 13 scenes (its poses are drawn without replacement from 13 angles; the
+    reference's own loops use batch 6).  BASELINE config 5 asks for batch 32: the patch is then optimised on the first
+    12 scenes and pasted into the remaining ones in groups of <= 12 by further zero-step calls (fresh pose draws per
+    group), i.e. one attack per iteration as in the reference, applied to all scenes."""
     if attack == "image":
         adv, ben = depth_atk(scene_img)
         return adv, ben, None
-    adv, ben, masks, _ = depth_atk(scene_img, batch_size, eval=eval)
-    return adv, ben, masks
+    if batch_size <= MAX_OBJ_BATCH + 1:
+        adv, ben, masks, _ = depth_atk(scene_img, batch_size, eval=eval)
+        return adv, ben, masks
+    outs, steps = [], depth_atk.steps
+    first = scene_img[:MAX_OBJ_BATCH]
+    adv, ben, masks, patch = depth_atk(first, MAX_OBJ_BATCH, eval=eval)
+    outs.append((adv, ben, masks))
+    saved_obj, saved_rs = depth_atk.obj_img, depth_atk.random_start
+    try:
+        # paste-only passes: the optimised patch is the "object", zero steps, no random start; the benign view of
+        # these groups is pasted from the original object afterwards
+        for lo in range(MAX_OBJ_BATCH, batch_size, MAX_OBJ_BATCH):
+            grp = scene_img[lo:lo + MAX_OBJ_BATCH]
+            depth_atk.steps, depth_atk.random_start = 0, False
+            depth_atk.obj_img = patch.detach()
+            import random as _r
+            state = _r.getstate()
+            adv_g, _, masks_g, _ = depth_atk(grp, grp.shape[0])
+            _r.setstate(state)                      # same pose draws for the benign paste of this group
+            depth_atk.obj_img = saved_obj
+            _, ben_g, _, _ = depth_atk(grp, grp.shape[0])
+            outs.append((adv_g, ben_g, masks_g))
+    finally:
+        depth_atk.steps, depth_atk.random_start, depth_atk.obj_img = steps, saved_rs, saved_obj
+    return tuple(torch.cat([o[i] for o in outs], 0) for i in range(3))
 
 
 def eval_atk_perf(model_gt, model, data, depth_atk, attack, batch_size, eval_count=100):
@@ -73,11 +104,12 @@ def eval_atk_perf(model_gt, model, data, depth_atk, attack, batch_size, eval_cou
 class HardeningJob(object):
     """State of the loop: frozen model, model being hardened, attack, Adam, gradient bucket."""
 
-    def __init__(self, batch_size=6, steps=atk_step, rank=0, world_size=1, device=None, attack="object", seed=17, lr=0.0001):
+    def __init__(self, batch_size=6, steps=atk_step, rank=0, world_size=1, device=None, attack="object", seed=17, lr=0.0001,
+                 model=None):
         self.batch_size, self.rank, self.world_size, self.attack = batch_size, rank, world_size, attack
         self.device = device if device is not None else torch.device("cuda")
         torch.manual_seed(seed)
-        self.model_ori = import_depth_model(scene_size).to(self.device).eval()
+        self.model_ori = (import_depth_model(scene_size) if model is None else model).to(self.device).eval()
         self.model_rob = copy.deepcopy(self.model_ori).to(self.device)
         for p in self.model_ori.parameters():
             p.requires_grad_(False)
@@ -85,7 +117,8 @@ class HardeningJob(object):
             broadcast_parameters([self.model_ori, self.model_rob])
         self.data = SyntheticKITTIDataset(scene_size[1], scene_size[0], [0, "s"], 4, 1 << 30, self.device, seed=seed + rank)
         self.optimizer = torch.optim.Adam(self.model_rob.parameters(), lr=lr)
-        fc_ids = {id(p) for p in self.model_rob.encoder.encoder.fc.parameters()}       # never receives a gradient
+        enc = getattr(getattr(self.model_rob, "encoder", None), "encoder", None)
+        fc_ids = {id(p) for p in enc.fc.parameters()} if enc is not None and hasattr(enc, "fc") else set()   # never gets a gradient
         self.bucket = GradBucket([p for p in self.model_rob.parameters() if id(p) not in fc_ids], world_size)
         self.depth_atk = make_attack(self.model_rob, attack, self.device, steps=steps)
         self._pending = False
