@@ -124,17 +124,37 @@ def generate_images_pred(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3
             outputs[("color_identity", frame_id, scale)] = inputs[("color", frame_id, 0)]
 
 
+def warp_hint(depth_hint, source, K, inv_K, T, H, W):
+    """depth-hints/trainer.py:510-525: the source view warped with the depth HINT.  The reference calls
+    F.grid_sample(..., padding_mode="border") without align_corners here, i.e. align_corners=False (the default since
+    torch 1.3), unlike the main warp (:500-504)."""
+    cam = backproject(depth_hint, inv_K)
+    grid = project3d(cam, K, T, H, W)
+    return F.grid_sample(source, grid, padding_mode="border", align_corners=False)
+
+
 def compute_losses(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), noise=None,
-                   smooth_wt=SMOOTH_WT, variant="md2"):
+                   smooth_wt=SMOOTH_WT, variant="md2", use_depth_hints=False):
     """trainer.py:588-674 (variant="md2") or depth-hints/trainer.py:638-741
     (variant="dh", no depth hints), photometric + smoothness part only.
 
     ``noise``: dict scale -> tensor shaped like the identity loss ([B,F,H,W] for md2,
     [B,1,H,W] for dh), the already-scaled tie-break term (reference: randn*1e-5,
     trainer.py:642-645); None -> zeros.
+    ``use_depth_hints`` (variant "dh" only; depth-hints/trainer.py:629-636,700-725): inputs["depth_hint"] [B,1,H,W] and
+    inputs["depth_hint_mask"]; argmin over [reprojection, identity, hint reprojection], proxy log-L1 supervision where
+    the hint wins.  Needs outputs[("depth", 0, s)] (generate_images_pred).
     Returns (losses dict, per-scale dict of to_optimise maps)."""
     losses, maps = {}, {}
     total = 0
+    hint_reproj = None
+    if use_depth_hints:
+        assert variant == "dh" and frame_ids[1:] == ("s",)
+        H, W = inputs[("color", 0, 0)].shape[-2:]
+        pred = warp_hint(inputs["depth_hint"], inputs[("color", "s", 0)], inputs[("K", 0)], inputs[("inv_K", 0)],
+                         inputs["stereo_T"], H, W)
+        outputs[("color_depth_hint", "s", 0)] = pred
+        hint_reproj = compute_reprojection_loss(pred, inputs[("color", 0, 0)]) + 1000 * (1 - inputs["depth_hint_mask"])
     for scale in scales:
         disp = outputs[("disp", scale)]
         color = inputs[("color", 0, scale)]
@@ -156,13 +176,22 @@ def compute_losses(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), noi
             reproj, _ = torch.min(reproj, dim=1, keepdim=True)
             if noise is not None:
                 ident = ident + noise[scale]
-            idxs = torch.argmin(torch.cat([reproj, ident], dim=1), dim=1, keepdim=True)
+            cands = [reproj, ident] + ([hint_reproj] if hint_reproj is not None else [])
+            idxs = torch.argmin(torch.cat(cands, dim=1), dim=1, keepdim=True)
             mask = (idxs != 1).float()
             rl = (reproj * mask).sum() / (mask.sum() + 1e-7)
             outputs["identity_selection/{}".format(scale)] = (1 - mask).float()
             losses["reproj_loss/{}".format(scale)] = rl
             loss = rl
             maps[scale] = reproj * mask
+            if hint_reproj is not None:
+                hmask = (idxs == 2).float()
+                pred_depth = outputs[("depth", 0, scale)]
+                hl = torch.log(torch.abs(inputs["depth_hint"] - pred_depth) + 1) * inputs["depth_hint_mask"] * hmask
+                hl = hl.sum() / (hmask.sum() + 1e-7)
+                outputs["depth_hint_pixels/{}".format(scale)] = hmask
+                losses["depth_hint_loss/{}".format(scale)] = hl
+                loss = loss + hl
         smooth = normalised_smooth_loss(disp, color)
         loss = loss + smooth_wt * smooth / (2 ** scale)
         total = total + loss

@@ -144,12 +144,12 @@ def gold_layers(layers):
 
 
 # --------------------------------------------------------------------------- losses
-def _fake_trainer(trainer_mod, layers, B, H, W, module_name):
+def _fake_trainer(trainer_mod, layers, B, H, W, module_name, use_depth_hints=False):
     opt = SimpleNamespace(scales=[0, 1, 2, 3], v1_multiscale=False, height=H, width=W, min_depth=0.1,
                           max_depth=100.0, frame_ids=[0, "s"], pose_model_type="separate_resnet",
                           disable_automasking=False, no_ssim=False, adv_train=False, supervised_adv=False,
                           contrastive_learning=False, no_original_train=False, avg_reprojection=False,
-                          predictive_mask=False, disparity_smoothness=1e-3, use_depth_hints=False)
+                          predictive_mask=False, disparity_smoothness=1e-3, use_depth_hints=use_depth_hints)
     self = SimpleNamespace(opt=opt, num_scales=4, ssim=layers.SSIM(), backproject_depth={}, project_3d={})
     for s in opt.scales:
         self.backproject_depth[s] = layers.BackprojectDepth(B, H // 2 ** s, W // 2 ** s)
@@ -162,12 +162,12 @@ def _fake_trainer(trainer_mod, layers, B, H, W, module_name):
     return self, T
 
 
-def _run_loss(trainer_mod, layers, case, noise, variant):
+def _run_loss(trainer_mod, layers, case, noise, variant, use_depth_hints=False):
     """Run the reference generate_images_pred + compute_losses + backward.  ``noise`` is a list of four
     standard-normal tensors (one per scale) that the patched torch.randn hands out, or None -> zeros."""
     inputs, disps = case
     B, _, H, W = inputs[("color", 0, 0)].shape
-    self, T = _fake_trainer(trainer_mod, layers, B, H, W, variant)
+    self, T = _fake_trainer(trainer_mod, layers, B, H, W, variant, use_depth_hints)
     outputs = {}
     leaves = []
     for s, d in enumerate(disps):
@@ -200,6 +200,11 @@ def _run_loss(trainer_mod, layers, case, noise, variant):
         res["warped_%d" % s] = outputs[("color", "s", s)]
         if "reproj_loss/%d" % s in losses:
             res["reproj_loss_%d" % s] = losses["reproj_loss/%d" % s]
+        if "depth_hint_loss/%d" % s in losses:
+            res["depth_hint_loss_%d" % s] = losses["depth_hint_loss/%d" % s]
+            res["depth_hint_pixels_%d" % s] = outputs["depth_hint_pixels/%d" % s]
+    if ("color_depth_hint", "s", 0) in outputs:
+        res["warped_hint"] = outputs[("color_depth_hint", "s", 0)]
     res["depth_0"] = outputs[("depth", 0, 0)]
     res["sample_0"] = outputs[("sample", "s", 0)]
     return res
@@ -233,6 +238,29 @@ def gold_losses(trainer_mod, layers, tag):
                 keep[k + "_sum"] = g0.double().sum((1, 2, 3))
                 keep[k + "_abssum"] = g0.double().abs().sum((1, 2, 3))
         save("loss_%s_%s" % (tag, name), **keep)
+
+
+def gold_depth_hints(trainer_mod, layers):
+    """DepthHints with --use_depth_hints (depth-hints/trainer.py:510-525,629-636,700-725): hint warp, three-way argmin,
+    proxy log-L1 supervision; synthetic hints with holes (oracle.synth.make_depth_hint)."""
+    from oracle.synth import make_depth_hint
+    for name, (B, H, W, seed) in {"small": (2, 32, 96, 21), "cfg1": (2, 192, 640, 22)}.items():
+        inputs, disps = make_loss_case(B, H, W, seed)
+        inputs["depth_hint"], inputs["depth_hint_mask"] = make_depth_hint(B, H, W, seed + 50)
+        g = torch.Generator().manual_seed(seed + 100)
+        noise = [torch.randn(B, 1, H, W, generator=g) for _ in range(4)]
+        keep = {"shape": np.array([B, H, W, seed])}
+        for tag, nz in (("nonoise", None), ("noise", noise)):
+            res = _run_loss(trainer_mod, layers, (inputs, disps), nz, "dh", use_depth_hints=True)
+            for k, v in res.items():
+                if k.startswith(("sample", "depth_0")) or (k.startswith("warped") and (name != "small" or tag != "nonoise")):
+                    continue
+                if "identity_selection" in k or "depth_hint_pixels" in k:
+                    v = np.packbits(v.numpy().astype(np.uint8))
+                elif name != "small" and k.startswith("grad_disp"):
+                    v = v[:, :, ::3, ::3] if k.endswith("_0") else v
+                keep[tag + "_" + k] = v
+        save("loss_dh_hints_%s" % name, **keep)
 
 
 # --------------------------------------------------------------------------- attacks
@@ -449,6 +477,7 @@ def main():
     import layers as dh_layers
     import trainer as dh_trainer
     gold_losses(dh_trainer, dh_layers, "dh")
+    gold_depth_hints(dh_trainer, dh_layers)
 
 
 if __name__ == "__main__":

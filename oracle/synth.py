@@ -76,6 +76,17 @@ def make_loss_case(B, H, W, seed, disp_lo=0.01, disp_hi=0.35, dtype=torch.float3
     return inputs, disps
 
 
+def make_depth_hint(B, H, W, seed):
+    """Synthetic depth hints (DepthHints' SGM stereo estimates, depth-hints/datasets/mono_dataset.py:368-388): a smooth
+    depth field in metres-of-the-0.1-baseline units with holes (hint == 0 where no estimate), and its validity mask."""
+    g = torch.Generator().manual_seed(seed)
+    disp = smooth_field(B, H, W, g, 0.02, 0.3, k=9)
+    depth = 1.0 / (0.01 + 9.99 * disp)
+    holes = F.avg_pool2d(torch.rand(B, 1, H + 6, W + 6, generator=g), 7, 1) < 0.457      # ~15 % of the pixels, in blobs
+    depth = torch.where(holes, torch.zeros_like(depth), depth)
+    return depth.contiguous(), (depth > 0).float()
+
+
 class TinyDepthNet(nn.Module):
     """A seeded 3-layer conv net [B,3,H,W] -> sigmoid disparity [B,1,H,W] with one BatchNorm,
     so that Attack.__call__'s eval()/train() bracket (attack.py:296-312) is observable."""

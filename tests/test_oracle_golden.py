@@ -294,3 +294,37 @@ def test_prep_adv_data(golden, side, do_flip):
         torch.testing.assert_close(out[name][sub], t(g[tag + key]), rtol=1e-6, atol=1e-7)
     assert abs(float(out["color_aug_0"].double().sum()) - float(g[tag + "aug0_sum"])) <= 1e-7 * float(g[tag + "aug0_sum"])
     assert float(g[tag + "mask0_sum"]) > 100.0      # the object is in the frame
+
+
+@pytest.mark.parametrize("name", ["small", "cfg1"])
+def test_depth_hints_loss_path(golden, name):
+    """oracle/loss_ref.py with use_depth_hints against the reference's DepthHints trainer run with --use_depth_hints
+    (depth-hints/trainer.py:510-525,629-636,700-725): hint warp (align_corners=False), three-way argmin, proxy loss."""
+    from oracle.synth import make_depth_hint
+    g = golden("loss_dh_hints_" + name)
+    B, H, W, seed = [int(v) for v in g["shape"]]
+    inputs, disps = make_loss_case(B, H, W, seed)
+    inputs["depth_hint"], inputs["depth_hint_mask"] = make_depth_hint(B, H, W, seed + 50)
+    gen = torch.Generator().manual_seed(seed + 100)
+    noise = {s: torch.randn(B, 1, H, W, generator=gen) * 0.00001 for s in range(4)}
+    for tag, nz in (("nonoise", None), ("noise", noise)):
+        outputs, leaves = {}, []
+        for s, d in enumerate(disps):
+            d = d.clone().requires_grad_(True)
+            leaves.append(d)
+            outputs[("disp", s)] = d
+        loss_ref.generate_images_pred(inputs, outputs)
+        losses, _ = loss_ref.compute_losses(inputs, outputs, noise=nz, variant="dh", use_depth_hints=True)
+        losses["loss"].backward()
+        torch.testing.assert_close(losses["loss"], t(g[tag + "_loss"]), rtol=3e-6, atol=0)
+        for s in range(4):
+            for k in ("loss", "reproj_loss", "depth_hint_loss"):
+                torch.testing.assert_close(losses["%s/%d" % (k, s)], t(g["%s_%s_%d" % (tag, k, s)]), rtol=3e-6, atol=0)
+            for key, out in (("identity_selection", "identity_selection/%d"), ("depth_hint_pixels", "depth_hint_pixels/%d")):
+                ref = np.unpackbits(g["%s_%s_%d" % (tag, key, s)])[:B * H * W].reshape(B, H, W)
+                assert (outputs[out % s].reshape(B, H, W).numpy() != ref).mean() < 1e-5
+            ref_g = t(g["%s_grad_disp_%d" % (tag, s)])
+            mine = leaves[s].grad[:, :, ::3, ::3] if (name != "small" and s == 0) else leaves[s].grad
+            torch.testing.assert_close(mine, ref_g, rtol=1e-4, atol=1e-9)
+        if name == "small" and tag == "nonoise":
+            torch.testing.assert_close(outputs[("color_depth_hint", "s", 0)], t(g["nonoise_warped_hint"]), rtol=1e-5, atol=1e-6)
