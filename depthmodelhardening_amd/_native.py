@@ -14,7 +14,7 @@ MAX_FRAMES = 4
 VARIANT_MD2, VARIANT_DH = 0, 1
 NOISE_NONE, NOISE_TENSOR, NOISE_PHILOX = 0, 1, 2
 PASTE_COMPOSITE, PASTE_WARP_ONLY = 0, 1
-FIN_LOSS, FIN_LOSS_S, FIN_REPROJ_S, FIN_COUNT_S, FIN_SMOOTH_S, FIN_SIZE = 0, 1, 5, 9, 13, 20
+FIN_LOSS, FIN_LOSS_S, FIN_REPROJ_S, FIN_COUNT_S, FIN_SMOOTH_S, FIN_HINT_S, FIN_HINTCOUNT_S, FIN_SIZE = 0, 1, 5, 9, 13, 20, 24, 28
 
 LIB_PATH = os.environ.get("DMH_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib",
                                                         "libdmh_hip.so")
@@ -28,7 +28,7 @@ class PhotoArgs(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("num_frames", C.c_int), ("num_scales", C.c_int),
                 ("min_depth", C.c_float), ("max_depth", C.c_float), ("variant", C.c_int), ("automask", C.c_int),
                 ("no_ssim", C.c_int), ("noise_mode", C.c_int), ("noise", _fp * MAX_SCALES),
-                ("seed", C.c_uint64), ("offset", C.c_uint64)]
+                ("seed", C.c_uint64), ("offset", C.c_uint64), ("depth_hint", _fp), ("depth_hint_mask", _fp)]
 
 
 class SmoothArgs(C.Structure):

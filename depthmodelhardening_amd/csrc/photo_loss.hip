@@ -357,9 +357,13 @@ struct FRow {   // row sums of one image row: target (y, y^2) and per stream (x,
 
 // ------------------------------------------------------------------------------------------------ forward
 // NF source frames, SPP scales per pass (NF * (1 + SPP) streams of rolling row sums live in registers).
-template <int NF, int SPP>
+// HINT: DepthHints' extra candidate (DH/trainer.py:510-525,629-636,700-725): the source view warped with the depth
+// HINT is one more stream (formed per pass, like the identity term), the per-pixel argmin runs over [reprojection,
+// identity, hint], and where the hint wins the proxy log-L1 term is accumulated.
+template <int NF, int SPP, bool HINT>
 __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArgs k) {
-    constexpr int NSTR = NF * (1 + SPP);
+    constexpr int NSTR = NF * (1 + SPP) + (HINT ? 1 : 0);
+    constexpr int ST_HINT = NF * (1 + SPP);
     const dmh_photo_args& a = k.a;
     const int lane = threadIdx.x & (WAVE - 1);
     const int tile = wave_item();
@@ -389,6 +393,12 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
     const int nf_noise = md2 ? NF : 1;
     const int npass = (NS + SPP - 1) / SPP;
     const Philox<7> rng(a.seed);
+    const rsrc_t rhint = make_rsrc(HINT ? a.depth_hint + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
+    const rsrc_t rhmask = make_rsrc(HINT ? a.depth_hint_mask + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
+    // grid_sample(align_corners=False) of the hint warp (DH/trainer.py:523-525 omits align_corners): the sample
+    // coordinate is px * W/(W-1) - 0.5, i.e. delta' = delta * W/(W-1) + x/(W-1) - 0.5
+    const float hsx = (float)W / (float)(W - 1), hsy = (float)H / (float)(H - 1);
+    const float hox = (float)xr / (float)(W - 1) - 0.5f;
 
     for (int s0 = 0, pass = 0; s0 < NS; s0 += SPP, ++pass) {
         DispGeo dg[SPP];
@@ -404,9 +414,10 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
         }
         FRow<NSTR> rowA, rowB;
         float l1p[NSTR];       // L1 of the previous row (the centre row of the next window)
-        float acc1[SPP], acc2[SPP];
+        float acc1[SPP], acc2[SPP], acc3[SPP], acc4[SPP];
+        float sd_prev[SPP];    // scaled disparity of the previous row (depth of the centre row, for the hint term)
 #pragma unroll
-        for (int j = 0; j < SPP; ++j) acc1[j] = acc2[j] = 0.f;
+        for (int j = 0; j < SPP; ++j) acc1[j] = acc2[j] = acc3[j] = acc4[j] = sd_prev[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < NSTR; ++i) l1p[i] = 0.f;
 
@@ -459,11 +470,41 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
             RowProj rp[NF];
 #pragma unroll
             for (int f = 0; f < NF; ++f) rp[f] = row_proj(cam[f], lp[f], yr);
+            if constexpr (HINT) {
+                // the hint view: same projection with depth = hint; a missing hint (depth 0) back-projects to the
+                // origin, i.e. the pixel (P03, P13) / (P23 + 1e-7), as in the reference
+                const float dh = ldb(rhint, (unsigned)(yr * W + xr) * 4u, 0u);
+                const bool have = dh > 0.f;
+                const float sdh = have ? fast_rcp(dh) : 0.f;
+                const float rden = fast_rcp(fmaf(sdh, cam[0].m, rp[0].az));
+                float dx = fmaf(sdh, lp[0].nx, rp[0].ex) * rden, dy = fmaf(sdh, rp[0].ny, rp[0].ey) * rden;
+                if (!have) {
+                    const float rm = fast_rcp(cam[0].m);
+                    dx = cam[0].p03 * rm - (float)xr;
+                    dy = cam[0].p13 * rm - (float)yr;
+                }
+                dx = fmaf(dx, hsx, hox);
+                dy = fmaf(dy, hsy, (float)yr / (float)(H - 1) - 0.5f);
+                const Tap t = make_tap(dx, dy, xr, yr, W, H);
+                const float gx = 1.f - t.tx, gy = 1.f - t.ty;
+                const float w00 = gx * gy, w01 = t.tx * gy, w10 = gx * t.ty, w11 = t.tx * t.ty;
+                float xv[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const unsigned po = plane * (unsigned)c;
+                    xv[c] = (ldb(rsrc[0], t.o00, po) * w00 + ldb(rsrc[0], t.o01, po) * w01 + ldb(rsrc[0], t.o10, po) * w10 +
+                             ldb(rsrc[0], t.o11, po) * w11) - SHIFT;
+                }
+                stream(ST_HINT, xv);
+            }
+            float sd_centre[SPP];
 #pragma unroll
             for (int j = 0; j < SPP; ++j) {
+                sd_centre[j] = sd_prev[j];
                 if (s0 + j >= NS) break;
                 const float d = disp_value_cached(rd[j], dg[j], dr[j], yr);
                 const float sd = fmaf(k.dmul, d, k.min_disp);
+                sd_prev[j] = sd;
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     const float rden = fast_rcp(fmaf(sd, cam[f].m, rp[f].az));
@@ -492,6 +533,13 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                 nz[1] = n01.y * 0.00001f;
                 nz[2] = n23.x * 0.00001f;
                 nz[3] = n23.y * 0.00001f;
+            }
+            float hint_cand = 3.0e38f, hint_d = 0.f, hint_valid = 0.f;
+            if constexpr (HINT) {
+                const unsigned ho = (unsigned)(min(qy, H - 1) * W + min(max(col, 0), W - 1)) * 4u;
+                hint_d = ldb(rhint, ho, 0u);
+                hint_valid = ldb(rhmask, ho, 0u);
+                hint_cand = val[ST_HINT] + 1000.f * (1.f - hint_valid);          // DH/trainer.py:632-634
             }
             unsigned bits = 0u;
 #pragma unroll
@@ -530,15 +578,28 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                         chosen = best < idn;   // torch.min keeps the first (identity) on ties
                         v = chosen ? best : idn;
                     } else {
-                        chosen = best <= idn;  // argmin over [reprojection, identity]: first wins ties
+                        // argmin over [reprojection, identity, hint]: first wins ties; the reprojection mask is
+                        // (idx != 1), so it also holds where the hint wins (DH/trainer.py:578-584)
+                        const bool ident_wins = idn < best && idn <= hint_cand;
+                        chosen = !ident_wins;
                         v = chosen ? best : 0.f;
                     }
+                }
+                bool hint_wins = false;
+                float hl = 0.f;
+                if constexpr (HINT) {
+                    hint_wins = chosen && hint_cand < best;        // idx == 2
+                    // proxy supervision log(|hint - depth_s| + 1) * valid where the hint wins (DH/trainer.py:541-555)
+                    const float pred = fast_rcp(sd_centre[j]);
+                    hl = hint_wins ? __logf(fabsf(hint_d - pred) + 1.f) * hint_valid : 0.f;
                 }
                 if (out_lane) {
                     if (k.to_opt[s]) k.to_opt[s][pix] = v;
                     acc1[j] += v;
                     acc2[j] += chosen ? 1.f : 0.f;
-                    bits |= (chosen ? (unsigned)(1 + bestf) : 0u) << (2 * s);
+                    acc3[j] += hl;
+                    acc4[j] += hint_wins ? 1.f : 0.f;
+                    bits |= (hint_wins ? 3u : (chosen ? (unsigned)(1 + bestf) : 0u)) << (2 * s);
                 }
             }
             if (out_lane) {
@@ -555,10 +616,9 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
         for (int j = 0; j < SPP; ++j) {
             if (s0 + j >= NS) break;
             const float t1 = wave_sum(acc1[j]), t2 = wave_sum(acc2[j]);
-            if (lane == 0) {
-                k.partials[((size_t)(s0 + j) * k.ntiles + tile) * 2 + 0] = t1;
-                k.partials[((size_t)(s0 + j) * k.ntiles + tile) * 2 + 1] = t2;
-            }
+            const float t3 = HINT ? wave_sum(acc3[j]) : 0.f, t4 = HINT ? wave_sum(acc4[j]) : 0.f;
+            if (lane == 0)
+                reinterpret_cast<float4*>(k.partials)[(size_t)(s0 + j) * k.ntiles + tile] = make_float4(t1, t2, t3, t4);
         }
     }
 }
@@ -569,6 +629,7 @@ struct BRow {   // record of one processed row: its row sums, the coefficient ro
     float hy[3], hyy[3], hx[3], hxx[3], hxy[3];
     float ch[3][3];          // [channel][a0, ax, ay] horizontal sums (with the reflection fold)
     float xv[3], yv[3], J[3];
+    float sdv;               // scaled disparity of this row (depth = 1/sdv, for the depth-hint proxy term)
     unsigned sel;            // selection field of this row for the wave's scale
     // operands of THIS row, fetched while the previous row was processed
     DispPre pd;
@@ -613,6 +674,15 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
     const int SX = k.sx_slots[s], SY = k.sy_slots[s];
     float* stage = SAME ? nullptr : k.stage[s] + (size_t)tile * SX * SY;
     const unsigned sel_shift = 2u * (unsigned)s;
+    // depth hints: where the hint won (selection code 3) the reprojection term of frame 0 applies too, plus the proxy
+    // term log(|hint - depth| + 1) * valid / (count + 1e-7)                       (DH/trainer.py:541-555,713-725)
+    const bool hints = a.depth_hint != nullptr;
+    const rsrc_t rhint = make_rsrc(hints ? a.depth_hint + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
+    const rsrc_t rhmask = make_rsrc(hints ? a.depth_hint_mask + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
+    float up_h = 0.f;
+    if (hints)
+        up_h = uni((k.gvec[DMH_FIN_LOSS] / (float)a.num_scales + k.gvec[DMH_FIN_LOSS_S + s] + k.gvec[DMH_FIN_HINT_S + s]) /
+                   (k.fin[DMH_FIN_HINTCOUNT_S + s] + 1e-7f));
 
     for (int f = 0; f < NF; ++f) {
         const rsrc_t rs = make_rsrc(a.source[f] + img_off, 3u * plane);
@@ -652,6 +722,8 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
             const float d = disp_finish(cur.pd, dg, yr);
             prefetch(kk + 1, older);        // `older` is the record of the next row; its sums are still read below
             const float sd = fmaf(k.dmul, d, k.min_disp);
+            const float sd_rq = older.sdv;  // of the row two above (read before the prefetch target is reused below)
+            cur.sdv = sd;
             const RowProj rp = row_proj(cam, lp, yr);
             const float rden = fast_rcp(fmaf(sd, cam.m, rp.az));
             const float dx = fmaf(sd, lp.nx, rp.ex) * rden, dy = fmaf(sd, rp.ny, rp.ey) * rden;
@@ -682,7 +754,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
             if constexpr (STAGE >= 1) {
                 const unsigned selb = (cur.psel >> sel_shift) & 3u;     // 0 outside the image
                 cur.sel = selb;
-                const float gate = (selb == fsel) ? gs0 : 0.f;
+                const float gate = (selb == fsel || (hints && selb == 3u)) ? gs0 : 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float Sx = older.hx[c] + newer.hx[c] + cur.hx[c], Sxx = older.hxx[c] + newer.hxx[c] + cur.hxx[c];
@@ -708,7 +780,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
             if constexpr (STAGE >= 2) {
                 const int rq = r - 2;
                 const float myt = (rq == 1) ? 2.f : 1.f, myb = (rq == H - 2) ? 2.f : 1.f;
-                const float l1g = (newer.sel == fsel) ? l1w : 0.f;
+                const float l1g = (newer.sel == fsel || (hints && newer.sel == 3u)) ? l1w : 0.f;
                 float g = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
@@ -719,6 +791,14 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
                     float gw = fmaf(older.xv[c], Sxc, fmaf(older.yv[c], Syc, S0));
                     gw = fmaf(l1g, df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f), gw);
                     g = fmaf(gw, older.J[c], g);
+                }
+                if (hints && newer.sel == 3u && out_lane) {
+                    const unsigned ho = (unsigned)(rq * W + col) * 4u;
+                    const float hd = ldb(rhint, ho, 0u), hv = ldb(rhmask, ho, 0u);
+                    const float pred = fast_rcp(sd_rq), df = pred - hd;
+                    const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+                    // d log(|hint - pred| + 1) / d pred * d pred / d disp,  pred = 1 / sd,  sd = min_disp + dmul * disp
+                    g = fmaf(up_h * hv * sg * fast_rcp(fabsf(df) + 1.f), -(pred * pred) * k.dmul, g);
                 }
                 if (!out_lane) g = 0.f;
                 if constexpr (SAME) {
@@ -871,6 +951,10 @@ int check_photo(const dmh_photo_args* a) {
         if (a->noise_mode == DMH_NOISE_TENSOR) DMH_REQUIRE(a->noise[s] != nullptr, "null noise tensor");
     }
     DMH_REQUIRE(a->noise_mode >= DMH_NOISE_NONE && a->noise_mode <= DMH_NOISE_PHILOX, "bad noise_mode");
+    DMH_REQUIRE((a->depth_hint == nullptr) == (a->depth_hint_mask == nullptr), "depth_hint and depth_hint_mask go together");
+    if (a->depth_hint)
+        DMH_REQUIRE(a->variant == DMH_VARIANT_DH && a->automask && a->num_frames == 1,
+                    "depth hints need the DH variant, auto-masking and exactly one (stereo) source frame");
     return DMH_OK;
 }
 
@@ -902,7 +986,7 @@ extern "C" {
 int64_t dmh_photo_partials_size(int B, int H, int W, int num_scales) {
     const int R = pick_rows(B, H, W, FW_OUT);
     const int64_t tiles = (int64_t)((W + FW_OUT - 1) / FW_OUT) * ((H + R - 1) / R) * B;
-    return tiles * 2 * num_scales;
+    return tiles * 4 * num_scales;
 }
 
 int64_t dmh_photo_stage_size(const dmh_photo_args* a) {
@@ -933,9 +1017,12 @@ int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_op
     switch (a->num_frames) {
         // one source frame: two passes of two scales (3 streams, ~160 VGPRs, 3 waves/SIMD) beat one pass of four (5 streams,
         // 229 VGPRs, 2 waves/SIMD) by 10 % although the identity and target sums are formed twice (profiles/README.md)
-        case 1: hipLaunchKernelGGL((photo_fwd_kernel<1, 2>), grid, block, 0, (hipStream_t)stream, k); break;
-        case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, 2>), grid, block, 0, (hipStream_t)stream, k); break;
-        default: hipLaunchKernelGGL((photo_fwd_kernel<3, 1>), grid, block, 0, (hipStream_t)stream, k); break;
+        case 1:
+            if (a->depth_hint) hipLaunchKernelGGL((photo_fwd_kernel<1, 2, true>), grid, block, 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((photo_fwd_kernel<1, 2, false>), grid, block, 0, (hipStream_t)stream, k);
+            break;
+        case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, 2, false>), grid, block, 0, (hipStream_t)stream, k); break;
+        default: hipLaunchKernelGGL((photo_fwd_kernel<3, 1, false>), grid, block, 0, (hipStream_t)stream, k); break;
     }
     return check_launch("dmh_photo_loss_fwd");
 }

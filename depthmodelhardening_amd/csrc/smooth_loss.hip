@@ -124,7 +124,7 @@ __global__ __launch_bounds__(NT) void smooth_bwd_kernel(const SArgs k) {
 
 // ---------------------------------------------------------------------------------------------- finalise
 struct FArgs {
-    const float* photo;   // [NS][nblk][2]
+    const float* photo;   // [NS][nblk][4] = selected-loss sum, selected count, depth-hint loss sum, depth-hint count
     const float* smooth;  // [blocks][3]
     dmh_smooth_args sm;
     Layout l;
@@ -154,26 +154,33 @@ __global__ __launch_bounds__(NTF) void finalize_kernel(const FArgs k) {
     if (tid < DMH_MAX_SCALES) s_sm[tid] = 0.0;
     // photometric partials: one strided pass over [NS][nblk] float2, all scales' loads independent and in flight
     double a1[DMH_MAX_SCALES] = {0, 0, 0, 0}, a2[DMH_MAX_SCALES] = {0, 0, 0, 0};
-    const float2* ph = reinterpret_cast<const float2*>(k.photo);
+    double a3[DMH_MAX_SCALES] = {0, 0, 0, 0}, a4[DMH_MAX_SCALES] = {0, 0, 0, 0};
+    const float4* ph = reinterpret_cast<const float4*>(k.photo);
     for (int i = tid; i < k.nblk; i += NTF) {
 #pragma unroll
         for (int s = 0; s < DMH_MAX_SCALES; ++s) {
             if (s < NS) {
-                const float2 v = ph[(size_t)s * k.nblk + i];
+                const float4 v = ph[(size_t)s * k.nblk + i];
                 a1[s] += (double)v.x;
                 a2[s] += (double)v.y;
+                a3[s] += (double)v.z;
+                a4[s] += (double)v.w;
             }
         }
     }
-    double reproj[DMH_MAX_SCALES], count[DMH_MAX_SCALES];
+    double reproj[DMH_MAX_SCALES], count[DMH_MAX_SCALES], hint[DMH_MAX_SCALES], hcount[DMH_MAX_SCALES];
 #pragma unroll
     for (int s = 0; s < DMH_MAX_SCALES; ++s) {
-        reproj[s] = count[s] = 0.0;
+        reproj[s] = count[s] = hint[s] = hcount[s] = 0.0;
         if (s < NS) {
             const double S1 = block_sum_d(a1[s], s_red);
             const double S2 = block_sum_d(a2[s], s_red);
+            const double S3 = block_sum_d(a3[s], s_red);
+            const double S4 = block_sum_d(a4[s], s_red);
             count[s] = S2;
             reproj[s] = (k.variant == DMH_VARIANT_MD2) ? S1 / ((double)B * k.H * k.W) : S1 / (S2 + 1e-7);
+            hcount[s] = S4;
+            hint[s] = S3 / (S4 + 1e-7);       // depth_hint_loss.sum() / (mask.sum() + 1e-7), DH/trainer.py:721; 0 without hints
         }
     }
     // smoothness: one (scale, image) pair per thread, chunks summed in a fixed order
@@ -211,12 +218,14 @@ __global__ __launch_bounds__(NTF) void finalize_kernel(const FArgs k) {
         double total = 0.0;
         for (int i = 0; i < DMH_FIN_SIZE; ++i) k.fin[i] = 0.f;
         for (int s = 0; s < NS; ++s) {
-            const double ls = reproj[s] + (double)k.smooth_wt * s_sm[s] / (double)(1 << s);
+            const double ls = reproj[s] + hint[s] + (double)k.smooth_wt * s_sm[s] / (double)(1 << s);
             total += ls;
             k.fin[DMH_FIN_LOSS_S + s] = (float)ls;
             k.fin[DMH_FIN_REPROJ_S + s] = (float)reproj[s];
             k.fin[DMH_FIN_COUNT_S + s] = (float)count[s];
             k.fin[DMH_FIN_SMOOTH_S + s] = (float)s_sm[s];
+            k.fin[DMH_FIN_HINT_S + s] = (float)hint[s];
+            k.fin[DMH_FIN_HINTCOUNT_S + s] = (float)hcount[s];
         }
         k.fin[DMH_FIN_LOSS] = (float)(total / NS);
     }
@@ -289,7 +298,7 @@ int dmh_loss_finalize(const float* photo_partials, const float* smooth_partials,
     k.B = B;
     k.H = H;
     k.W = W;
-    k.nblk = (int)(dmh_photo_partials_size(B, H, W, 1) / 2);
+    k.nblk = (int)(dmh_photo_partials_size(B, H, W, 1) / 4);
     k.variant = variant;
     k.smooth_wt = smooth_wt;
     k.fin = fin;

@@ -69,9 +69,14 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
-def _photo_args(cfg, target, sources, Ts, K, inv_K, disps, noises):
+def _photo_args(cfg, target, sources, Ts, K, inv_K, disps, noises, hint=None):
     a = N.PhotoArgs()
     B, _, H, W = target.shape
+    if hint is not None:
+        for t_ in hint:
+            if tuple(t_.shape) != (B, 1, H, W):
+                raise RuntimeError("photometric loss: depth_hint / depth_hint_mask must be [B,1,H,W]")
+        a.depth_hint, a.depth_hint_mask = N.ptr(hint[0]), N.ptr(hint[1])
     a.target = N.ptr(target)
     for f, (s_, t_) in enumerate(zip(sources, Ts)):
         if tuple(s_.shape) != (B, 3, H, W) or tuple(t_.shape) != (B, 4, 4):
@@ -129,13 +134,14 @@ class _PhotoSmoothLoss(torch.autograd.Function):
             noises = rest[pos:pos + NS]
             pos += NS
         disps = rest[pos:pos + NS]
+        hint = tuple(rest[pos + NS:pos + NS + 2]) if cfg["hints"] else None
         if any(t.requires_grad for t in Ts):
             raise NotImplementedError("gradient w.r.t. camera poses (cam_T_cam) is not implemented in the fused "
                                       "photometric kernel yet; stereo training (frame_ids [0,'s']) does not need it")
         lib = N.lib()
         B, _, H, W = target.shape
         dev = target.device
-        a = _photo_args(cfg, target, sources, Ts, K, inv_K, disps, noises)
+        a = _photo_args(cfg, target, sources, Ts, K, inv_K, disps, noises, hint)
         sm = _smooth_args(disps, colors)
         sel = torch.empty((B, H, W), device=dev, dtype=torch.uint8)    # 2 bits per scale: 0 identity, 1+f frame f
         to_opt = [torch.empty((B, H, W), device=dev, dtype=torch.float32) if cfg["want_to_opt"] else None
@@ -151,7 +157,7 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         N.check(lib.dmh_loss_finalize(N.ptr(pp), N.ptr(sp), B, H, W, C.byref(sm), a.variant, cfg["smooth_wt"],
                                       N.ptr(fin), N.ptr(sstats), st))
         ctx.cfg = cfg
-        ctx.save_for_backward(target, K, inv_K, fin, sstats, sel, *sources, *Ts, *colors, *disps)
+        ctx.save_for_backward(target, K, inv_K, fin, sstats, sel, *sources, *Ts, *colors, *disps, *(hint or ()))
         outs = [fin, sel] + [t for t in to_opt if t is not None]
         ctx.mark_non_differentiable(*outs[1:])
         return tuple(outs)
@@ -165,11 +171,12 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         sources, Ts = sv[6:6 + F], sv[6 + F:6 + 2 * F]
         colors = sv[6 + 2 * F:6 + 2 * F + NS]
         disps = sv[6 + 2 * F + NS:6 + 2 * F + 2 * NS]
+        hint = tuple(sv[6 + 2 * F + 2 * NS:6 + 2 * F + 2 * NS + 2]) if cfg["hints"] else None
         lib = N.lib()
         dev = target.device
         gvec = _c(g_fin.to(torch.float32))
         cfg_b = dict(cfg, noise_mode=N.NOISE_NONE)
-        a = _photo_args(cfg_b, target, sources, Ts, K, inv_K, disps, ())
+        a = _photo_args(cfg_b, target, sources, Ts, K, inv_K, disps, (), hint)
         sm = _smooth_args(disps, colors)
         st = N.stream()
         g_disp = [torch.empty_like(d) for d in disps]
@@ -179,7 +186,7 @@ class _PhotoSmoothLoss(torch.autograd.Function):
                                                                   N.ptr(stage), gp, st)))
         N.check(lib.dmh_smooth_loss_bwd(C.byref(sm), N.ptr(gvec), N.ptr(sstats), cfg["smooth_wt"], gp, 1, st))
         n_mid = 2 * F + NS + (NS if cfg["noise_mode"] == N.NOISE_TENSOR else 0)
-        return (None, None, None, None) + (None,) * n_mid + tuple(g_disp)
+        return (None, None, None, None) + (None,) * n_mid + tuple(g_disp) + ((None, None) if cfg["hints"] else ())
 
 
 class SelectionMaps(object):
@@ -209,12 +216,15 @@ class SelectionMaps(object):
 
 def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_depth=0.1, max_depth=100.0,
                             variant="md2", automask=True, no_ssim=False, smooth_wt=1e-3, noise="philox",
-                            want_to_opt=False):
+                            want_to_opt=False, depth_hint=None, depth_hint_mask=None):
     """Fused photometric-reprojection + SSIM + auto-mask + smoothness loss over all scales.
 
     target [B,3,H,W]; sources / Ts: one per non-target frame; disps[s] [B,1,H/2^s,W/2^s];
     colors[s] = inputs[("color",0,s)].  ``noise``: "philox" (in-kernel randn*1e-5, the reference's
     tie-break of MD2/trainer.py:642-645), None, or a list of NS already-scaled tensors.
+    ``depth_hint`` / ``depth_hint_mask`` [B,1,H,W]: DepthHints' --use_depth_hints (DH/trainer.py:510-525,629-636,
+    700-725; variant "dh", one source frame): fin[FIN_HINT_S+s] is depth_hint_loss/s (already part of loss/s) and
+    sel[s] == 3 marks the pixels where the hint won the argmin (outputs["depth_hint_pixels/s"]).
     Returns LossOut(fin, sel, to_opt): fin[FIN_*] is differentiable w.r.t. the disparities; sel is a SelectionMaps
     (sel[s] unpacks scale s on demand).
     """
@@ -225,8 +235,11 @@ def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_de
     if variant not in ("md2", "dh"):
         raise RuntimeError("variant must be 'md2' or 'dh'")
     B, _, H, W = target.shape
+    if (depth_hint is None) != (depth_hint_mask is None):
+        raise RuntimeError("depth_hint and depth_hint_mask go together")
     cfg = dict(F=F, NS=NS, min_depth=float(min_depth), max_depth=float(max_depth), variant=variant,
-               automask=bool(automask), no_ssim=bool(no_ssim), smooth_wt=float(smooth_wt), want_to_opt=want_to_opt)
+               automask=bool(automask), no_ssim=bool(no_ssim), smooth_wt=float(smooth_wt), want_to_opt=want_to_opt,
+               hints=depth_hint is not None)
     noises = ()
     if noise is None or not automask:
         cfg["noise_mode"] = N.NOISE_NONE
@@ -238,6 +251,8 @@ def photometric_smooth_loss(target, sources, Ts, K, inv_K, disps, colors, min_de
         noises = tuple(_c(z) for z in noise)
     args = (_c(target), _c(K), _c(inv_K)) + tuple(_c(s) for s in sources) + tuple(_c(t) for t in Ts) + \
         tuple(_c(c) for c in colors) + noises + tuple(_c(d) for d in disps)
+    if depth_hint is not None:
+        args += (_c(depth_hint), _c(depth_hint_mask))
     outs = _PhotoSmoothLoss.apply(cfg, *args)
     fin, sel = outs[0], SelectionMaps(outs[1], NS)
     to_opt = list(outs[2:]) if want_to_opt else [None] * NS

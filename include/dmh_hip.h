@@ -46,7 +46,9 @@ extern "C" {
 #define DMH_FIN_REPROJ_S 5   /* [4] mean(to_optimise) | DH reproj_loss/{s}                   */
 #define DMH_FIN_COUNT_S 9    /* [4] number of pixels where reprojection was selected         */
 #define DMH_FIN_SMOOTH_S 13  /* [4] get_smooth_loss(norm_disp, color)     MD2/trainer.py:664 */
-#define DMH_FIN_SIZE 20
+#define DMH_FIN_HINT_S 20    /* [4] depth_hint_loss/{s} (0 without depth hints)   DH/trainer.py:713-725 */
+#define DMH_FIN_HINTCOUNT_S 24 /* [4] number of pixels where the depth hint won the argmin */
+#define DMH_FIN_SIZE 28
 
 const char* dmh_version(void);
 const char* dmh_last_error(void);
@@ -78,16 +80,21 @@ typedef struct dmh_photo_args {
     int noise_mode;                      /* DMH_NOISE_*                                            */
     const float* noise[DMH_MAX_SCALES];  /* TENSOR mode: [B,NF,H,W], NF = num_frames (MD2) or 1 (DH) */
     uint64_t seed, offset;               /* PHILOX mode                                            */
+    /* DepthHints --use_depth_hints (DH/trainer.py:510-525,629-636,700-725); both NULL = off.  Needs variant DH,
+     * automask and ONE source frame (the reference builds the hint view for the stereo frame only).              */
+    const float* depth_hint;             /* [B,1,H,W] inputs["depth_hint"], 0 where there is no hint */
+    const float* depth_hint_mask;        /* [B,1,H,W] inputs["depth_hint_mask"]                      */
 } dmh_photo_args;
 
 /* number of floats the photometric partial-sum workspace needs */
-int64_t dmh_photo_partials_size(int B, int H, int W, int num_scales);
+int64_t dmh_photo_partials_size(int B, int H, int W, int num_scales);   /* 4 floats per (scale, strip) */
 /* number of floats of the backward staging workspace (per-strip partial low-resolution gradients) */
 int64_t dmh_photo_stage_size(const dmh_photo_args* a);
 
 /* Forward.  sel      : out [B,H,W] uint8, the selection of every scale packed 2 bits per scale: bits [2s, 2s+1] =
  *                      0 identity chosen, 1+f reprojection of source frame f chosen (== outputs["identity_selection/s"]
- *                      for one source frame, MD2/trainer.py:656-658).  At most 3 source frames.
+ *                      for one source frame, MD2/trainer.py:656-658); with depth hints 3 = the hint won (reprojection
+ *                      of frame 0 applies as well, DH/trainer.py:583-584).  At most 3 source frames.
  *           to_opt[s]: out [B,H,W] per-pixel selected loss, or NULL
  *           partials : out, dmh_photo_partials_size floats
  * disp[s] must be [B,1,H/f,W/f] with f in {1,2,4,8,16}.                                                     */

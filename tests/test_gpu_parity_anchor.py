@@ -327,3 +327,55 @@ def test_config3_shape_l0_supervised_full_size_step(tmp_path):
         assert torch.equal(oa[("disp", s)].grad, ob[("disp", s)].grad)
         sel = oa["identity_selection/%d" % s]
         assert sel.shape == (32, 320, 1024) and float(sel.min()) >= 0 and float(sel.max()) <= 1
+
+
+@pytest.mark.parametrize("name", ["small", "cfg1"])
+def test_depth_hints_meet_the_reference_golden(golden, name):
+    """DepthHints --use_depth_hints through the fused kernel against the reference's own run
+    (DH/trainer.py:510-525,629-636,700-725): hint warp (align_corners=False, holes back-project to the origin), three-way
+    argmin, proxy log-L1 term; gradients anchored on the fp64 oracle as everywhere else."""
+    N, ops, loss_ref, synth = _mods()
+    g = golden("loss_dh_hints_" + name)
+    B, H, W, seed = [int(v) for v in g["shape"]]
+
+    def case(dtype):
+        inputs, disps = synth.make_loss_case(B, H, W, seed, dtype=dtype)
+        hd, hm = synth.make_depth_hint(B, H, W, seed + 50)
+        inputs["depth_hint"], inputs["depth_hint_mask"] = hd.to(dtype), hm.to(dtype)
+        return inputs, disps
+    in64, d64 = case(torch.float64)
+    o64 = {("disp", s): d64[s].clone().requires_grad_(True) for s in range(4)}
+    loss_ref.generate_images_pred(in64, o64)
+    loss_ref.compute_losses(in64, o64, noise=None, variant="dh", use_depth_hints=True)[0]["loss"].backward()
+    inputs, disps = case(torch.float32)
+    gen = torch.Generator().manual_seed(seed + 100)
+    noise = [torch.randn(B, 1, H, W, generator=gen) * 0.00001 for _ in range(4)]
+    for tag, nz in (("nonoise", None), ("noise", noise)):
+        out, dd = _hip(ops, inputs, disps, "dh", nz, depth_hint=inputs["depth_hint"].cuda(),
+                       depth_hint_mask=inputs["depth_hint_mask"].cuda())
+        out.fin[N.FIN_LOSS].backward()
+        f = out.fin.detach().cpu()
+        tol = max(2e-5, 3.0 / (B * H * W))       # masked-sum / count: one flipped near-tie moves it by ~1/count
+        assert abs(f[N.FIN_LOSS].item() - float(g[tag + "_loss"])) <= tol * abs(float(g[tag + "_loss"]))
+        for s in range(4):
+            n_hint = max(1.0, f[N.FIN_HINTCOUNT_S + s].item())
+            for key, slot in (("loss", N.FIN_LOSS_S), ("reproj_loss", N.FIN_REPROJ_S), ("depth_hint_loss", N.FIN_HINT_S)):
+                ref = float(g["%s_%s_%d" % (tag, key, s)])
+                # the hint term is a mean over the ~18 % of pixels where the hint wins: a flipped near-tie moves it by
+                # up to log(|hint - depth| + 1) / count
+                t_k = tol if key == "reproj_loss" else max(tol, 5.0 / n_hint)
+                assert abs(f[slot + s].item() - ref) <= t_k * abs(ref), (tag, key, s, f[slot + s].item(), ref)
+            sel = out.sel[s].cpu().numpy()
+            ident_ref = np.unpackbits(g["%s_identity_selection_%d" % (tag, s)])[:B * H * W].reshape(B, H, W)
+            hint_ref = np.unpackbits(g["%s_depth_hint_pixels_%d" % (tag, s)])[:B * H * W].reshape(B, H, W)
+            assert int(((sel == 0) != (ident_ref > 0)).sum()) <= max(2, 5e-4 * B * H * W)
+            assert int(((sel == 3) != (hint_ref > 0)).sum()) <= max(2, 5e-4 * B * H * W)
+            assert abs(f[N.FIN_HINTCOUNT_S + s].item() - float((sel == 3).sum())) <= 1.0
+            if tag == "nonoise":
+                g64 = o64[("disp", s)].grad
+                gref = np_t(g["nonoise_grad_disp_%d" % s]).double()
+                gh = dd[s].grad.double().cpu()
+                if name != "small" and s == 0:
+                    g64, gh = g64[:, :, ::3, ::3], gh[:, :, ::3, ::3]
+                e_h, e_r = rel_l2(gh, g64), rel_l2(gref, g64)
+                assert e_h <= 1.5 * e_r + 3.0 * g64.abs().max().item() / g64.norm().item(), (s, e_h, e_r)

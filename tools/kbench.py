@@ -58,7 +58,7 @@ def main():
     res = {}
 
     cfg = dict(F=1, NS=4, min_depth=0.1, max_depth=100.0, variant="md2", automask=True, no_ssim=bool(a.no_ssim),
-               smooth_wt=1e-3, want_to_opt=False, noise_mode=a.noise, seed=1, offset=0)
+               smooth_wt=1e-3, want_to_opt=False, hints=False, noise_mode=a.noise, seed=1, offset=0)
     pa = ops._photo_args(cfg, left, [right], [T], K, inv_K, [d.detach() for d in disps], ())
     sm = ops._smooth_args([d.detach() for d in disps], colors)
     sel = torch.empty(B, H, W, device=dev, dtype=torch.uint8)

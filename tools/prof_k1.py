@@ -18,7 +18,7 @@ K, inv_K = K.repeat(B, 1, 1).contiguous(), inv_K.repeat(B, 1, 1).contiguous()
 T = torch.eye(4, device=dev).repeat(B, 1, 1); T[:, 0, 3] = -0.1
 disps = [(0.02 + 0.1 * F.avg_pool2d(torch.rand(B, 1, (H >> s) + 8, (W >> s) + 8, device=dev, generator=g), 9, 1)).contiguous() for s in range(4)]
 lib = N.lib()
-cfg = dict(F=1, NS=4, min_depth=0.1, max_depth=100.0, variant="md2", automask=True, no_ssim=False, smooth_wt=1e-3, want_to_opt=False, noise_mode=noise_mode, seed=1, offset=0)
+cfg = dict(F=1, NS=4, min_depth=0.1, max_depth=100.0, variant="md2", automask=True, no_ssim=False, smooth_wt=1e-3, want_to_opt=False, hints=False, noise_mode=noise_mode, seed=1, offset=0)
 pa = ops._photo_args(cfg, left, [right], [T], K, inv_K, disps, ())
 sm = ops._smooth_args(disps, colors)
 sel = torch.empty(B, H, W, device=dev, dtype=torch.uint8)
