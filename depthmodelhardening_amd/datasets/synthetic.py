@@ -64,6 +64,7 @@ class SyntheticKITTIDataset(object):
         self.both_sides = True
         self.flip_augmentation = True
         self.reference_stale_patch = False
+        self.make_depth_hints = False
         self._epoch_patch = None
         self.K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
         stereo_T = np.eye(4, dtype=np.float32)
@@ -188,6 +189,15 @@ class SyntheticKITTIDataset(object):
         for s in range(self.num_scales):
             inputs[("color", 0, s)] = left if s == 0 else F.avg_pool2d(left, 2 ** s)
             inputs[("color", "s", s)] = right if s == 0 else F.avg_pool2d(right, 2 ** s)
+        if self.make_depth_hints:
+            # stand-in for DepthHints' precomputed SGM estimates (DH/datasets/mono_dataset.py:368-388): a smooth depth field
+            # with holes; inputs["depth_hint_mask"] = (hint > 0)
+            d = F.avg_pool2d(torch.rand(batch_size, 1, H + 8, W + 8, device=dev, generator=self.gen), 9, 1)
+            d = (d - d.amin((2, 3), keepdim=True)) / (d.amax((2, 3), keepdim=True) - d.amin((2, 3), keepdim=True) + 1e-12)
+            depth = 1.0 / (0.01 + 9.99 * (0.02 + 0.28 * d))
+            holes = F.avg_pool2d(torch.rand(batch_size, 1, H + 6, W + 6, device=dev, generator=self.gen), 7, 1) < 0.457
+            inputs["depth_hint"] = torch.where(holes, torch.zeros_like(depth), depth).contiguous()
+            inputs["depth_hint_mask"] = (inputs["depth_hint"] > 0).float()
         inputs.update(self._camera(batch_size))
         # stereo_T[0,3] = side_sign * baseline_sign * 0.1 (mono_dataset.py:367-373)
         sign = [(-1.0 if sd == "l" else 1.0) * (-1.0 if fl else 1.0) for sd, fl in zip(geo["side"], geo["flip"])]

@@ -91,6 +91,9 @@ class MonodepthOptions:
                        help="strict reference order: wait for the gradient all-reduce + Adam before the next attack")
         p.add_argument("--materialize_warps", action="store_true",
                        help="generate_images_pred also writes depth/sample/color tensors (the fused loss never reads them)")
+        p.add_argument("--use_depth_hints", action="store_true",
+                       help="DepthHints (DH/options.py:99-101): depth-hint reprojection candidate + proxy supervision; needs "
+                            "--loss_variant dh.  The synthetic dataset makes up hints (smooth depth with holes)")
         p.add_argument("--reference_stale_patch", action="store_true",
                        help="paste the adversarial patch as of the epoch start, as the reference's forked DataLoader workers "
                             "do (SURVEY.md section 3.1); default: the freshly attacked patch (its num_workers=0 behaviour)")

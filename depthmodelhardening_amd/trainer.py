@@ -80,6 +80,9 @@ class Trainer:
         for flag in ("v1_multiscale", "avg_reprojection", "predictive_mask", "gt_depth"):
             if getattr(self.opt, flag):
                 raise NotImplementedError("--%s is not supported by the fused photometric kernel" % flag)
+        if self.opt.use_depth_hints and (self.opt.loss_variant != "dh" or self.opt.disable_automasking):
+            raise RuntimeError("--use_depth_hints is the DepthHints trainer's option: use --loss_variant dh with "
+                               "auto-masking (DH/trainer.py:71-75,557-590)")
 
         if self.opt.fine_tune:
             m = import_depth_model((1024, 320), pre_model_path=self.opt.load_weights_folder)
@@ -123,6 +126,7 @@ class Trainer:
                                              self.opt.synthetic_len, self.device, seed=self.opt.seed + rank)
         self.dataset.both_sides = self.dataset.flip_augmentation = not self.opt.no_flip_sides
         self.dataset.reference_stale_patch = bool(self.opt.reference_stale_patch)
+        self.dataset.make_depth_hints = bool(self.opt.use_depth_hints)
         self.num_total_steps = len(self.dataset) // self.opt.batch_size * self.opt.num_epochs
 
         if self.opt.adv_train:
@@ -322,11 +326,23 @@ class Trainer:
             [outputs[("disp", s)] for s in self.opt.scales], [inputs[("color", 0, s)] for s in self.opt.scales],
             min_depth=self.opt.min_depth, max_depth=self.opt.max_depth, variant=self.opt.loss_variant,
             automask=not self.opt.disable_automasking, no_ssim=self.opt.no_ssim,
-            smooth_wt=self.opt.disparity_smoothness, noise="philox")
+            smooth_wt=self.opt.disparity_smoothness, noise="philox",
+            depth_hint=inputs["depth_hint"] if self.opt.use_depth_hints else None,
+            depth_hint_mask=inputs["depth_hint_mask"] if self.opt.use_depth_hints else None)
         for i, scale in enumerate(self.opt.scales):
             losses["loss/{}".format(scale)] = out.fin[N.FIN_LOSS_S + i]
             if self.opt.loss_variant == "dh":
                 losses["reproj_loss/{}".format(scale)] = out.fin[N.FIN_REPROJ_S + i]
+            if self.opt.use_depth_hints:
+                losses["depth_hint_loss/{}".format(scale)] = out.fin[N.FIN_HINT_S + i]      # DH/trainer.py:725
+                hkey = "depth_hint_pixels/{}".format(scale)
+
+                def hint_pixels(i=i):
+                    return (out.sel[i] == 3).float().unsqueeze(1)
+                if isinstance(outputs, LazyOutputs):
+                    outputs.lazy(hkey, hint_pixels)
+                else:
+                    outputs[hkey] = hint_pixels()
             if not self.opt.disable_automasking:
                 def selection(i=i, multi=len(frames) > 1 or self.opt.loss_variant == "dh",
                               dh=self.opt.loss_variant == "dh"):

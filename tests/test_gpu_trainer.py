@@ -627,3 +627,27 @@ def test_physical_adv_training_harness(attack, bs):
     assert not any(p.requires_grad for p in job.model_ori.parameters())
     acc, perf = pat.eval_atk_perf(job.model_ori, job.model_rob, job.data, job.depth_atk, attack, min(bs, 3), eval_count=1)
     assert acc >= 0 and perf >= 0
+
+
+def test_trainer_depth_hints_step(tmp_path):
+    """--loss_variant dh --use_depth_hints through the Trainer: the reference's extra dict entries (DH/trainer.py:715-725)
+    appear, the hint term is part of loss/s, a training step runs, and the wrong variant fails loudly."""
+    from depthmodelhardening_amd.options import MonodepthOptions
+    from depthmodelhardening_amd.trainer import Trainer
+    tr = _trainer(tmp_path, ["--loss_variant", "dh", "--use_depth_hints"])
+    tr.set_train()
+    inputs = tr.dataset.next_batch(2)
+    assert inputs["depth_hint"].shape == (2, 1, 64, 192) and 0.5 < float(inputs["depth_hint_mask"].mean()) < 1.0
+    outputs, losses = tr.process_batch(inputs)
+    for s in range(4):
+        hl, rl = float(losses["depth_hint_loss/%d" % s]), float(losses["reproj_loss/%d" % s])
+        assert hl > 0 and rl > 0 and float(losses["loss/%d" % s]) > hl + rl - 1e-6
+        hp = outputs["depth_hint_pixels/%d" % s]
+        assert hp.shape == (2, 1, 64, 192) and 0.0 < float(hp.mean()) < 0.9
+        assert float((hp[:, 0] * outputs["identity_selection/%d" % s]).max()) == 0.0     # a hint pixel is never auto-masked
+    losses["loss"].backward()
+    assert torch.isfinite(tr.models["depth"].decoder[0].conv.conv.weight.grad).all()
+    with pytest.raises(RuntimeError, match="DepthHints"):
+        Trainer(MonodepthOptions().parse(["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "64",
+                                          "--width", "192", "--use_depth_hints", "--log_dir", str(tmp_path)]),
+                device=torch.device("cuda"))
