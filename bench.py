@@ -337,12 +337,16 @@ def run_rank(a):
             for k, (cnt, ms, nb, fl) in sorted(kbytes.items()):
                 if not k.startswith("photo_") and ms > 0:
                     ent = {"launches_per_step": round(cnt / a.steps, 1), "ms_per_step": round(ms / a.steps, 3)}
-                    if fl > 0:      # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe, not by HBM
+                    if fl > 0 and k.startswith("wino_"):    # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe
                         direct = fl / (ms * 1e-3) / 1e12
                         ent.update({"bound": "mfma", "TFLOP/s_direct_equivalent": round(direct, 1),
                                     "achieved": round(direct / 2.25, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(direct / 2.25 / MFMA_F32_PEAK_TFLOPS, 4),
                                     "note": "achieved = MFMA flops actually issued (Winograd F(2x2,3x3): direct / 2.25)"})
+                    elif fl > 0:                            # direct MFMA convolution (K14 stem): flops as counted
+                        tf = fl / (ms * 1e-3) / 1e12
+                        ent.update({"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
                     else:
                         ent.update({"GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
                                     "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})

@@ -184,13 +184,23 @@ class ResnetEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
+    def _stem(self, input_image):
+        """conv1((input_image - 0.45) / 0.225): one K14 launch for the standard first layer on the GPU, the reference's
+        two steps otherwise."""
+        c = self.encoder.conv1
+        if (ops.WINO_ENABLED and input_image.is_cuda and input_image.dtype == torch.float32 and input_image.dim() == 4
+                and input_image.shape[1] == 3 and tuple(c.weight.shape) == (64, 3, 7, 7) and c.stride == (2, 2)
+                and c.padding == (3, 3) and c.dilation == (1, 1) and c.groups == 1 and c.bias is None
+                and input_image.shape[2] % 2 == 0 and input_image.shape[3] % 2 == 0):
+            return ops.stem_conv_norm(input_image, c.weight, 0.45, 0.225)
+        return self._conv1((input_image - 0.45) / 0.225)
+
     def forward(self, input_image):
         e = self.encoder
-        x = (input_image - 0.45) / 0.225
-        if e.fused_eval_ok(x):
-            self.features = self._forward_fused_eval(x)
+        if e.fused_eval_ok(input_image):
+            self.features = self._forward_fused_eval(input_image)
             return self.features
-        z = self._conv1(x)
+        z = self._stem(input_image)
         if _train_fused(e.bn1, z) and z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
             f0, p = ops.stem_bn_relu_pool_train(e.bn1, z)
         else:
@@ -210,10 +220,10 @@ class ResnetEncoder(nn.Module):
             return ops.stem_conv(x, c.weight)
         return c(x)
 
-    def _forward_fused_eval(self, x):
+    def _forward_fused_eval(self, input_image):
         e = self.encoder
         aff = e.eval_affine()
-        z = self._conv1(x)
+        z = self._stem(input_image)
         if z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
             f0, y = ops.stem_bn_relu_pool(z, *aff[e.bn1])
         else:

@@ -1031,6 +1031,57 @@ def stem_conv(x, weight):
     return _StemConv.apply(_c(x), weight)
 
 
+class _StemConvNorm(torch.autograd.Function):
+    """K14 forward (normalisation + 7x7/2 convolution on the fp32 MFMA); backward: image gradient by K12 (scaled by 1/std),
+    weight gradient by MIOpen on the re-normalised image (train pass only)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, mean, std):
+        lib = N.lib()
+        B, _, H, W = x.shape
+        y = torch.empty((B, 64, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        nb = 4 * (x.numel() + y.numel())
+        N.check(_timed("stem_conv_fwd", lambda: lib.dmh_stem_conv_norm_fwd(N.ptr(x), N.ptr(_c(weight.detach())), B, H, W, mean,
+                                                                          std, N.ptr(y), N.stream()), nb,
+                       2 * 147 * y.numel()))
+        ctx.save_for_backward(x, weight)
+        ctx.norm = (mean, std)
+        ctx.params_const = _wino_frozen > 0
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        mean, std = ctx.norm
+        lib = N.lib()
+        g = _c(g)
+        B, Cin, H, W = x.shape
+        g_x = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_x = torch.empty_like(x)
+            nb = 4 * (g.numel() + g_x.numel())
+            N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(_c(weight.detach())), B, 64, Cin,
+                                                                              H, W, N.ptr(g_x), N.stream()), nb))
+            g_x.mul_(1.0 / std)
+        if ctx.needs_input_grad[1] and not ctx.params_const:
+            xn = (x - mean) / std
+            g_w = torch.ops.aten.convolution_backward(g, xn, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                      [False, True, False])[1]
+        return g_x, g_w, None, None
+
+
+def stem_conv_norm(x, weight, mean=0.45, std=0.225):
+    """conv1((x - mean) / std) for the encoder's first layer -- MD2/networks/resnet_encoder.py:89-90 with torchvision's
+    ResNet.conv1 (3 -> 64 channels, 7x7, stride 2, padding 3, no bias) -- as ONE launch of the K14 MFMA kernel: the
+    normalisation is applied while the input tile is staged, so neither the normalised image nor a layout transpose
+    ever exists in memory."""
+    if not x.is_cuda:
+        raise RuntimeError("libdmh_hip ops need CUDA (ROCm) tensors; got device %s -- there is no CPU path" % x.device)
+    if tuple(weight.shape) != (64, 3, 7, 7) or x.dim() != 4 or x.shape[1] != 3 or x.shape[2] % 2 or x.shape[3] % 2:
+        raise RuntimeError("stem_conv_norm: x must be [B,3,H,W] with even H, W and weight [64,3,7,7]")
+    return _StemConvNorm.apply(_c(x), weight, float(mean), float(std))
+
+
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,
                         clamp_hi=80.0):
     """The eight attack-evaluation metrics of MD2/evaluate_depth.py:57-99 computed from two disparity maps in one

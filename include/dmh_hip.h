@@ -329,6 +329,15 @@ int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int C
 int dmh_conv3x3_head(const float* x, const float* w, const float* bias, int B, int C, int H, int W, int pad, float* y,
                      void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K14 the encoder's first layer with its input normalisation fused (MD2/networks/resnet_encoder.py:89-90:
+ *     x = (input_image - 0.45) / 0.225;  x = conv1(x),  conv1 = nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False)):
+ *     y[B,64,H/2,W/2] = corr7x7_s2(zero_pad3((x[B,3,H,W] - mean) / std), w[64][3][7][7]) on the exact-fp32 MFMA.
+ *     H and W even.  The gradient w.r.t. x is dmh_conv7x7s2_bwd_data(g_y, w) / std.
+ * ---------------------------------------------------------------------------------- */
+int dmh_stem_conv_norm_fwd(const float* x, const float* w, int B, int H, int W, float mean, float std, float* y,
+                           void* stream);
+
 #ifdef __cplusplus
 }
 #endif

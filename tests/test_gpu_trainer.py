@@ -651,3 +651,30 @@ def test_trainer_depth_hints_step(tmp_path):
         Trainer(MonodepthOptions().parse(["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "64",
                                           "--width", "192", "--use_depth_hints", "--log_dir", str(tmp_path)]),
                 device=torch.device("cuda"))
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 192), (3, 46, 130), (12, 320, 1024)])
+def test_stem_conv_norm_vs_aten(shape):
+    """K14: conv1((x - 0.45) / 0.225) of MD2/networks/resnet_encoder.py:89-90 against ATen's two steps; forward, image
+    gradient (K12 / std) and weight gradient; ragged tiles (46x130 -> 23x65 outputs)."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import ops
+    B, H, W = shape
+    g = torch.Generator().manual_seed(B + H)
+    x = torch.rand(B, 3, H, W, generator=g).cuda().requires_grad_(True)
+    w = ((torch.rand(64, 3, 7, 7, generator=g) - 0.5) * 0.2).cuda().requires_grad_(True)
+    y = ops.stem_conv_norm(x, w)
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    yr = F.conv2d((xr - 0.45) / 0.225, wr, None, 2, 3)
+    assert y.shape == yr.shape
+    assert_close_frac(y, yr, rtol=1e-5, atol=2e-6 * yr.abs().max().item(), name="stem conv forward")
+    gy = (torch.rand(yr.shape, generator=torch.Generator().manual_seed(1)) - 0.5).cuda()
+    y.backward(gy)
+    yr.backward(gy)
+    assert_close_frac(x.grad, xr.grad, rtol=1e-4, atol=2e-6 * xr.grad.abs().max().item(), name="stem conv d/dx")
+    assert_close_frac(w.grad, wr.grad, rtol=1e-3, atol=1e-5 * wr.grad.abs().max().item(), name="stem conv d/dw")
+    with ops.frozen_weights():          # inside an attack: no weight gradient is formed
+        x2 = x.detach().clone().requires_grad_(True)
+        w.grad = None
+        ops.stem_conv_norm(x2, w).backward(gy)
+        assert w.grad is None and torch.equal(x2.grad, x.grad)

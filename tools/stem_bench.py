@@ -35,3 +35,15 @@ k12 = timeit(lambda: N.check(lib.dmh_conv7x7s2_bwd_data(N.ptr(gy), N.ptr(w), B, 
 ref = torch.autograd.grad(y, x, gy, retain_graph=True)[0]
 print("conv1 backward-data B=%d: miopen %.1f us, K12 %.1f us, max rel err %.1e" %
       (B, mi, k12, float((gx - ref).abs().max() / ref.abs().max())))
+
+# K14: normalisation + forward convolution in one launch vs ATen's (x - 0.45) / 0.225 followed by MIOpen's convolution
+from depthmodelhardening_amd import ops  # noqa: E402
+xd = x.detach()
+with torch.no_grad():
+    aten = timeit(lambda: F.conv2d((xd - 0.45) / 0.225, w, None, 2, 3))
+    conv_only = timeit(lambda: F.conv2d(xd, w, None, 2, 3))
+    k14 = timeit(lambda: ops.stem_conv_norm(xd, w))
+    err = float((ops.stem_conv_norm(xd, w) - F.conv2d((xd - 0.45) / 0.225, w, None, 2, 3)).abs().max())
+fl = 2 * 147 * B * 64 * 160 * 512
+print("conv1 forward B=%d: ATen normalise + MIOpen %.1f us (convolution alone %.1f us), K14 %.1f us = %.1f TFLOP/s of 157.3; "
+      "max abs err %.1e" % (B, aten, conv_only, k14, fl / k14 / 1e6, err))
