@@ -12,6 +12,8 @@
 // and the convolutions run with padding = 0 on the padded tensors.  Backward kernels are gathers (the adjoint of the
 // reflection pad folds the border rows/columns back onto rows 1 and H-2): deterministic, no atomics.
 // Pure HBM streaming: one read + one write per element, 64-lane coalesced rows.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 using namespace dmh;
@@ -147,7 +149,142 @@ __global__ __launch_bounds__(NT) void elu_pad_bwd_kernel(const float* __restrict
     }
 }
 
+// ---- four-wide variants (w even, i.e. W = 2w a multiple of 4) -------------------------------------------------------
+// The pair kernels above are instruction-bound next to the memory system (an integer division, two reflections and up
+// to four expf per 8 bytes).  Here a thread owns four horizontally adjacent INTERIOR elements: the unpadded side moves
+// as aligned 16-byte accesses, the padded side as 4-byte-aligned 16-byte accesses (row pitch W+2 and the +1 column
+// shift make them unaligned by construction), the reflected border entries are written / folded by the threads that
+// own rows 1, H-2 and the first / last quad of a row, and up_cat_pad evaluates ELU once per source element instead
+// of once per upsampled copy.
+struct __attribute__((packed, aligned(4))) quad_u { float x, y, z, w; };
+__device__ __forceinline__ float4 load4u(const float* p) {
+    const quad_u v = *reinterpret_cast<const quad_u*>(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void store4u(float* p, const float4 v) {
+    quad_u q;
+    q.x = v.x; q.y = v.y; q.z = v.z; q.w = v.w;
+    *reinterpret_cast<quad_u*>(p) = q;
+}
+
+// writes interior quad (Y, X..X+3) of a padded plane and every border entry that reflects onto it
+__device__ __forceinline__ void put_quad(float* __restrict__ op, const float4 v, int Y, int X, int H, int W) {
+    const int PW = W + 2;
+    const bool first = X == 0, last = X + 4 == W;
+    float* r = op + (size_t)(Y + 1) * PW + X;
+    store4u(r + 1, v);
+    if (first) r[0] = v.y;
+    if (last) r[5] = v.z;
+    if (Y == 1) {
+        float* t = op + X;
+        store4u(t + 1, v);
+        if (first) t[0] = v.y;
+        if (last) t[5] = v.z;
+    }
+    if (Y == H - 2) {
+        float* t = op + (size_t)(H + 1) * PW + X;
+        store4u(t + 1, v);
+        if (first) t[0] = v.y;
+        if (last) t[5] = v.z;
+    }
+}
+
+// gradient of interior quad (Y, X..X+3): one unaligned 16-byte load away from the folded rows / columns
+__device__ __forceinline__ float4 fold_quad(const float* __restrict__ gp, int Y, int X, int H, int W) {
+    if (Y != 1 && Y != H - 2 && X != 0 && X + 4 != W) return load4u(gp + (size_t)(Y + 1) * (W + 2) + X + 1);
+    return make_float4(fold2d(gp, Y, X, H, W), fold2d(gp, Y, X + 1, H, W), fold2d(gp, Y, X + 2, H, W),
+                       fold2d(gp, Y, X + 3, H, W));
+}
+
+// blocks [0, nA): y planes, a thread = two source elements (i, j0), (i, j0+1) -> two output rows of four;
+// blocks [nA, ..): skip planes, a thread = one quad.  bpa / bpb = blocks per plane of each part.
+__global__ __launch_bounds__(NT) void up_cat_pad_fwd4_kernel(const float* __restrict__ y, const float* __restrict__ skip,
+                                                             int C1, int C2, int h, int w, int nA, int bpa, int bpb,
+                                                             float* __restrict__ out) {
+    const int H = 2 * h, W = 2 * w, C = C1 + C2;
+    const size_t pplane = (size_t)(H + 2) * (W + 2);
+    if ((int)blockIdx.x < nA) {
+        const int plane = blockIdx.x / bpa, t = (blockIdx.x - plane * bpa) * NT + threadIdx.x;
+        const int hw2 = w >> 1;
+        if (t >= h * hw2) return;
+        const int b = plane / C1, c = plane - b * C1;
+        const int i = t / hw2, j0 = (t - i * hw2) * 2;
+        const float2 yy = *reinterpret_cast<const float2*>(y + ((size_t)plane * h + i) * w + j0);
+        const float e0 = elu_f(yy.x), e1 = elu_f(yy.y);
+        const float4 v = make_float4(e0, e0, e1, e1);
+        float* op = out + (size_t)(b * C + c) * pplane;
+        put_quad(op, v, 2 * i, 2 * j0, H, W);
+        put_quad(op, v, 2 * i + 1, 2 * j0, H, W);
+    } else {
+        const int bi = blockIdx.x - nA, q = bi / bpb, t = (bi - q * bpb) * NT + threadIdx.x;
+        const int idx = t * 4;
+        if (idx >= H * W) return;
+        const int b = q / C2, c = q - b * C2;
+        const int Y = idx / W, X = idx - Y * W;
+        const float4 v = *reinterpret_cast<const float4*>(skip + (size_t)q * H * W + idx);
+        put_quad(out + (size_t)(b * C + C1 + c) * pplane, v, Y, X, H, W);
+    }
+}
+
+__global__ __launch_bounds__(NT) void up_cat_pad_bwd4_kernel(const float* __restrict__ y, const float* __restrict__ g_out,
+                                                             int C1, int C2, int h, int w, int nA, int bpa, int bpb,
+                                                             float* __restrict__ g_y, float* __restrict__ g_skip) {
+    const int H = 2 * h, W = 2 * w, C = C1 + C2;
+    const size_t pplane = (size_t)(H + 2) * (W + 2);
+    if ((int)blockIdx.x < nA) {
+        const int plane = blockIdx.x / bpa, t = (blockIdx.x - plane * bpa) * NT + threadIdx.x;
+        const int hw2 = w >> 1;
+        if (t >= h * hw2) return;
+        const int b = plane / C1, c = plane - b * C1;
+        const int i = t / hw2, j0 = (t - i * hw2) * 2;
+        const float* gp = g_out + (size_t)(b * C + c) * pplane;
+        const float4 r0 = fold_quad(gp, 2 * i, 2 * j0, H, W), r1 = fold_quad(gp, 2 * i + 1, 2 * j0, H, W);
+        const size_t o = ((size_t)plane * h + i) * w + j0;
+        const float2 yy = *reinterpret_cast<const float2*>(y + o);
+        *reinterpret_cast<float2*>(g_y + o) = make_float2((r0.x + r0.y + r1.x + r1.y) * elu_grad(yy.x),
+                                                          (r0.z + r0.w + r1.z + r1.w) * elu_grad(yy.y));
+    } else {
+        const int bi = blockIdx.x - nA, q = bi / bpb, t = (bi - q * bpb) * NT + threadIdx.x;
+        const int idx = t * 4;
+        if (idx >= H * W) return;
+        const int b = q / C2, c = q - b * C2;
+        const int Y = idx / W, X = idx - Y * W;
+        *reinterpret_cast<float4*>(g_skip + (size_t)q * H * W + idx) =
+            fold_quad(g_out + (size_t)(b * C + C1 + c) * pplane, Y, X, H, W);
+    }
+}
+
+__global__ __launch_bounds__(NT) void elu_pad_fwd4_kernel(const float* __restrict__ z, int H, int W, int apply_elu,
+                                                          float* __restrict__ out) {
+    const int idx = (blockIdx.x * NT + threadIdx.x) * 4;
+    if (idx >= H * W) return;
+    const int Y = idx / W, X = idx - Y * W;
+    float4 v = *reinterpret_cast<const float4*>(z + (size_t)blockIdx.y * H * W + idx);
+    if (apply_elu) v = make_float4(elu_f(v.x), elu_f(v.y), elu_f(v.z), elu_f(v.w));
+    put_quad(out + (size_t)blockIdx.y * (H + 2) * (W + 2), v, Y, X, H, W);
+}
+
+__global__ __launch_bounds__(NT) void elu_pad_bwd4_kernel(const float* __restrict__ z, const float* __restrict__ g_out,
+                                                          int H, int W, int apply_elu, float* __restrict__ g_z) {
+    const int idx = (blockIdx.x * NT + threadIdx.x) * 4;
+    if (idx >= H * W) return;
+    const int Y = idx / W, X = idx - Y * W;
+    const size_t base = (size_t)blockIdx.y * H * W + idx;
+    float4 g = fold_quad(g_out + (size_t)blockIdx.y * (H + 2) * (W + 2), Y, X, H, W);
+    if (apply_elu) {
+        const float4 zz = *reinterpret_cast<const float4*>(z + base);
+        g = make_float4(g.x * elu_grad(zz.x), g.y * elu_grad(zz.y), g.z * elu_grad(zz.z), g.w * elu_grad(zz.w));
+    }
+    *reinterpret_cast<float4*>(g_z + base) = g;
+}
+
 inline unsigned blocks_for(int n) { return (unsigned)((n + NT - 1) / NT); }
+
+// DMH_GLUE_PAIRS=1 forces the two-wide kernels (timing comparisons, tools/glue_bench.py)
+inline bool use_quads() {
+    static const bool q = [] { const char* e = getenv("DMH_GLUE_PAIRS"); return !(e && e[0] == '1'); }();
+    return q;
+}
 
 }  // namespace
 
@@ -158,8 +295,16 @@ int dmh_dec_up_cat_pad_fwd(const float* y, const float* skip, int B, int C1, int
     DMH_REQUIRE(y && out && (skip || C2 == 0), "null pointer");
     DMH_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && h >= 1 && w >= 1, "bad sizes");
     DMH_REQUIRE((int64_t)B * (C1 + C2) <= 65535 && (int64_t)(2 * h + 2) * (2 * w + 2) < (1 << 30), "tensor too large");
-    hipLaunchKernelGGL(up_cat_pad_fwd_kernel<true>, dim3(blocks_for((h + 1) * (2 * w + 2)), B * (C1 + C2)), dim3(NT), 0,
-                       (hipStream_t)stream, y, skip, C1, C2, h, w, out);
+    if ((w & 1) == 0 && use_quads()) {
+        const int bpa = (int)blocks_for(h * (w / 2)), bpb = (int)blocks_for(h * w);
+        const int64_t nA = (int64_t)B * C1 * bpa, nB = (int64_t)B * C2 * bpb;
+        DMH_REQUIRE(nA + nB < ((int64_t)1 << 31), "grid too large");
+        hipLaunchKernelGGL(up_cat_pad_fwd4_kernel, dim3((unsigned)(nA + nB)), dim3(NT), 0, (hipStream_t)stream, y, skip, C1,
+                           C2, h, w, (int)nA, bpa, bpb, out);
+    } else {
+        hipLaunchKernelGGL(up_cat_pad_fwd_kernel<true>, dim3(blocks_for((h + 1) * (2 * w + 2)), B * (C1 + C2)), dim3(NT),
+                           0, (hipStream_t)stream, y, skip, C1, C2, h, w, out);
+    }
     return check_launch("dmh_dec_up_cat_pad_fwd");
 }
 
@@ -169,9 +314,17 @@ int dmh_dec_up_cat_pad_bwd(const float* y, const float* g_out, int B, int C1, in
     DMH_REQUIRE(B > 0 && C1 > 0 && C2 >= 0 && h >= 1 && w >= 1, "bad sizes");
     const int planes = B * C1 + (g_skip ? B * C2 : 0);
     DMH_REQUIRE(planes <= 65535 && (int64_t)(2 * h + 2) * (2 * w + 2) < (1 << 30), "tensor too large");
-    const int per_plane = (g_skip && C2 > 0) ? 2 * h * w : h * w;   // threads: one per g_y element / per g_skip pair
-    hipLaunchKernelGGL(up_cat_pad_bwd_kernel<true>, dim3(blocks_for(per_plane), planes), dim3(NT), 0,
-                       (hipStream_t)stream, y, g_out, B, C1, C2, h, w, g_y, g_skip);
+    if ((w & 1) == 0 && use_quads()) {
+        const int bpa = (int)blocks_for(h * (w / 2)), bpb = (int)blocks_for(h * w);
+        const int64_t nA = (int64_t)B * C1 * bpa, nB = g_skip ? (int64_t)B * C2 * bpb : 0;
+        DMH_REQUIRE(nA + nB < ((int64_t)1 << 31), "grid too large");
+        hipLaunchKernelGGL(up_cat_pad_bwd4_kernel, dim3((unsigned)(nA + nB)), dim3(NT), 0, (hipStream_t)stream, y, g_out,
+                           C1, C2, h, w, (int)nA, bpa, bpb, g_y, g_skip);
+    } else {
+        const int per_plane = (g_skip && C2 > 0) ? 2 * h * w : h * w;   // threads: one per g_y element / per g_skip pair
+        hipLaunchKernelGGL(up_cat_pad_bwd_kernel<true>, dim3(blocks_for(per_plane), planes), dim3(NT), 0,
+                           (hipStream_t)stream, y, g_out, B, C1, C2, h, w, g_y, g_skip);
+    }
     return check_launch("dmh_dec_up_cat_pad_bwd");
 }
 
@@ -179,7 +332,10 @@ int dmh_elu_pad_fwd(const float* z, int B, int C, int H, int W, int apply_elu, f
     DMH_REQUIRE(z && out, "null pointer");
     DMH_REQUIRE(B > 0 && C > 0 && H >= 2 && W >= 2, "bad sizes");
     DMH_REQUIRE((int64_t)B * C <= 65535 && (int64_t)(H + 2) * (W + 2) < (1 << 30), "tensor too large");
-    if ((W & 1) == 0)
+    if ((W & 3) == 0 && use_quads())
+        hipLaunchKernelGGL(elu_pad_fwd4_kernel, dim3(blocks_for(H * W / 4), B * C), dim3(NT), 0, (hipStream_t)stream, z, H,
+                           W, apply_elu, out);
+    else if ((W & 1) == 0)
         hipLaunchKernelGGL(elu_pad_fwd_kernel<true>, dim3(blocks_for((H + 2) * (W + 2) / 2), B * C), dim3(NT), 0,
                            (hipStream_t)stream, z, H, W, apply_elu, out);
     else
@@ -193,7 +349,10 @@ int dmh_elu_pad_bwd(const float* z, const float* g_out, int B, int C, int H, int
     DMH_REQUIRE(z && g_out && g_z, "null pointer");
     DMH_REQUIRE(B > 0 && C > 0 && H >= 2 && W >= 2, "bad sizes");
     DMH_REQUIRE((int64_t)B * C <= 65535 && (int64_t)(H + 2) * (W + 2) < (1 << 30), "tensor too large");
-    if ((W & 1) == 0)
+    if ((W & 3) == 0 && use_quads())
+        hipLaunchKernelGGL(elu_pad_bwd4_kernel, dim3(blocks_for(H * W / 4), B * C), dim3(NT), 0, (hipStream_t)stream, z,
+                           g_out, H, W, apply_elu, g_z);
+    else if ((W & 1) == 0)
         hipLaunchKernelGGL(elu_pad_bwd_kernel<true>, dim3(blocks_for(H * W / 2), B * C), dim3(NT), 0, (hipStream_t)stream,
                            z, g_out, H, W, apply_elu, g_z);
     else

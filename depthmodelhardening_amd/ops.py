@@ -1060,9 +1060,12 @@ class _StemConvNorm(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_x = torch.empty_like(x)
             nb = 4 * (g.numel() + g_x.numel())
-            N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(_c(weight.detach())), B, 64, Cin,
-                                                                              H, W, N.ptr(g_x), N.stream()), nb))
-            g_x.mul_(1.0 / std)
+            # d/dx of conv((x - mean) / std, w) = conv_bwd_data(g, w / std): the 1/std goes into the 9,408 filter taps
+            # (once per attack inside frozen_weights()) instead of a pass over the image gradient
+            w_s = frozen_memo(("stem_w_over_std", weight.data_ptr(), weight._version, std),
+                              lambda: _c(weight.detach() * (1.0 / std)))
+            N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(w_s), B, 64, Cin, H, W,
+                                                                              N.ptr(g_x), N.stream()), nb))
         if ctx.needs_input_grad[1] and not ctx.params_const:
             xn = (x - mean) / std
             g_w = torch.ops.aten.convolution_backward(g, xn, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,

@@ -134,7 +134,8 @@ def test_glue_ops_small_shapes():
     from depthmodelhardening_amd import ops
     import torch.nn.functional as F
     g = torch.Generator(device="cuda").manual_seed(1)
-    for (B, C1, C2, h, w) in [(1, 2, 0, 2, 3), (2, 3, 2, 1, 2), (1, 1, 1, 5, 4)]:
+    for (B, C1, C2, h, w) in [(1, 2, 0, 2, 3), (2, 3, 2, 1, 2), (1, 1, 1, 5, 4), (2, 2, 3, 3, 6), (1, 3, 0, 2, 2),
+                               (1, 2, 1, 7, 130), (2, 1, 2, 1, 4)]:
         y = (torch.rand(B, C1, h, w, device="cuda", generator=g) - 0.5).requires_grad_(True)
         skip = torch.rand(B, C2, 2 * h, 2 * w, device="cuda", generator=g).requires_grad_(True) if C2 else None
         got = ops.up_cat_pad(y, skip)
@@ -149,8 +150,9 @@ def test_glue_ops_small_shapes():
         torch.testing.assert_close(got, ref, rtol=1e-6, atol=1e-7)
         for a, b in zip(ga, gb):
             torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
-    z = (torch.rand(2, 3, 4, 5, device="cuda", generator=g) - 0.5).requires_grad_(True)
-    for elu in (True, False):
+    for zshape, elu in [(s, e) for s in [(2, 3, 4, 5), (2, 3, 4, 8), (1, 2, 2, 4), (1, 1, 3, 4), (1, 2, 9, 260), (1, 1, 5, 6)]
+                        for e in (True, False)]:
+        z = (torch.rand(*zshape, device="cuda", generator=g) - 0.5).requires_grad_(True)
         got = ops.elu_pad(z, elu)
         ref = F.pad(F.elu(z) if elu else z, [1, 1, 1, 1], mode="reflect")
         w8 = torch.rand(got.shape, device="cuda", generator=g)
