@@ -12,6 +12,8 @@
 // HBM-bound: the scene (5.6 MB/sample) is read once, the 1.2 MB patch+mask stay L2-resident, the
 // output (5.2 MB/sample) is written once with 64-lane coalesced rows.  The backward is a gather per patch
 // texel over the inverse homography: deterministic, no atomics.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 using namespace dmh;
@@ -94,6 +96,36 @@ __device__ __forceinline__ RTap resize_tap(int oy, int ox, int SH, int SW, int O
     return r;
 }
 
+// Object bounding box in the scene: image of the patch rectangle (one texel of margin) under the inverse homography.
+// ok = all four corners finite and in front of the horizon; composite pixels whose centre lies outside the box have
+// an empty patch footprint (mask 0: the composite is the scene).
+struct ObjBox { float x0, x1, y0, y1; bool ok; };
+__device__ __forceinline__ ObjBox object_box(const float* __restrict__ c, const dmh_paste_args& a) {
+    ObjBox b;
+    b.x0 = 3.0e38f;
+    b.x1 = -3.0e38f;
+    b.y0 = 3.0e38f;
+    b.y1 = -3.0e38f;
+    b.ok = true;
+    const float i00 = c[4] - c[5] * c[7], i01 = c[2] * c[7] - c[1], i02 = c[1] * c[5] - c[2] * c[4];
+    const float i10 = c[5] * c[6] - c[3], i11 = c[0] - c[2] * c[6], i12 = c[2] * c[3] - c[0] * c[5];
+    const float i20 = c[3] * c[7] - c[4] * c[6], i21 = c[1] * c[6] - c[0] * c[7], i22 = c[0] * c[4] - c[1] * c[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float px = (float)a.l_pad + ((q & 1) ? (float)a.PW + 1.f : -1.f);
+        const float py = (float)a.t_pad + ((q & 2) ? (float)a.PH + 1.f : -1.f);
+        const float w = i20 * px + i21 * py + i22;
+        const float xs = (i00 * px + i01 * py + i02) / w, ys = (i10 * px + i11 * py + i12) / w;
+        b.ok = b.ok && (xs == xs) && (ys == ys) && (c[6] * xs + c[7] * ys + 1.0f > 0.f);
+        b.x0 = fminf(b.x0, xs);
+        b.x1 = fmaxf(b.x1, xs);
+        b.y0 = fminf(b.y0, ys);
+        b.y1 = fmaxf(b.y1, ys);
+    }
+    return b;
+}
+
+
 __global__ __launch_bounds__(NT) void paste_fwd_kernel(const dmh_paste_args a, float* __restrict__ adv,
                                                        float* __restrict__ mask_out) {
     const int n = blockIdx.y;
@@ -157,26 +189,9 @@ __global__ __launch_bounds__(NT) void paste_fwd4_kernel(const dmh_paste_args a, 
     const float sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
     const int y0 = (int)sy, y1 = y0 + (y0 < a.SH - 1 ? 1 : 0);
     const float ly = sy - (float)y0, hy = 1.f - ly;
-    // object bounding box in the scene: image of the patch rectangle (one texel of margin) under the inverse homography
-    float bx0 = 3.0e38f, bx1 = -3.0e38f, by0 = 3.0e38f, by1 = -3.0e38f;
-    bool box_ok = true;
-    {
-        const float i00 = c[4] - c[5] * c[7], i01 = c[2] * c[7] - c[1], i02 = c[1] * c[5] - c[2] * c[4];
-        const float i10 = c[5] * c[6] - c[3], i11 = c[0] - c[2] * c[6], i12 = c[2] * c[3] - c[0] * c[5];
-        const float i20 = c[3] * c[7] - c[4] * c[6], i21 = c[1] * c[6] - c[0] * c[7], i22 = c[0] * c[4] - c[1] * c[3];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float px = (float)a.l_pad + ((q & 1) ? (float)a.PW + 1.f : -1.f);
-            const float py = (float)a.t_pad + ((q & 2) ? (float)a.PH + 1.f : -1.f);
-            const float w = i20 * px + i21 * py + i22;
-            const float xs = (i00 * px + i01 * py + i02) / w, ys = (i10 * px + i11 * py + i12) / w;
-            box_ok = box_ok && (xs == xs) && (ys == ys) && (c[6] * xs + c[7] * ys + 1.0f > 0.f);
-            bx0 = fminf(bx0, xs);
-            bx1 = fmaxf(bx1, xs);
-            by0 = fminf(by0, ys);
-            by1 = fmaxf(by1, ys);
-        }
-    }
+    const ObjBox bb = object_box(c, a);
+    const float bx0 = bb.x0, bx1 = bb.x1, by0 = bb.y0, by1 = bb.y1;
+    const bool box_ok = bb.ok;
     const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW, ohw = (size_t)a.OH * a.OW;
     const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
     const float* sc = warp_only ? nullptr : a.scene + (size_t)n * a.scene_bstride;
@@ -249,6 +264,120 @@ __global__ __launch_bounds__(NT) void paste_fwd4_kernel(const dmh_paste_args a, 
     if (mask_out)
         *reinterpret_cast<float4*>(mask_out + (size_t)n * ohw + o) =
             flip ? make_float4(mres[3], mres[2], mres[1], mres[0]) : make_float4(mres[0], mres[1], mres[2], mres[3]);
+}
+
+// Tiled forward (OW % 4 == 0, resize ratios up to ~1.24 x 1.43: the attack's 375x1242 -> 320x1024).  A workgroup owns
+// TH x TW output pixels: (1a) the scene rectangle their bilinear taps cover is copied once into LDS with coalesced
+// row loads, (1b) if the object's bounding box meets that rectangle the composite is formed in place, ONCE per scene
+// pixel (paste_fwd4 re-formed it for every output tap: 2.8x), (2) every thread resizes four output pixels out of LDS
+// and stores them as 16-byte words.  Same per-pixel arithmetic as paste_fwd4_kernel.
+constexpr int TH = 8, TW = 128;          // output tile (TH * TW / 4 == NT)
+constexpr int RMAX = 12, CMAX = 160;     // scene rectangle held in LDS: 4 planes x 12 x 160 floats = 30 KB
+constexpr int NIT = (RMAX * CMAX + NT - 1) / NT;
+
+__device__ __forceinline__ int resize_src0(float ratio, int o) { return (int)fmaxf(ratio * ((float)o + 0.5f) - 0.5f, 0.f); }
+
+__global__ __launch_bounds__(NT) void paste_fwd_tile_kernel(const dmh_paste_args a, float* __restrict__ adv,
+                                                            float* __restrict__ mask_out) {
+    __shared__ float tile[4][RMAX * CMAX];
+    const int n = blockIdx.z, tid = threadIdx.x;
+    const bool flip = a.flip && a.flip[n];
+    const float* c = a.coeffs + n * 8;
+    const float rh = (float)a.SH / (float)a.OH, rw = (float)a.SW / (float)a.OW;
+    const int oyA = blockIdx.y * TH, oyB = min(oyA + TH, a.OH) - 1;
+    const int oxA = blockIdx.x * TW, oxB = min(oxA + TW, a.OW) - 1;      // computed (un-mirrored) columns
+    const int ry0 = resize_src0(rh, oyA), ry1 = min(resize_src0(rh, oyB) + 1, a.SH - 1);
+    const int rx0 = resize_src0(rw, oxA), rx1 = min(resize_src0(rw, oxB) + 1, a.SW - 1);
+    const int nr = min(ry1 - ry0 + 1, RMAX), nc = min(rx1 - rx0 + 1, CMAX);   // the host checked that nothing is clipped
+    const int ne = nr * nc;
+    const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW, ohw = (size_t)a.OH * a.OW;
+    const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
+    const float* sc = warp_only ? nullptr : a.scene + (size_t)n * a.scene_bstride;
+
+    // ---- 1a: scene rectangle -> LDS (mask plane 0)
+    {
+        const float inv_nc = 1.f / (float)nc;
+        float v[NIT][3];
+        int at[NIT];
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int e = min(tid + i * NT, ne - 1);
+            const int r = (int)(((float)e + 0.5f) * inv_nc), cc = e - r * nc;     // exact: e < 2^11
+            at[i] = r * CMAX + cc;
+            const size_t so = (size_t)(ry0 + r) * a.SW + (rx0 + cc);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) v[i][ch] = warp_only ? 0.f : sc[ch * shw + so];
+        }
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (tid + i * NT < ne) {
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) tile[ch][at[i]] = v[i][ch];
+                tile[3][at[i]] = 0.f;
+            }
+        }
+    }
+    // ---- 1b: composite inside (bounding box  ∩  rectangle); wave-uniform decision
+    {
+        const ObjBox bb = object_box(c, a);
+        int X0 = rx0, X1 = rx1, Y0 = ry0, Y1 = ry1;
+        if (bb.ok) {     // pixel centres X + 0.5 inside [x0, x1] (clamped before the float -> int conversion)
+            X0 = max(X0, (int)ceilf(fminf(fmaxf(bb.x0 - 0.5f, -1.f), (float)a.SW)));
+            X1 = min(X1, (int)floorf(fminf(fmaxf(bb.x1 - 0.5f, -1.f), (float)a.SW)));
+            Y0 = max(Y0, (int)ceilf(fminf(fmaxf(bb.y0 - 0.5f, -1.f), (float)a.SH)));
+            Y1 = min(Y1, (int)floorf(fminf(fmaxf(bb.y1 - 0.5f, -1.f), (float)a.SH)));
+        }
+        const int bw = X1 - X0 + 1, bh = Y1 - Y0 + 1;
+        if (bw > 0 && bh > 0) {
+            const Homog m = load_homog(c, a.SW, a.SH);
+            __syncthreads();                        // 1a's plain copies are in place
+            const float inv_bw = 1.f / (float)bw;
+#pragma unroll 1
+            for (int e = tid; e < bw * bh; e += NT) {
+                const int r = (int)(((float)e + 0.5f) * inv_bw), cc = e - r * bw;
+                const int Y = Y0 + r, X = X0 + cc;
+                const PTap t = patch_tap(m, X, Y, a.l_pad, a.t_pad, a.PW, a.PH);
+                if (!t.any) continue;
+                const int li = (Y - ry0) * CMAX + (X - rx0);
+                const float mk = patch_sample(a.pmask, t, a.PW, a.PH);
+                tile[3][li] = mk;
+#pragma unroll
+                for (int ch = 0; ch < 3; ++ch) {
+                    const float o = patch_sample(a.patch + ch * phw, t, a.PW, a.PH);
+                    tile[ch][li] = warp_only ? o : tile[ch][li] * (1.f - mk) + o * mk;      // phy_obj_atk.py:88
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- 2: bilinear resize of four output pixels per thread out of LDS
+    const int oy = oyA + (tid >> 5), ox0 = oxA + ((tid & 31) << 2);
+    if (oy > oyB || ox0 > oxB) return;
+    const float sy = fmaxf(rh * ((float)oy + 0.5f) - 0.5f, 0.f);
+    const int y0 = (int)sy, y1 = y0 + (y0 < a.SH - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, hy = 1.f - ly;
+    const int j0 = (y0 - ry0) * CMAX - rx0, j1 = (y1 - ry0) * CMAX - rx0;
+    float res[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float sx = fmaxf(rw * ((float)(ox0 + i) + 0.5f) - 0.5f, 0.f);
+        const int x0 = (int)sx, x1 = x0 + (x0 < a.SW - 1 ? 1 : 0);
+        const float lx = sx - (float)x0, hx = 1.f - lx;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch)
+            res[ch][i] = hy * (hx * tile[ch][j0 + x0] + lx * tile[ch][j0 + x1]) + ly * (hx * tile[ch][j1 + x0] + lx * tile[ch][j1 + x1]);
+    }
+    const size_t o = (size_t)oy * a.OW + (flip ? a.OW - 4 - ox0 : ox0);
+    if (adv) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch)
+            *reinterpret_cast<float4*>(adv + ((size_t)n * 3 + ch) * ohw + o) =
+                flip ? make_float4(res[ch][3], res[ch][2], res[ch][1], res[ch][0])
+                     : make_float4(res[ch][0], res[ch][1], res[ch][2], res[ch][3]);
+    }
+    if (mask_out)
+        *reinterpret_cast<float4*>(mask_out + (size_t)n * ohw + o) =
+            flip ? make_float4(res[3][3], res[3][2], res[3][1], res[3][0]) : make_float4(res[3][0], res[3][1], res[3][2], res[3][3]);
 }
 
 // ---------------------------------------------------------------------------------------------- backward
@@ -342,6 +471,12 @@ __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, c
     g_patch[2 * phw + idx] = acc2;
 }
 
+// DMH_PASTE_FWD4=1 keeps the untiled four-pixel kernel (timing comparisons, tools/prof_k3.py)
+inline bool force_paste4() {
+    static const bool f = [] { const char* e = getenv("DMH_PASTE_FWD4"); return e && e[0] == '1'; }();
+    return f;
+}
+
 int check_paste(const dmh_paste_args* a) {
     DMH_REQUIRE(a != nullptr, "args is null");
     DMH_REQUIRE(a->mode == DMH_PASTE_COMPOSITE || a->mode == DMH_PASTE_WARP_ONLY, "bad mode");
@@ -362,7 +497,13 @@ int dmh_eot_paste_fwd(const dmh_paste_args* a, float* adv, float* mask_out, void
     DMH_REQUIRE(adv || mask_out, "no output requested");
     const bool vec4 = (a->OW % 4) == 0 && ((uintptr_t)adv % 16) == 0 && ((uintptr_t)mask_out % 16) == 0 &&
                       (a->mode == DMH_PASTE_WARP_ONLY || a->scene != nullptr);
-    if (vec4)
+    // the tiled kernel's LDS rectangle must hold the taps of a TH x TW output tile
+    const float rh = (float)a->SH / (float)a->OH, rw = (float)a->SW / (float)a->OW;
+    const bool tiled = vec4 && (int)floorf(rh * (TH - 1)) + 3 <= RMAX && (int)floorf(rw * (TW - 1)) + 3 <= CMAX && !force_paste4();
+    if (tiled)
+        hipLaunchKernelGGL(paste_fwd_tile_kernel, dim3((a->OW + TW - 1) / TW, (a->OH + TH - 1) / TH, a->N), dim3(NT), 0,
+                           (hipStream_t)stream, *a, adv, mask_out);
+    else if (vec4)
         hipLaunchKernelGGL(paste_fwd4_kernel, dim3((a->OH * (a->OW / 4) + NT - 1) / NT, a->N), dim3(NT), 0, (hipStream_t)stream,
                            *a, adv, mask_out);
     else

@@ -297,8 +297,11 @@ def _paste_case(attack_ref, synth, tv082, n, seed):
     return obj, mask, scenes, pt, z0, al, torch.tensor(coeffs, dtype=torch.float32), l_pad, t_pad
 
 
-@pytest.mark.parametrize("n,seed,bcast", [(3, 1, False), (2, 2, True)])
-def test_eot_paste_vs_oracle(n, seed, bcast):
+@pytest.mark.parametrize("n,seed,bcast,out_size", [(3, 1, False, (320, 1024)), (2, 2, True, (320, 1024)),
+                                                   (2, 3, False, (330, 1100)),      # tiled kernel, ragged last tiles
+                                                   (2, 4, False, (288, 960)),       # ratio 1.29: untiled 4-pixel kernel
+                                                   (2, 5, False, (375, 1242))])     # OW % 4 != 0: generic kernel
+def test_eot_paste_vs_oracle(n, seed, bcast, out_size):
     N, ops, _, attack_ref, synth, tv082 = _mods()
     obj, mask, scenes, pt, z0, al, coeffs, l_pad, t_pad = _paste_case(attack_ref, synth, tv082, n, seed)
     if bcast:
@@ -306,14 +309,17 @@ def test_eot_paste_vs_oracle(n, seed, bcast):
     patch = obj.clone().requires_grad_(True)
     pt.reset_img(patch, mask)
     sc_full = scenes if not bcast else torch.cat(n * [scenes], 0)
-    adv, msk, _, _, _ = attack_ref.paste(sc_full, pt, n, z0, al)
+    o_full, m_full, _, _ = pt.project(batch_size=n, z0_sample=z0, alpha_sample=al)      # phy_obj_atk.py:87-90
+    adv, msk = tv082.resize(sc_full * (1 - m_full) + o_full * m_full, out_size), tv082.resize(m_full, out_size)
     gadv = torch.rand(adv.shape, generator=torch.Generator().manual_seed(9)) - 0.5
     (adv * gadv).sum().backward()
     dpatch = obj.cuda().requires_grad_(True)
-    dadv, dmsk = ops.eot_paste(scenes.cuda(), dpatch, mask.cuda(), coeffs.cuda(), l_pad, t_pad, (320, 1024))
+    dadv, dmsk = ops.eot_paste(scenes.cuda(), dpatch, mask.cuda(), coeffs.cuda(), l_pad, t_pad, out_size)
     (dadv * gadv.cuda()).sum().backward()
-    assert_close_frac(dadv, adv, rtol=1e-4, atol=2e-5, max_bad_frac=1e-5, name="adv scenes")
-    assert_close_frac(dmsk, msk, rtol=1e-4, atol=2e-5, max_bad_frac=1e-5, name="mask out")
+    # the few elements over tolerance sit on the mask edge (a 0/1 step sampled through the homography); none is far off
+    assert_close_frac(dadv, adv, rtol=1e-4, atol=2e-5, max_bad_frac=3e-5, name="adv scenes")
+    assert_close_frac(dmsk, msk, rtol=1e-4, atol=2e-5, max_bad_frac=3e-5, name="mask out")
+    assert float((dadv.detach().cpu() - adv.detach()).abs().max()) < 5e-4 and float((dmsk.cpu() - msk).abs().max()) < 5e-4
     assert float(dmsk.max()) > 0.99 and float(dmsk.min()) >= 0.0
     scale = patch.grad.abs().max().item()
     assert_close_frac(dpatch.grad, patch.grad, rtol=1e-3, atol=1e-4 * scale, max_bad_frac=1e-4, name="patch grad")
@@ -453,7 +459,7 @@ def test_full_size_properties():
         assert abs(float(o.fin[N.FIN_COUNT_S + s]) - float((o.sel[s] > 0).sum())) <= 2.0
 
 
-@pytest.mark.parametrize("out_size", [(320, 1024), (375, 1242), (64, 190)])
+@pytest.mark.parametrize("out_size", [(320, 1024), (375, 1242), (64, 190), (330, 1100), (300, 1000), (288, 960)])
 def test_eot_paste_flip_is_the_mirrored_paste(out_size):
     """flip[n] != 0: the whole composite of sample n is written mirrored (mono_dataset.py:222-225 on an un-flipped frame);
     both the 4-pixel-per-thread kernel (OW % 4 == 0) and the generic one; gradients follow."""
