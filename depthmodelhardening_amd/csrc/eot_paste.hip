@@ -381,19 +381,23 @@ __global__ __launch_bounds__(NT) void paste_fwd_tile_kernel(const dmh_paste_args
 }
 
 // ---------------------------------------------------------------------------------------------- backward
-// Deterministic gather: one thread per patch texel (v, u) collects, sample by sample and pixel by pixel in a fixed
-// order, what the forward pass spread over it -- no float atomics, no zero-initialised output, run-to-run bitwise
-// identical (an attack is a chain of sign() steps: bit-reproducible gradients make it replayable).
+// Deterministic gather: a patch texel (v, u) collects, sample by sample and pixel by pixel in a fixed order, what the
+// forward pass spread over it -- no float atomics, no zero-initialised output, run-to-run bitwise identical (an attack
+// is a chain of sign() steps: bit-reproducible gradients make it replayable).  LPT lanes share a texel: lane q takes
+// the samples n = q, q + LPT, ... (one each at the attack's 12 scenes, so 78,000 texels fill the chip instead of 1.2
+// workgroups per CU walking 12 samples in turn) and a fixed xor-butterfly adds the LPT partial sums.
 //   forward:  adv[n,c,oy,ox] = sum_{Y in {y0,y1}, X in {x0,x1}} wy wx [ scene (1 - mk) + o mk ](Y, X),
 //             o(Y,X) = bilinear(patch, S_n(X, Y)),  mk = bilinear(mask, S_n(X, Y))          (S_n: the homography)
 //   backward: g_patch[c,v,u] = sum_n sum_{(X,Y): texel (v,u) is a tap of S_n(X,Y)} tent * mk(Y,X) * G_n,c(Y,X),
 //             G_n,c(Y,X)     = sum_{(oy,ox): (Y,X) is a resize tap of (oy,ox)} wy wx g_adv[n,c,oy,ox]
 // The composite pixels (X, Y) that can reach a texel are those inside the image, under the inverse homography, of
 // the 2x2-texel square around it: a handful (the object is 0.4-0.9 scene pixels per texel at 5-10 m).
+constexpr int LPT = 16;
+
 __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, const float* __restrict__ g_adv,
                                                        float* __restrict__ g_patch) {
-    const int idx = blockIdx.x * NT + threadIdx.x;
-    if (idx >= a.PH * a.PW) return;
+    const int idx = blockIdx.x * (NT / LPT) + (threadIdx.x / LPT), sub = threadIdx.x % LPT;
+    if (idx >= a.PH * a.PW) return;             // whole LPT-lane groups leave together
     const int v = idx / a.PW, u = idx - v * a.PW;
     const float Uc = (float)(u + a.l_pad) + 0.5f, Vc = (float)(v + a.t_pad) + 0.5f;   // texel centre, padded frame
     const size_t ohw = (size_t)a.OH * a.OW, phw = (size_t)a.PH * a.PW;
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, c
     const float irh = (float)a.OH / (float)a.SH, irw = (float)a.OW / (float)a.SW;
     const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
     float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
-    for (int n = 0; n < a.N; ++n) {
+    for (int n = sub; n < a.N; n += LPT) {
         const float* c = a.coeffs + n * 8;
         const Homog m = load_homog(c, a.SW, a.SH);
         // adjugate of M = [[c0,c1,c2],[c3,c4,c5],[c6,c7,1]] (source = M * scene, pixel-centre coordinates)
@@ -466,9 +470,17 @@ __global__ __launch_bounds__(NT) void paste_bwd_kernel(const dmh_paste_args a, c
                 acc2 = fmaf(w, G2, acc2);
             }
     }
-    g_patch[idx] = acc0;
-    g_patch[phw + idx] = acc1;
-    g_patch[2 * phw + idx] = acc2;
+#pragma unroll
+    for (int d = LPT / 2; d >= 1; d >>= 1) {    // a + b is commutative: every lane of the group ends with the same bits
+        acc0 += __shfl_xor(acc0, d, LPT);
+        acc1 += __shfl_xor(acc1, d, LPT);
+        acc2 += __shfl_xor(acc2, d, LPT);
+    }
+    if (sub == 0) {
+        g_patch[idx] = acc0;
+        g_patch[phw + idx] = acc1;
+        g_patch[2 * phw + idx] = acc2;
+    }
 }
 
 // DMH_PASTE_FWD4=1 keeps the untiled four-pixel kernel (timing comparisons, tools/prof_k3.py)
@@ -515,8 +527,9 @@ int dmh_eot_paste_fwd(const dmh_paste_args* a, float* adv, float* mask_out, void
 int dmh_eot_paste_bwd(const dmh_paste_args* a, const float* g_adv, float* g_patch, void* stream) {
     if (int rc = check_paste(a)) return rc;
     DMH_REQUIRE(g_adv && g_patch, "null gradient buffers");
-    hipLaunchKernelGGL(paste_bwd_kernel, dim3((a->PH * a->PW + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, *a, g_adv,
-                       g_patch);
+    const int per_block = NT / LPT;
+    hipLaunchKernelGGL(paste_bwd_kernel, dim3((a->PH * a->PW + per_block - 1) / per_block), dim3(NT), 0, (hipStream_t)stream,
+                       *a, g_adv, g_patch);
     return check_launch("dmh_eot_paste_bwd");
 }
 
