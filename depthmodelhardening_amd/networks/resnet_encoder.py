@@ -53,10 +53,28 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
+    def _down_pair(self, x):
+        """(conv1(x), downsample[0](x)) as one K15 launch where the block opens a resolution level (3x3 stride 2 + 1x1
+        stride 2 on the same input: layer2.0 / layer3.0 / layer4.0); None for every other block."""
+        d = self.downsample
+        if d is None:
+            return None
+        c1, cd = self.conv1, d[0]
+        if (c1.stride == (2, 2) and c1.padding == (1, 1) and c1.dilation == (1, 1) and c1.groups == 1 and c1.bias is None
+                and cd.kernel_size == (1, 1) and cd.stride == (2, 2) and cd.padding == (0, 0) and cd.groups == 1
+                and cd.bias is None and ops.down_convs_ok(x, c1.weight, cd.weight)):
+            return ops.down_convs(x, c1.weight, cd.weight)
+        return None
+
     def forward(self, x):
         if _train_fused(self.bn1, x):       # train(): batch statistics by the K9 kernels, one pass for BN + add + ReLU
-            idt = x if self.downsample is None else ops.bn_act_train(self.downsample[1], self.downsample[0](x), relu=False)
-            out = ops.bn_act_train(self.bn1, _conv(self.conv1, x))
+            pair = self._down_pair(x)
+            if pair is not None:
+                idt = ops.bn_act_train(self.downsample[1], pair[1], relu=False)
+                out = ops.bn_act_train(self.bn1, pair[0])
+            else:
+                idt = x if self.downsample is None else ops.bn_act_train(self.downsample[1], self.downsample[0](x), relu=False)
+                out = ops.bn_act_train(self.bn1, _conv(self.conv1, x))
             return ops.bn_act_train(self.bn2, _conv(self.conv2, out), residual=idt)
         idt = x if self.downsample is None else self.downsample(x)
         out = self.relu(self.bn1(_conv(self.conv1, x)))
@@ -64,8 +82,13 @@ class BasicBlock(nn.Module):
         return self.relu(out + idt)
 
     def forward_fused(self, x, aff):
-        idt = x if self.downsample is None else ops.bn_act(self.downsample[0](x), *aff[self.downsample[1]], relu=False)
-        out = _conv_bn_act(self.conv1, x, aff[self.bn1])
+        pair = self._down_pair(x)
+        if pair is not None:
+            idt = ops.bn_act(pair[1], *aff[self.downsample[1]], relu=False)
+            out = ops.bn_act(pair[0], *aff[self.bn1])
+        else:
+            idt = x if self.downsample is None else ops.bn_act(self.downsample[0](x), *aff[self.downsample[1]], relu=False)
+            out = _conv_bn_act(self.conv1, x, aff[self.bn1])
         return _conv_bn_act(self.conv2, out, aff[self.bn2], residual=idt)
 
 

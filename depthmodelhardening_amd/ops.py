@@ -1085,6 +1085,72 @@ def stem_conv_norm(x, weight, mean=0.45, std=0.225):
     return _StemConvNorm.apply(_c(x), weight, float(mean), float(std))
 
 
+class _DownConvs(torch.autograd.Function):
+    """K15: conv3x3 stride 2 and the 1x1 stride-2 shortcut convolution of a down-sampling BasicBlock, one launch; backward:
+    both input gradients in one launch (no separate accumulation pass), weight gradients by MIOpen (train pass only)."""
+
+    @staticmethod
+    def forward(ctx, x, w3, wd):
+        lib = N.lib()
+        B, Cin, H, W = x.shape
+        Cout = w3.shape[0]
+        y3 = torch.empty((B, Cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        yd = torch.empty_like(y3)
+        nb = 4 * (x.numel() + 2 * y3.numel() + w3.numel() + wd.numel())
+        N.check(_timed("down_conv_fwd", lambda: lib.dmh_down_conv_fwd(
+            N.ptr(x), N.ptr(_c(w3.detach())), N.ptr(_c(wd.detach())), B, Cin, Cout, H, W, N.ptr(y3), N.ptr(yd), N.stream()),
+            nb, 20 * Cin * y3.numel()))
+        ctx.save_for_backward(x, w3, wd)
+        ctx.params_const = _wino_frozen > 0
+        return y3, yd
+
+    @staticmethod
+    def backward(ctx, g3, gd):
+        x, w3, wd = ctx.saved_tensors
+        lib = N.lib()
+        B, Cin, H, W = x.shape
+        Cout = w3.shape[0]
+        g3, gd = _c(g3), _c(gd)
+        g_x = g_w3 = g_wd = None
+        if ctx.needs_input_grad[0]:
+            # the kernel takes the filters transposed ([C_in][C_out][...]): once per attack inside frozen_weights()
+            w3t = frozen_memo(("down_w3t", w3.data_ptr(), w3._version), lambda: _c(w3.detach().transpose(0, 1)))
+            wdt = frozen_memo(("down_wdt", wd.data_ptr(), wd._version), lambda: _c(wd.detach().reshape(Cout, Cin).t()))
+            g_x = torch.empty_like(x)
+            nb = 4 * (g_x.numel() + 2 * g3.numel() + w3.numel() + wd.numel())
+            N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data(
+                N.ptr(g3), N.ptr(gd), N.ptr(w3t), N.ptr(wdt), B, Cin, Cout, H, W, N.ptr(g_x), N.stream()),
+                nb, 20 * Cin * g3.numel()))
+        if not ctx.params_const:
+            if ctx.needs_input_grad[1]:
+                g_w3 = torch.ops.aten.convolution_backward(g3, x, w3, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                           [False, True, False])[1]
+            if ctx.needs_input_grad[2]:
+                g_wd = torch.ops.aten.convolution_backward(gd, x, wd, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1,
+                                                           [False, True, False])[1]
+        return g_x, g_w3, g_wd
+
+
+def down_convs_ok(x, w3, wd):
+    """Shapes K15 takes: fp32 CUDA, [C_out, C_in, 3, 3] + [C_out, C_in, 1, 1] with both channel counts multiples of 64,
+    even input size."""
+    return (WINO_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and w3.dim() == 4 and wd.dim() == 4
+            and tuple(w3.shape[2:]) == (3, 3) and tuple(wd.shape[2:]) == (1, 1) and w3.shape[:2] == wd.shape[:2]
+            and w3.shape[1] == x.shape[1] and x.shape[1] % 64 == 0 and w3.shape[0] % 64 == 0
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2)
+
+
+def down_convs(x, w3, wd):
+    """(conv2d(x, w3, stride=2, padding=1), conv2d(x, wd, stride=2)): the first 3x3 convolution and the 1x1 shortcut of a
+    down-sampling torchvision BasicBlock (layer2.0 / layer3.0 / layer4.0 under MD2/networks/resnet_encoder.py:94-98), which
+    read the same input -- one K15 MFMA launch forward, one for the summed input gradient."""
+    if not x.is_cuda:
+        raise RuntimeError("libdmh_hip ops need CUDA (ROCm) tensors; got device %s -- there is no CPU path" % x.device)
+    if not down_convs_ok(x, w3, wd):
+        raise RuntimeError("down_convs: x [B,C,H,W] (C %% 64 == 0, even H, W), w3 [K,C,3,3], wd [K,C,1,1] (K %% 64 == 0) expected")
+    return _DownConvs.apply(_c(x), w3, wd)
+
+
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,
                         clamp_hi=80.0):
     """The eight attack-evaluation metrics of MD2/evaluate_depth.py:57-99 computed from two disparity maps in one

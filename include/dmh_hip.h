@@ -338,6 +338,20 @@ int dmh_conv3x3_head(const float* x, const float* w, const float* bias, int B, i
 int dmh_stem_conv_norm_fwd(const float* x, const float* w, int B, int H, int W, float mean, float std, float* y,
                            void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * K15 the two convolutions that open a down-sampling ResNet block (torchvision BasicBlock.conv1 with stride 2 and
+ *     BasicBlock.downsample[0], the layers behind MD2/networks/resnet_encoder.py:94-98), one launch per direction:
+ *     fwd:  y3[B,Co,H/2,W/2] = corr3x3_s2(zero_pad1(x[B,Ci,H,W]), w3[Co][Ci][3][3]);
+ *           yd[B,Co,H/2,W/2] = corr1x1_s2(x, wd[Co][Ci])                      (wd, yd both NULL: 3x3 only)
+ *     bwd:  g_x[B,Ci,H,W] = adjoint3x3(g3) + adjoint1x1(gd) with the filters TRANSPOSED: w3t[Ci][Co][3][3],
+ *           wdt[Ci][Co]                                                      (gd, wdt both NULL: 3x3 only)
+ *     Exact-fp32 MFMA.  H, W even; fwd: Ci % 8 == 0, Co % 64 == 0; bwd: Co % 8 == 0, Ci % 64 == 0.
+ * ---------------------------------------------------------------------------------- */
+int dmh_down_conv_fwd(const float* x, const float* w3, const float* wd, int B, int Cin, int Cout, int H, int W,
+                      float* y3, float* yd, void* stream);
+int dmh_down_conv_bwd_data(const float* g3, const float* gd, const float* w3t, const float* wdt, int B, int Cin, int Cout,
+                           int H, int W, float* g_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

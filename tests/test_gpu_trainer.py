@@ -680,3 +680,35 @@ def test_stem_conv_norm_vs_aten(shape):
         w.grad = None
         ops.stem_conv_norm(x2, w).backward(gy)
         assert w.grad is None and torch.equal(x2.grad, x.grad)
+
+
+def test_down_convs_vs_aten():
+    """ops.down_convs (K15: BasicBlock.conv1 with stride 2 + the 1x1 shortcut convolution in one MFMA launch; both input
+    gradients in one launch) == the two ATen/MIOpen convolutions: values, input gradient, weight gradients; ragged tiles
+    (rows of a tile from two images, partial column tiles), inside and outside frozen_weights()."""
+    from depthmodelhardening_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(11)
+    for (B, Ci, Co, H, W) in [(2, 64, 64, 6, 10), (3, 64, 128, 20, 64), (1, 128, 64, 2, 2), (2, 64, 64, 10, 70),
+                              (8, 64, 64, 80, 256)]:     # the last one: 64-channel backward tiles
+        x = torch.randn(B, Ci, H, W, device="cuda", generator=g).requires_grad_(True)
+        w3 = (torch.randn(Co, Ci, 3, 3, device="cuda", generator=g) * 0.05).requires_grad_(True)
+        wd = (torch.randn(Co, Ci, 1, 1, device="cuda", generator=g) * 0.1).requires_grad_(True)
+        assert ops.down_convs_ok(x, w3, wd)
+        g3 = torch.randn(B, Co, H // 2, W // 2, device="cuda", generator=g)
+        gd = torch.randn(B, Co, H // 2, W // 2, device="cuda", generator=g)
+        r3, rd = F.conv2d(x, w3, None, 2, 1), F.conv2d(x, wd, None, 2, 0)
+        ref = torch.autograd.grad([r3, rd], [x, w3, wd], [g3, gd])
+        y3, yd = ops.down_convs(x, w3, wd)
+        got = torch.autograd.grad([y3, yd], [x, w3, wd], [g3, gd])
+        for a, b, name in [(y3, r3, "y3"), (yd, rd, "yd"), (got[0], ref[0], "g_x"), (got[1], ref[1], "g_w3"), (got[2], ref[2], "g_wd")]:
+            assert_close_frac(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max()), name="down_convs %s %s" % (name, (B, Ci, Co, H, W)))
+        with ops.frozen_weights():      # parameters are constants: the input gradient only
+            y3, yd = ops.down_convs(x, w3, wd)
+            gx = torch.autograd.grad([y3, yd], [x], [g3, gd])[0]
+        assert torch.equal(gx, got[0])
+    assert not ops.down_convs_ok(torch.zeros(1, 32, 4, 4, device="cuda"), torch.zeros(64, 32, 3, 3, device="cuda"),
+                                 torch.zeros(64, 32, 1, 1, device="cuda"))
+    with pytest.raises(RuntimeError):
+        ops.down_convs(torch.zeros(1, 64, 5, 4, device="cuda"), torch.zeros(64, 64, 3, 3, device="cuda"),
+                       torch.zeros(64, 64, 1, 1, device="cuda"))
