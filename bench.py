@@ -36,7 +36,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured floa
 # widths are uncalibrated: calibrate on a known byte count in your own access pattern") -- calibrated on
 # smooth_fwd_kernel, which reads its 222.9 MB exactly once and reports FETCH_SIZE = 198.8 MB.  The backward reports
 # fewer bytes than its algorithmic reads because the images are still in the 256 MB Infinity Cache from the forward.
-MEASURED_TRAFFIC = {(32, 320, 1024): {"photo_fwd": 328.6e6, "photo_bwd": 219.0e6, "source": "profiles/r02_k1k2_pmc.csv"}}
+MEASURED_TRAFFIC = {(32, 320, 1024): {"photo_fwd": 328.9e6, "photo_bwd": 218.9e6, "source": "profiles/r02_k1k2_pmc.csv"}}
 
 
 def k1_bytes(B, H, W, scales=4):

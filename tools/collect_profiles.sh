@@ -23,6 +23,10 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/k3_fetch -- $K3 2 > $OUT/
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/k3_write -- $K3 2 > $OUT/k3_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/k3_pmc_a -- $K3 2 > $OUT/k3_pmc_a.log 2>&1
 echo "k3 passes done"
+# K14 (stem) and K15 (down-sampling block convolutions) against MIOpen at the attack shapes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k15_trace -- python3 tools/down_bench.py > $OUT/k15_trace.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k14_trace -- python3 tools/stem_bench.py > $OUT/k14_trace.log 2>&1
+echo "k14/k15 passes done"
 if [ "${2:-bench}" = "bench" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline > $OUT/bench.json 2> $OUT/bench.err
   tail -1 $OUT/bench.json

@@ -79,6 +79,14 @@ if tabs3:
             print("%-50s FETCH_SIZE %.1f MB WRITE_SIZE %.1f MB" % (k[:50], v.get("FETCH_SIZE", 0) * 1024 / 1e6,
                                                                   v.get("WRITE_SIZE", 0) * 1024 / 1e6))
 
+for kk in ("k14", "k15"):
+    f = first(G + kk + "_trace/*/*_kernel_stats.csv")
+    if f:
+        shutil.copy(f, "profiles/%s_%s_kernel_stats.csv" % (tag, kk))
+        for r in csv.DictReader(open(f)):
+            if "anonymous" in r["Name"]:
+                print("%s: %-70s %4s calls avg %.1f us" % (kk, r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
+
 ks10 = first(G + "k10_trace/*/*_kernel_stats.csv")
 if ks10:
     shutil.copy(ks10, "profiles/%s_k10_kernel_stats.csv" % tag)
