@@ -46,8 +46,8 @@ struct WArgs {
     const float* x;
     const f32x4* U;              // [C/8][16][2][Kp][4 floats], Kp = K rounded up to 64
     const float* bias;           // [K] or null
-    const float* res;            // EPI kernels: tensor added to the output before the activation, or null
-    int relu;                    // EPI kernels: clamp the output at zero
+    const float* res;            // EPI kernels: tensor added to the output before the activation (or, flag 2, its mask), or null
+    int relu;                    // EPI kernels: bit 0 clamp the output at zero; bit 1 `res` is a ReLU mask, not an addend
     float* y;
     int B, C, K, Kp, H, W, Ho, Wo, pad;
     int gx, gy, kg;              // tile-region groups along x / y, output-channel groups
@@ -416,9 +416,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             const float* rp = a.res + (yp - a.y);
                             const float2 r0 = *reinterpret_cast<const float2*>(rp);
                             const float2 r1 = *reinterpret_cast<const float2*>(rp + a.Wo);
-                            y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+                            if (a.relu & 2) {   // the tensor is a saved ReLU output: pass the gradient where it was positive
+                                y00 = r0.x > 0.f ? y00 : 0.f; y01 = r0.y > 0.f ? y01 : 0.f;
+                                y10 = r1.x > 0.f ? y10 : 0.f; y11 = r1.y > 0.f ? y11 : 0.f;
+                            } else {
+                                y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+                            }
                         }
-                        if (a.relu) {
+                        if (a.relu & 1) {
                             y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
                         }
                     }

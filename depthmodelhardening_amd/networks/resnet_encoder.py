@@ -26,6 +26,11 @@ def _conv_bn_act(conv, x, aff, residual=None):
     return ops.bn_act(conv(x), aff[0], aff[1], residual)
 
 
+def _plain3x3(conv):
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.bias is None)
+
+
 def _train_fused(bn, x):
     """Train-mode BatchNorm on a CUDA tensor with the standard configuration (affine, running statistics, momentum)."""
     return (ops.WINO_ENABLED and x.is_cuda and x.dtype == torch.float32 and bn.training and bn.momentum is not None
@@ -82,6 +87,10 @@ class BasicBlock(nn.Module):
         return self.relu(out + idt)
 
     def forward_fused(self, x, aff):
+        if (self.downsample is None and all(_plain3x3(c) for c in (self.conv1, self.conv2))
+                and ops.basic_block_eval_ok(x, self.conv1.weight, self.conv2.weight)):
+            # inside an attack: the whole block as one autograd node (masks and the identity add in K10's epilogues)
+            return ops.basic_block_eval(x, self.conv1.weight, *aff[self.bn1], self.conv2.weight, *aff[self.bn2])
         pair = self._down_pair(x)
         if pair is not None:
             idt = ops.bn_act(pair[1], *aff[self.downsample[1]], relu=False)

@@ -1151,6 +1151,76 @@ def down_convs(x, w3, wd):
     return _DownConvs.apply(_c(x), w3, wd)
 
 
+class _BasicBlockEval(torch.autograd.Function):
+    """A stride-1 torchvision BasicBlock in eval() with constant parameters (inside an attack), as one autograd node:
+        out1 = relu(bn1(conv1(x)));   y = relu(bn2(conv2(out1)) + x)          MD2/networks/resnet_encoder.py:85-98
+    forward = the two K10 launches of conv3x3_bn_act; backward = one K9 pass (mask by y) + two K10 launches whose
+    epilogues apply the ReLU mask of out1 and add the identity branch's gradient -- instead of two K9 passes, two K10
+    launches and autograd's accumulation add."""
+
+    @staticmethod
+    def forward(ctx, x, w1, s1, b1, w2, s2, b2):
+        lib = N.lib()
+        B, Cc, H, W = x.shape
+        out1, y = torch.empty_like(x), torch.empty_like(x)
+        nb = 4 * 2 * x.numel()
+        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+            N.ptr(x), N.ptr(_wino_filter(w1, False, s1)), N.ptr(b1), None, 1, B, Cc, Cc, H, W, 1, N.ptr(out1), N.stream()),
+            nb, 18 * Cc * x.numel()))
+        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+            N.ptr(out1), N.ptr(_wino_filter(w2, False, s2)), N.ptr(b2), N.ptr(x), 1, B, Cc, Cc, H, W, 1, N.ptr(y), N.stream()),
+            nb + 4 * x.numel(), 18 * Cc * x.numel()))
+        ctx.save_for_backward(out1, y, w1, s1, w2, s2)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        out1, y, w1, s1, w2, s2 = ctx.saved_tensors
+        lib = N.lib()
+        B, Cc, H, W = y.shape
+        g = _c(g)
+        ones = frozen_memo(("ones", Cc, g.device), lambda: torch.ones(Cc, device=g.device, dtype=torch.float32))
+        g2 = torch.empty_like(g)            # g * [y > 0]: gradient of conv2's BatchNorm output and of the identity branch
+        N.check(_timed("bn_act_bwd", lambda: lib.dmh_bn_act_bwd(N.ptr(y), N.ptr(g), N.ptr(ones), B, Cc, H * W, 1, N.ptr(g2),
+                                                               None, N.stream()), 12 * g.numel()))
+        g1, g_x = torch.empty_like(g), torch.empty_like(g)
+        nb = 4 * 3 * g.numel()
+        # conv2's backward-data, masked by [out1 > 0] in the epilogue (flag 2)
+        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+            N.ptr(g2), N.ptr(_wino_filter(w2, True, s2)), None, N.ptr(out1), 2, B, Cc, Cc, H, W, 1, N.ptr(g1), N.stream()),
+            nb, 18 * Cc * g.numel()))
+        # conv1's backward-data + the identity branch's gradient in the epilogue
+        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+            N.ptr(g1), N.ptr(_wino_filter(w1, True, s1)), None, N.ptr(g2), 0, B, Cc, Cc, H, W, 1, N.ptr(g_x), N.stream()),
+            nb, 18 * Cc * g.numel()))
+        return g_x, None, None, None, None, None, None
+
+
+def basic_block_eval_ok(x, w1, w2):
+    """Shapes and state the one-node BasicBlock takes: inside frozen_weights() (no parameter gradients exist there), fp32
+    CUDA, equal channel counts, both convolutions on the K10 epilogue kernel (no channel split)."""
+    if not (_wino_frozen > 0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+        return False
+    B, Cc, H, W = x.shape
+    return (tuple(w1.shape) == (Cc, Cc, 3, 3) and tuple(w2.shape) == (Cc, Cc, 3, 3)
+            and _wino_ok(B, Cc, Cc, H, W, allow_split=False))
+
+
+def basic_block_eval(x, w1, scale1, shift1, w2, scale2, shift2):
+    """relu(bn2(conv2(relu(bn1(conv1(x))))) + x) with the BatchNorms given as (scale, shift): a stride-1 BasicBlock of the
+    encoder during an attack (model in eval(), parameters constant), as one autograd node (see _BasicBlockEval)."""
+    if not basic_block_eval_ok(x, w1, w2):
+        raise RuntimeError("basic_block_eval: needs ops.frozen_weights(), an fp32 CUDA [B,C,H,W] input and [C,C,3,3] filters "
+                           "of a shape the Winograd kernel takes (ops.basic_block_eval_ok)")
+    _reject_affine_grad("basic_block_eval", scale1, shift1)
+    _reject_affine_grad("basic_block_eval", scale2, shift2)
+    if not x.requires_grad:         # nothing to differentiate: the two fused launches
+        y = conv3x3_bn_act(x, w1, scale1, shift1, None, True, 1)
+        return conv3x3_bn_act(y, w2, scale2, shift2, x, True, 1)
+    return _BasicBlockEval.apply(_c(x), w1.detach(), _c(scale1.detach()), _c(shift1.detach()), w2.detach(),
+                                 _c(scale2.detach()), _c(shift2.detach()))
+
+
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,
                         clamp_hi=80.0):
     """The eight attack-evaluation metrics of MD2/evaluate_depth.py:57-99 computed from two disparity maps in one

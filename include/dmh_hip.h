@@ -296,7 +296,9 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
  * MD2/networks/resnet_encoder.py:85-98, model in eval()): the per-channel scale is folded into the filter by
  * weight_transform_scaled (backward != 0: into the filter of the backward-data pass, whose input is then the masked
  * output gradient), the shift is `bias`, `residual` (same shape as y, may be NULL) is added before the ReLU.
- *   y = act(corr3x3(zero_pad(x), w * scale[k]) + bias[k] (+ residual)),  act = ReLU when relu != 0 */
+ *   y = act(corr3x3(zero_pad(x), w * scale[k]) + bias[k] (+ residual)),  act = ReLU when relu & 1.
+ * relu & 2: `residual` is not an addend but a saved ReLU output m: y = (corr3x3(...) + bias[k]) * [m > 0] -- the
+ * backward-data pass of one convolution of a block, masked for the ReLU in front of it, in the same launch. */
 int dmh_wino_weight_transform_scaled(const float* w, int K, int C, int backward, const float* scale, float* U,
                                      void* stream);
 int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,

@@ -712,3 +712,40 @@ def test_down_convs_vs_aten():
     with pytest.raises(RuntimeError):
         ops.down_convs(torch.zeros(1, 64, 5, 4, device="cuda"), torch.zeros(64, 64, 3, 3, device="cuda"),
                        torch.zeros(64, 64, 1, 1, device="cuda"))
+
+
+def test_basic_block_eval_node_vs_module_path():
+    """ops.basic_block_eval (one autograd node per stride-1 BasicBlock inside an attack: ReLU mask and identity gradient in
+    the K10 epilogues) == the block's module path (conv, BatchNorm2d.eval(), add, ReLU as ATen ops): output and input
+    gradient; outside frozen_weights() the encoder keeps the per-convolution path."""
+    from depthmodelhardening_amd import ops
+    from depthmodelhardening_amd.networks.resnet_encoder import BasicBlock
+    torch.manual_seed(5)
+    for (B, C, H, W) in [(12, 64, 80, 256), (12, 128, 40, 128), (3, 64, 22, 70)]:
+        blk = BasicBlock(C, C).cuda().eval()
+        with torch.no_grad():
+            for bn in (blk.bn1, blk.bn2):
+                bn.running_mean.uniform_(-0.2, 0.2)
+                bn.running_var.uniform_(0.5, 1.5)
+                bn.weight.uniform_(0.5, 1.5)
+                bn.bias.uniform_(-0.2, 0.2)
+        x = torch.randn(B, C, H, W, device="cuda").requires_grad_(True)
+        gy = torch.randn(B, C, H, W, device="cuda")
+        ref = blk(x)                      # module path (outside frozen_weights, BN parameters require grad)
+        gref = torch.autograd.grad(ref, x, gy)[0]
+        aff = {}
+        for bn in (blk.bn1, blk.bn2):
+            sc = (bn.weight * torch.rsqrt(bn.running_var + bn.eps)).detach()
+            aff[bn] = (sc, (bn.bias - bn.running_mean * sc).detach())
+        assert not ops.basic_block_eval_ok(x, blk.conv1.weight, blk.conv2.weight)       # not inside an attack
+        with ops.frozen_weights():
+            if not ops.basic_block_eval_ok(x, blk.conv1.weight, blk.conv2.weight):
+                assert (H, W) == (22, 70)       # ragged shape the Winograd kernel does not take: per-convolution path
+                got = blk.forward_fused(x, aff)
+            else:
+                got = blk.forward_fused(x, aff)
+                assert type(got.grad_fn).__name__.startswith("_BasicBlockEval")
+            ggot = torch.autograd.grad(got, x, gy)[0]
+        assert_close_frac(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()), name="block out")
+        # ReLU kinks: elements whose pre-activation is within rounding of zero may take the other branch
+        assert_close_frac(ggot, gref, rtol=1e-3, atol=1e-4 * float(gref.abs().max()), max_bad_frac=2e-4, name="block grad")
