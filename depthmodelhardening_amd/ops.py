@@ -908,12 +908,22 @@ class _Conv3x3(torch.autograd.Function):
         elif need_x and _small_ok(K, Cc):
             g_x = _small_conv(g, weight, None, 2 - pad, True)
             need_x = False
+        if need_w and K == 1 and WINO_ENABLED:
+            # disparity head (one output channel): K13's strip reduction instead of MIOpen's 1-row implicit GEMM
+            lib = N.lib()
+            part = torch.empty(lib.dmh_conv3x3_head_wrw_partials_size(B, Cc, H, W, pad), device=g.device, dtype=torch.float32)
+            g_w = torch.empty_like(weight)
+            g_b = torch.empty(1, device=g.device, dtype=torch.float32) if need_b else None
+            N.check(_timed("conv3x3_head_wrw", lambda: lib.dmh_conv3x3_head_wrw(
+                N.ptr(x), N.ptr(g), B, Cc, H, W, pad, N.ptr(part), N.ptr(g_w), N.ptr(g_b), N.stream()),
+                4 * (x.numel() + g.numel())))
+            need_w = need_b = False
         if need_x or need_w or need_b:
             r = torch.ops.aten.convolution_backward(g, x, weight, [K] if ctx.has_bias else None, [1, 1], [pad, pad], [1, 1],
                                                     False, [0, 0], 1, [need_x, need_w, need_b])
             g_x = r[0] if need_x else g_x
-            g_w = r[1] if need_w else None
-            g_b = r[2] if need_b else None
+            g_w = r[1] if need_w else g_w
+            g_b = r[2] if need_b else g_b
         return g_x, g_w, g_b, None
 
 

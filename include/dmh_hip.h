@@ -330,6 +330,12 @@ int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int C
  * ---------------------------------------------------------------------------------- */
 int dmh_conv3x3_head(const float* x, const float* w, const float* bias, int B, int C, int H, int W, int pad, float* y,
                      void* stream);
+/* weight and bias gradient of the same layer (train pass): g_w[1][C][3][3] = sum_{b,y,x} g[b,0,y,x] * zero_pad(x)[b,c,y+ky,x+kx],
+ * g_b[0] = sum g (g_b may be NULL).  `partials`: dmh_conv3x3_head_wrw_partials_size(...) floats of workspace (per-strip
+ * sums, added in a fixed order: deterministic).  Any C. */
+int64_t dmh_conv3x3_head_wrw_partials_size(int B, int C, int H, int W, int pad);
+int dmh_conv3x3_head_wrw(const float* x, const float* g, int B, int C, int H, int W, int pad, float* partials, float* g_w,
+                         float* g_b, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K14 the encoder's first layer with its input normalisation fused (MD2/networks/resnet_encoder.py:89-90:

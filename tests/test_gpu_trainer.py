@@ -749,3 +749,24 @@ def test_basic_block_eval_node_vs_module_path():
         assert_close_frac(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()), name="block out")
         # ReLU kinks: elements whose pre-activation is within rounding of zero may take the other branch
         assert_close_frac(ggot, gref, rtol=1e-3, atol=1e-4 * float(gref.abs().max()), max_bad_frac=2e-4, name="block grad")
+
+
+def test_head_weight_gradient_vs_aten():
+    """ops.conv3x3 with ONE output channel (the disparity heads): weight and bias gradient by K13's strip reduction ==
+    aten.convolution_backward; ragged strips, every padding, channel counts that split over several waves; run twice
+    bitwise identical (fixed-order reduction)."""
+    from depthmodelhardening_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(13)
+    for (B, C, H, W, pad) in [(2, 16, 42, 70, 0), (1, 32, 20, 130, 1), (3, 64, 10, 34, 2), (2, 128, 42, 130, 0),
+                              (1, 5, 3, 3, 0), (4, 16, 82, 258, 0)]:
+        x = torch.randn(B, C, H, W, device="cuda", generator=g).requires_grad_(True)
+        w = (torch.randn(1, C, 3, 3, device="cuda", generator=g) * 0.1).requires_grad_(True)
+        bias = torch.randn(1, device="cuda", generator=g).requires_grad_(True)
+        gy = torch.randn(B, 1, H + 2 * pad - 2, W + 2 * pad - 2, device="cuda", generator=g)
+        ref = torch.autograd.grad(F.conv2d(x, w, bias, 1, pad), [x, w, bias], gy)
+        got = torch.autograd.grad(ops.conv3x3(x, w, bias, pad), [x, w, bias], gy)
+        again = torch.autograd.grad(ops.conv3x3(x, w, bias, pad), [x, w, bias], gy)
+        for a, b_, name in zip(got, ref, ("g_x", "g_w", "g_b")):
+            assert_close_frac(a, b_, rtol=2e-4, atol=2e-5 * float(b_.abs().max()) + 1e-6, name="head %s %s" % (name, (B, C, H, W, pad)))
+        assert torch.equal(got[1], again[1]) and torch.equal(got[2], again[2])
