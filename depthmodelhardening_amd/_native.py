@@ -93,6 +93,8 @@ _SIGNATURES = {
     "dmh_conv3x3_head": (C.c_int, [_fp] * 3 + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_conv3x3_head_wrw_partials_size": (C.c_int64, [C.c_int] * 5),
     "dmh_conv3x3_head_wrw": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp] * 4),
+    "dmh_conv3x3_small_wrw_partials_size": (C.c_int64, [C.c_int]),
+    "dmh_conv3x3_small_wrw": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp] * 4),
     "dmh_conv7x7s2_bwd_data": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_stem_conv_norm_fwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp]),
     "dmh_down_conv_fwd": (C.c_int, [_fp] * 3 + [C.c_int] * 5 + [_fp] * 3),

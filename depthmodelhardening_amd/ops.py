@@ -918,6 +918,16 @@ class _Conv3x3(torch.autograd.Function):
                 N.ptr(x), N.ptr(g), B, Cc, H, W, pad, N.ptr(part), N.ptr(g_w), N.ptr(g_b), N.stream()),
                 4 * (x.numel() + g.numel())))
             need_w = need_b = False
+        if need_w and K == 16 and Cc in (16, 32) and WINO_ENABLED:
+            # last decoder stage: K16 (pixel axis on the MFMA, persistent workgroups) instead of MIOpen's implicit GEMM
+            lib = N.lib()
+            part = torch.empty(lib.dmh_conv3x3_small_wrw_partials_size(Cc), device=g.device, dtype=torch.float32)
+            g_w = torch.empty_like(weight)
+            g_b = torch.empty(16, device=g.device, dtype=torch.float32) if need_b else None
+            N.check(_timed("conv3x3_small_wrw", lambda: lib.dmh_conv3x3_small_wrw(
+                N.ptr(x), N.ptr(g), B, Cc, H, W, pad, N.ptr(part), N.ptr(g_w), N.ptr(g_b), N.stream()),
+                4 * (x.numel() + g.numel()), 2 * 9 * 16 * Cc * g.numel() // 16))
+            need_w = need_b = False
         if need_x or need_w or need_b:
             r = torch.ops.aten.convolution_backward(g, x, weight, [K] if ctx.has_bias else None, [1, 1], [pad, pad], [1, 1],
                                                     False, [0, 0], 1, [need_x, need_w, need_b])

@@ -338,6 +338,17 @@ int dmh_conv3x3_head_wrw(const float* x, const float* g, int B, int C, int H, in
                          float* g_b, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K16 weight and bias gradient of the 3x3 stride-1 convolutions with 16 OUTPUT channels and 16 or 32 input channels (the
+ *     last decoder stage, MD2/networks/depth_decoder.py:38-41 upconv(0,0) / upconv(0,1); train pass):
+ *     g_w[16][C][3][3] = sum_{b,y,x} g[b,k,y,x] * zero_pad(x)[b,c,y+ky,x+kx],  g_b[16] = sum g  (g_b may be NULL).
+ *     Pixel axis on the fp32 MFMA; `partials`: dmh_conv3x3_small_wrw_partials_size(C) floats of workspace
+ *     (per-workgroup sums, added in a fixed order: deterministic).
+ * ---------------------------------------------------------------------------------- */
+int64_t dmh_conv3x3_small_wrw_partials_size(int C);
+int dmh_conv3x3_small_wrw(const float* x, const float* g, int B, int C, int H, int W, int pad, float* partials, float* g_w,
+                          float* g_b, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K14 the encoder's first layer with its input normalisation fused (MD2/networks/resnet_encoder.py:89-90:
  *     x = (input_image - 0.45) / 0.225;  x = conv1(x),  conv1 = nn.Conv2d(3, 64, 7, stride 2, padding 3, bias=False)):
  *     y[B,64,H/2,W/2] = corr7x7_s2(zero_pad3((x[B,3,H,W] - mean) / std), w[64][3][7][7]) on the exact-fp32 MFMA.

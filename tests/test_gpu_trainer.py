@@ -770,3 +770,24 @@ def test_head_weight_gradient_vs_aten():
         for a, b_, name in zip(got, ref, ("g_x", "g_w", "g_b")):
             assert_close_frac(a, b_, rtol=2e-4, atol=2e-5 * float(b_.abs().max()) + 1e-6, name="head %s %s" % (name, (B, C, H, W, pad)))
         assert torch.equal(got[1], again[1]) and torch.equal(got[2], again[2])
+
+
+def test_small_weight_gradient_vs_aten():
+    """ops.conv3x3 with 16 output and 16 / 32 input channels (the last decoder stage): weight and bias gradient by K16
+    (pixel axis on the fp32 MFMA, persistent workgroups, fixed-order reduction) == aten.convolution_backward; ragged
+    tiles, every padding, more tiles than workgroups; run twice bitwise identical."""
+    from depthmodelhardening_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator(device="cuda").manual_seed(17)
+    for (B, C, H, W, pad) in [(2, 16, 22, 70, 0), (1, 32, 9, 130, 1), (3, 16, 5, 30, 2), (2, 32, 42, 130, 0),
+                              (1, 16, 3, 3, 0), (8, 16, 162, 514, 0), (6, 32, 82, 258, 0)]:
+        x = torch.randn(B, C, H, W, device="cuda", generator=g).requires_grad_(True)
+        w = (torch.randn(16, C, 3, 3, device="cuda", generator=g) * 0.1).requires_grad_(True)
+        bias = torch.randn(16, device="cuda", generator=g).requires_grad_(True)
+        gy = torch.randn(B, 16, H + 2 * pad - 2, W + 2 * pad - 2, device="cuda", generator=g)
+        ref = torch.autograd.grad(F.conv2d(x, w, bias, 1, pad), [x, w, bias], gy)
+        got = torch.autograd.grad(ops.conv3x3(x, w, bias, pad), [x, w, bias], gy)
+        again = torch.autograd.grad(ops.conv3x3(x, w, bias, pad), [x, w, bias], gy)
+        for a, b_, name in zip(got, ref, ("g_x", "g_w", "g_b")):
+            assert_close_frac(a, b_, rtol=2e-4, atol=3e-5 * float(b_.abs().max()) + 1e-6, name="small wrw %s %s" % (name, (B, C, H, W, pad)))
+        assert torch.equal(got[1], again[1]) and torch.equal(got[2], again[2])

@@ -55,12 +55,12 @@ print("total per train pass: %.2f ms" % (tot / 1e3))
 sys.path.insert(0, ".")
 from depthmodelhardening_amd import ops  # noqa: E402
 for name, ci, co, h, w, k, st, pad, cnt in SHAPES:
-    if co != 1:
+    if not (co == 1 or (co == 16 and ci in (16, 32))):      # K13 heads, K16 last decoder stage
         continue
     x = torch.randn(B, ci, h, w, device=dev)
-    wt = torch.randn(1, ci, 3, 3, device=dev, requires_grad=True)
-    bs = torch.randn(1, device=dev, requires_grad=True)
+    wt = torch.randn(co, ci, 3, 3, device=dev, requires_grad=True)
+    bs = torch.randn(co, device=dev, requires_grad=True)
     y = ops.conv3x3(x, wt, bs, pad)
     g = torch.randn_like(y)
     t = timeit(lambda: torch.autograd.grad(y, [wt, bs], g, retain_graph=True))
-    print("%-16s K13 weight+bias gradient through autograd: %7.1f us" % (name, t))
+    print("%-16s K13 / K16 weight+bias gradient through autograd: %7.1f us" % (name, t))
