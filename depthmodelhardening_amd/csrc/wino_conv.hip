@@ -397,9 +397,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const bool inside = (FLAT ? Rt < NR : oy < a.Ho) && ox < a.Wo;
             float* yb = a.y + (size_t)ob * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
             const int kbase = it.k0 + kb * 32 + 4 * (lane_o >> 5);
+            // EPI: the residual / mask values of channel v + RPF are requested while channel v is transformed (a load
+            // issued and consumed inside one fenced iteration costs its full latency 16 times per item)
+            constexpr int RPF = 4;
+            float2 rq0[RPF], rq1[RPF];
+            const bool use_res = EPI && a.res != nullptr;
+            auto res_fetch = [&](const int v, float2& q0, float2& q1) __attribute__((always_inline)) {
+                const int ko = kbase + (v & 3) + 8 * (v >> 2);
+                q0 = q1 = make_float2(0.f, 0.f);
+                if (use_res && inside && ko < a.K) {
+                    const float* rp = a.res + ((yb - a.y) + (size_t)ko * a.Ho * a.Wo);
+                    q0 = *reinterpret_cast<const float2*>(rp);
+                    q1 = *reinterpret_cast<const float2*>(rp + a.Wo);
+                }
+            };
+            if (EPI) {
+#pragma unroll
+                for (int v = 0; v < RPF; ++v) res_fetch(v, rq0[v], rq1[v]);
+            }
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int ko = kbase + (v & 3) + 8 * (v >> 2);
+                float2 r0 = make_float2(0.f, 0.f), r1 = r0;
+                if (EPI) {
+                    r0 = rq0[v % RPF];
+                    r1 = rq1[v % RPF];
+                    if (v + RPF < 16) res_fetch(v + RPF, rq0[v % RPF], rq1[v % RPF]);
+                }
                 float s0[4], s1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -413,9 +437,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     float* yp = yb + (size_t)ko * a.Ho * a.Wo;
                     if (EPI) {      // fused eval-mode BatchNorm (scale in the filter, shift = bias) + identity + ReLU
                         if (a.res) {
-                            const float* rp = a.res + (yp - a.y);
-                            const float2 r0 = *reinterpret_cast<const float2*>(rp);
-                            const float2 r1 = *reinterpret_cast<const float2*>(rp + a.Wo);
                             if (a.relu & 2) {   // the tensor is a saved ReLU output: pass the gradient where it was positive
                                 y00 = r0.x > 0.f ? y00 : 0.f; y01 = r0.y > 0.f ? y01 : 0.f;
                                 y10 = r1.x > 0.f ? y10 : 0.f; y11 = r1.y > 0.f ? y11 : 0.f;
