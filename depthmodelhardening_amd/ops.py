@@ -18,11 +18,16 @@ LossOut = namedtuple("LossOut", ["fin", "sel", "to_opt"])
 # Optional per-launch HIP-event timing of the K1 kernels (bench.py's roofline figure): a dict
 # name -> list of (start, end) torch.cuda.Event pairs recorded on the launch stream, or None (off).
 _profile = None
+_profile_only = None
 
 
-def enable_profile(on=True):
-    global _profile
+def enable_profile(on=True, only=None):
+    """HIP-event timing of the instrumented launches.  ``only``: tuple of name prefixes to time (the others launch
+    untouched) -- an event pair adds ~10 us of dispatch latency around a launch, so a timed region should carry events
+    on the kernels it reports and nothing else."""
+    global _profile, _profile_only
     _profile = {} if on else None
+    _profile_only = tuple(only) if (on and only) else None
 
 
 def profile_ms():
@@ -44,7 +49,7 @@ def profile_bytes():
 
 
 def _timed(name, launch, nbytes=0, flops=0):
-    if _profile is None:
+    if _profile is None or (_profile_only is not None and not name.startswith(_profile_only)):
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
