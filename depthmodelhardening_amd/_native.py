@@ -98,6 +98,7 @@ _SIGNATURES = {
     "dmh_conv7x7s2_bwd_data": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_stem_conv_norm_fwd": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _fp, _fp]),
     "dmh_down_conv_fwd": (C.c_int, [_fp] * 3 + [C.c_int] * 5 + [_fp] * 3),
+    "dmh_down_conv_fwd_act": (C.c_int, [_fp] * 5 + [C.c_int] * 6 + [_fp] * 3),
     "dmh_down_conv_bwd_data": (C.c_int, [_fp] * 4 + [C.c_int] * 5 + [_fp, _fp]),
 }
 

@@ -79,6 +79,8 @@ constexpr int F_NP = (CK * F_PEL + NT - 1) / NT;                                
 
 struct FArgs {
     const float *x, *w3, *wd;
+    const float *shift3, *shiftd;     // optional per-channel addends of y3 / yd (an eval-mode BatchNorm whose scale is in the filter)
+    int relu3;                        // clamp y3 at zero after the shift
     float *y3, *yd;
     int B, Cin, Cout, H, W, Ho, Wo, gx, gy, gk;     // gy = row tiles over B * Ho
 };
@@ -184,11 +186,25 @@ __global__ __launch_bounds__(NT, 2) void down_conv_fwd_kernel(const FArgs a) {
 #pragma unroll
         for (int v = 0; v < 16; ++v) {
             const int i = 8 * (v >> 2) + 4 * h + (v & 3);
-            a.y3[o + (size_t)i * HWo] = accA[v];
-            a.y3[o + (size_t)(i + 32) * HWo] = accB[v];
+            float ya = accA[v], yb = accB[v];
+            if (a.shift3) {
+                ya += a.shift3[k0 + i];
+                yb += a.shift3[k0 + i + 32];
+            }
+            if (a.relu3) {
+                ya = fmaxf(ya, 0.f);
+                yb = fmaxf(yb, 0.f);
+            }
+            a.y3[o + (size_t)i * HWo] = ya;
+            a.y3[o + (size_t)(i + 32) * HWo] = yb;
             if constexpr (DOWN) {
-                a.yd[o + (size_t)i * HWo] = accDA[v];
-                a.yd[o + (size_t)(i + 32) * HWo] = accDB[v];
+                float da = accDA[v], db = accDB[v];
+                if (a.shiftd) {
+                    da += a.shiftd[k0 + i];
+                    db += a.shiftd[k0 + i + 32];
+                }
+                a.yd[o + (size_t)i * HWo] = da;
+                a.yd[o + (size_t)(i + 32) * HWo] = db;
             }
         }
     }
@@ -361,15 +377,27 @@ int check_sizes(int B, int Cin, int Cout, int H, int W) {
 
 extern "C" {
 
+int dmh_down_conv_fwd_act(const float* x, const float* w3, const float* wd, const float* shift3, const float* shiftd,
+                          int relu3, int B, int Cin, int Cout, int H, int W, float* y3, float* yd, void* stream);
+
 int dmh_down_conv_fwd(const float* x, const float* w3, const float* wd, int B, int Cin, int Cout, int H, int W,
                       float* y3, float* yd, void* stream) {
+    return dmh_down_conv_fwd_act(x, w3, wd, nullptr, nullptr, 0, B, Cin, Cout, H, W, y3, yd, stream);
+}
+
+int dmh_down_conv_fwd_act(const float* x, const float* w3, const float* wd, const float* shift3, const float* shiftd,
+                          int relu3, int B, int Cin, int Cout, int H, int W, float* y3, float* yd, void* stream) {
     DMH_REQUIRE(x && w3 && y3 && ((wd == nullptr) == (yd == nullptr)), "null pointer");
+    DMH_REQUIRE(shiftd == nullptr || wd != nullptr, "shiftd without the shortcut convolution");
     if (int rc = check_sizes(B, Cin, Cout, H, W)) return rc;
     DMH_REQUIRE(Cin % CK == 0 && Cout % 64 == 0, "C_in must be a multiple of 8 and C_out of 64");
     FArgs a;
     a.x = x;
     a.w3 = w3;
     a.wd = wd;
+    a.shift3 = shift3;
+    a.shiftd = shiftd;
+    a.relu3 = relu3 ? 1 : 0;
     a.y3 = y3;
     a.yd = yd;
     a.B = B;
@@ -388,7 +416,7 @@ int dmh_down_conv_fwd(const float* x, const float* w3, const float* wd, int B, i
         hipLaunchKernelGGL(down_conv_fwd_kernel<true>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(down_conv_fwd_kernel<false>, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, a);
-    return check_launch("dmh_down_conv_fwd");
+    return check_launch("dmh_down_conv_fwd_act");
 }
 
 int dmh_down_conv_bwd_data(const float* g3, const float* gd, const float* w3t, const float* wdt, int B, int Cin, int Cout,

@@ -58,17 +58,21 @@ class BasicBlock(nn.Module):
         self.bn2 = nn.BatchNorm2d(planes)
         self.downsample = downsample
 
+    def _is_down_pair(self):
+        """The block opens a resolution level with the standard pair: conv1 3x3 stride 2 + a 1x1 stride-2 shortcut."""
+        d = self.downsample
+        if d is None:
+            return False
+        c1, cd = self.conv1, d[0]
+        return (c1.kernel_size == (3, 3) and c1.stride == (2, 2) and c1.padding == (1, 1) and c1.dilation == (1, 1)
+                and c1.groups == 1 and c1.bias is None and cd.kernel_size == (1, 1) and cd.stride == (2, 2)
+                and cd.padding == (0, 0) and cd.groups == 1 and cd.bias is None)
+
     def _down_pair(self, x):
         """(conv1(x), downsample[0](x)) as one K15 launch where the block opens a resolution level (3x3 stride 2 + 1x1
         stride 2 on the same input: layer2.0 / layer3.0 / layer4.0); None for every other block."""
-        d = self.downsample
-        if d is None:
-            return None
-        c1, cd = self.conv1, d[0]
-        if (c1.stride == (2, 2) and c1.padding == (1, 1) and c1.dilation == (1, 1) and c1.groups == 1 and c1.bias is None
-                and cd.kernel_size == (1, 1) and cd.stride == (2, 2) and cd.padding == (0, 0) and cd.groups == 1
-                and cd.bias is None and ops.down_convs_ok(x, c1.weight, cd.weight)):
-            return ops.down_convs(x, c1.weight, cd.weight)
+        if self._is_down_pair() and ops.down_convs_ok(x, self.conv1.weight, self.downsample[0].weight):
+            return ops.down_convs(x, self.conv1.weight, self.downsample[0].weight)
         return None
 
     def forward(self, x):
@@ -91,6 +95,11 @@ class BasicBlock(nn.Module):
                 and ops.basic_block_eval_ok(x, self.conv1.weight, self.conv2.weight)):
             # inside an attack: the whole block as one autograd node (masks and the identity add in K10's epilogues)
             return ops.basic_block_eval(x, self.conv1.weight, *aff[self.bn1], self.conv2.weight, *aff[self.bn2])
+        if (self._is_down_pair() and _plain3x3(self.conv2)
+                and ops.down_block_eval_ok(x, self.conv1.weight, self.downsample[0].weight, self.conv2.weight)):
+            # inside an attack: the whole down-sampling block as one node (BatchNorms and ReLU in the K15 / K10 epilogues)
+            return ops.down_block_eval(x, self.conv1.weight, *aff[self.bn1], self.downsample[0].weight,
+                                       *aff[self.downsample[1]], self.conv2.weight, *aff[self.bn2])
         pair = self._down_pair(x)
         if pair is not None:
             idt = ops.bn_act(pair[1], *aff[self.downsample[1]], relu=False)

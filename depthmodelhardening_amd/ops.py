@@ -1246,6 +1246,85 @@ def basic_block_eval(x, w1, scale1, shift1, w2, scale2, shift2):
                                  _c(scale2.detach()), _c(shift2.detach()))
 
 
+class _DownBlockEval(torch.autograd.Function):
+    """A down-sampling torchvision BasicBlock in eval() with constant parameters (inside an attack), as one autograd node:
+        out1 = relu(bn1(conv1_s2(x)));  idt = bn_d(conv1x1_s2(x));  y = relu(bn2(conv2(out1)) + idt)
+    forward = ONE K15 launch (both BatchNorm scales folded into the filters, shifts and the ReLU in its epilogue) + one K10
+    launch; backward = one K9 pass (mask by y), one K10 launch (conv2's backward-data masked by [out1 > 0] in the
+    epilogue) and one K15 launch on the transposed, scaled filters -- no separate BatchNorm / ReLU passes."""
+
+    @staticmethod
+    def forward(ctx, x, w3, s1, b1, wd, sd, bd, w2, s2, b2):
+        lib = N.lib()
+        B, Cin, H, W = x.shape
+        Co = w3.shape[0]
+        w3s = frozen_memo(("down_w3s", w3.data_ptr(), w3._version, s1.data_ptr()), lambda: _c(w3 * s1.view(-1, 1, 1, 1)))
+        wds = frozen_memo(("down_wds", wd.data_ptr(), wd._version, sd.data_ptr()), lambda: _c(wd * sd.view(-1, 1, 1, 1)))
+        out1 = torch.empty((B, Co, H // 2, W // 2), device=x.device, dtype=torch.float32)
+        idt, y = torch.empty_like(out1), torch.empty_like(out1)
+        N.check(_timed("down_conv_fwd", lambda: lib.dmh_down_conv_fwd_act(
+            N.ptr(x), N.ptr(w3s), N.ptr(wds), N.ptr(b1), N.ptr(bd), 1, B, Cin, Co, H, W, N.ptr(out1), N.ptr(idt), N.stream()),
+            4 * (x.numel() + 2 * out1.numel() + w3.numel() + wd.numel()), 20 * Cin * out1.numel()))
+        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+            N.ptr(out1), N.ptr(_wino_filter(w2, False, s2)), N.ptr(b2), N.ptr(idt), 1, B, Co, Co, H // 2, W // 2, 1, N.ptr(y),
+            N.stream()), 4 * 3 * out1.numel(), 18 * Co * out1.numel()))
+        ctx.save_for_backward(out1, y, w3, s1, wd, sd, w2, s2)
+        ctx.in_shape = (B, Cin, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        out1, y, w3, s1, wd, sd, w2, s2 = ctx.saved_tensors
+        lib = N.lib()
+        B, Cin, H, W = ctx.in_shape
+        Co = w3.shape[0]
+        g = _c(g)
+        ones = frozen_memo(("ones", Co, g.device), lambda: torch.ones(Co, device=g.device, dtype=torch.float32))
+        g2 = torch.empty_like(g)            # g * [y > 0]: gradient of bn2's output and of the shortcut's BatchNorm output
+        N.check(_timed("bn_act_bwd", lambda: lib.dmh_bn_act_bwd(N.ptr(y), N.ptr(g), N.ptr(ones), B, Co, (H // 2) * (W // 2), 1,
+                                                               N.ptr(g2), None, N.stream()), 12 * g.numel()))
+        g1 = torch.empty_like(g)            # gradient of bn1's output: conv2's backward-data masked by [out1 > 0]
+        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+            N.ptr(g2), N.ptr(_wino_filter(w2, True, s2)), None, N.ptr(out1), 2, B, Co, Co, H // 2, W // 2, 1, N.ptr(g1),
+            N.stream()), 4 * 3 * g.numel(), 18 * Co * g.numel()))
+        w3ts = frozen_memo(("down_w3ts", w3.data_ptr(), w3._version, s1.data_ptr()),
+                           lambda: _c((w3 * s1.view(-1, 1, 1, 1)).transpose(0, 1)))
+        wdts = frozen_memo(("down_wdts", wd.data_ptr(), wd._version, sd.data_ptr()),
+                           lambda: _c((wd * sd.view(-1, 1, 1, 1)).reshape(Co, Cin).t()))
+        g_x = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32)
+        N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data(
+            N.ptr(g1), N.ptr(g2), N.ptr(w3ts), N.ptr(wdts), B, Cin, Co, H, W, N.ptr(g_x), N.stream()),
+            4 * (g_x.numel() + 2 * g.numel()), 20 * Cin * g.numel()))
+        return (g_x,) + (None,) * 9
+
+
+DOWN_NODE_ENABLED = os.environ.get("DMH_DOWN_NODE", "1") != "0"     # timing comparisons
+
+
+def down_block_eval_ok(x, w3, wd, w2):
+    """Inside frozen_weights(), K15 shapes, and the block's second convolution on the K10 epilogue kernel."""
+    if not (_wino_frozen > 0 and DOWN_NODE_ENABLED and down_convs_ok(x, w3, wd)):
+        return False
+    Co = w3.shape[0]
+    return tuple(w2.shape) == (Co, Co, 3, 3) and _wino_ok(x.shape[0], Co, Co, x.shape[2] // 2, x.shape[3] // 2, allow_split=False)
+
+
+def down_block_eval(x, w3, scale1, shift1, wd, scale_d, shift_d, w2, scale2, shift2):
+    """relu(bn2(conv2(relu(bn1(conv1_s2(x))))) + bn_d(conv1x1_s2(x))) with the BatchNorms given as (scale, shift): a
+    down-sampling BasicBlock of the encoder during an attack, as one autograd node (see _DownBlockEval)."""
+    if not down_block_eval_ok(x, w3, wd, w2):
+        raise RuntimeError("down_block_eval: needs ops.frozen_weights() and shapes K15 / K10 take (ops.down_block_eval_ok)")
+    for sc, sh in ((scale1, shift1), (scale_d, shift_d), (scale2, shift2)):
+        _reject_affine_grad("down_block_eval", sc, sh)
+    d = lambda t: _c(t.detach())        # noqa: E731
+    if not x.requires_grad:
+        with torch.no_grad():
+            return _DownBlockEval.apply(_c(x), w3.detach(), d(scale1), d(shift1), wd.detach(), d(scale_d), d(shift_d),
+                                        w2.detach(), d(scale2), d(shift2))
+    return _DownBlockEval.apply(_c(x), w3.detach(), d(scale1), d(shift1), wd.detach(), d(scale_d), d(shift_d), w2.detach(),
+                                d(scale2), d(shift2))
+
+
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,
                         clamp_hi=80.0):
     """The eight attack-evaluation metrics of MD2/evaluate_depth.py:57-99 computed from two disparity maps in one

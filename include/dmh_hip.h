@@ -368,6 +368,10 @@ int dmh_stem_conv_norm_fwd(const float* x, const float* w, int B, int H, int W, 
  * ---------------------------------------------------------------------------------- */
 int dmh_down_conv_fwd(const float* x, const float* w3, const float* wd, int B, int Cin, int Cout, int H, int W,
                       float* y3, float* yd, void* stream);
+/* the same with eval-mode BatchNorms folded in (scales already in the filters): y3 = act(corr3x3_s2(x, w3) + shift3[k]),
+ * act = ReLU when relu3 != 0; yd = corr1x1_s2(x, wd) + shiftd[k]; shift3 / shiftd may be NULL. */
+int dmh_down_conv_fwd_act(const float* x, const float* w3, const float* wd, const float* shift3, const float* shiftd,
+                          int relu3, int B, int Cin, int Cout, int H, int W, float* y3, float* yd, void* stream);
 int dmh_down_conv_bwd_data(const float* g3, const float* gd, const float* w3t, const float* wdt, int B, int Cin, int Cout,
                            int H, int W, float* g_x, void* stream);
 
