@@ -14,6 +14,8 @@
 // channel by channel, 14 rows per batch of loads (3 coalesced loads + 9 FMAs per row); nine wave sums per channel go to a
 // per-strip partial, and head_wrw_reduce_kernel adds the partials in a fixed order (deterministic, no atomics).
 // Small maps split their channels over several waves per strip.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 using namespace dmh;
@@ -86,9 +88,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void he
     }
 }
 
-// ---------------------------------------------------------------------------------------------- weight gradient
-constexpr int WRB = 40;                 // rows per strip (gradient values kept in registers)
-
+// ---------------------------------------------------------------------------------------------- forward, strips
+// pad 0 (the heads run on the reflection-padded decoder features), C a multiple of 4.  The LDS-tile kernel above reaches
+// 1.2 TB/s (its staging loop is index arithmetic and a barrier per 16 channels); a head is a 254 MB streaming read.  Here a
+// wave owns 62 output columns x FR rows and a quarter of the channels: per channel it walks the strip's FR + 2 input rows
+// with ONE coalesced buffer load per row (row offset in an SGPR), takes the two right-hand neighbours by DPP lane shifts
+// and does 9 FMAs against taps held in registers into FR row accumulators; the four waves of a workgroup (channel
+// quarters) are added through LDS in a fixed order and the bias (and optionally the sigmoid of the disparity head) is
+// applied on the way out.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     const unsigned long long v = (unsigned long long)p;
@@ -98,6 +105,79 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
 __device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned s_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, s_off, 0));
 }
+// wave_shl:1 (GFX9 DPP): lane i reads lane i + 1, lane 63 reads 0
+__device__ __forceinline__ float lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+constexpr int FR = 40;                  // output rows per strip
+constexpr int FCOLS = 62;               // output columns per strip: lanes 62, 63 only feed their left neighbours
+constexpr int FBATCH = 14;              // input rows per batch of loads ((FR + 2) % FBATCH == 0)
+static_assert((FR + 2) % FBATCH == 0 && FR % 4 == 0, "strip geometry");
+
+struct HFArgs {
+    const float *x, *w, *bias;
+    float* y;
+    int B, C, H, W, Ho, Wo, sx, sy, sigmoid;
+};
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void head_fwd_strip_kernel(const HFArgs a) {
+    __shared__ float red[NT / 64][FR][64];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    int s = blockIdx.x;
+    const int xs = s % a.sx;
+    s /= a.sx;
+    const int ys = s % a.sy, b = s / a.sy;
+    const int ox0 = xs * FCOLS, oy0 = ys * FR;
+    const unsigned xo = (unsigned)min(ox0 + lane, a.W - 1) * 4u;
+    const rsrc_t rx = make_rsrc(a.x + (size_t)b * a.C * a.H * a.W, (unsigned)a.C * (unsigned)(a.H * a.W) * 4u);
+    float acc[FR];
+#pragma unroll
+    for (int r = 0; r < FR; ++r) acc[r] = 0.f;
+    const int cpg = a.C >> 2;
+    for (int c = wv * cpg; c < (wv + 1) * cpg; ++c) {
+        float wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = a.w[c * 9 + t];         // wave-uniform
+#pragma unroll
+        for (int i0 = 0; i0 < FR + 2; i0 += FBATCH) {
+            float rows[FBATCH];
+#pragma unroll
+            for (int j = 0; j < FBATCH; ++j) {
+                const unsigned so = (unsigned)((c * a.H + min(oy0 + i0 + j, a.H - 1)) * a.W) * 4u;
+                rows[j] = ldb(rx, xo, so);
+            }
+#pragma unroll
+            for (int j = 0; j < FBATCH; ++j) {
+                const float x0 = rows[j], x1 = lane_next(x0), x2 = lane_next(x1);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int r = i0 + j - ky;
+                    if (r >= 0 && r < FR)
+                        acc[r] = fmaf(wt[ky * 3 + 2], x2, fmaf(wt[ky * 3 + 1], x1, fmaf(wt[ky * 3], x0, acc[r])));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < FR; ++r) red[wv][r][lane] = acc[r];
+    __syncthreads();
+    const float bs = a.bias ? a.bias[0] : 0.f;
+    const int ox = ox0 + lane;
+#pragma unroll
+    for (int k = 0; k < FR / 4; ++k) {
+        const int r = wv * (FR / 4) + k, oy = oy0 + r;
+        float v = ((red[0][r][lane] + red[1][r][lane]) + (red[2][r][lane] + red[3][r][lane])) + bs;
+        if (a.sigmoid) v = 1.f / (1.f + __expf(-v));
+        if (lane < FCOLS && ox < a.Wo && oy < a.Ho) a.y[((size_t)b * a.Ho + oy) * a.Wo + ox] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- weight gradient
+constexpr int WRB = 40;                 // rows per strip (gradient values kept in registers)
+
 
 struct HWArgs {
     const float *x, *g;
@@ -203,6 +283,12 @@ __global__ __launch_bounds__(NT) void head_wrw_reduce_kernel(const float* __rest
     }
 }
 
+// DMH_HEAD_TILE=1 keeps the LDS-tile forward kernel (timing comparisons)
+inline bool force_tile_kernel() {
+    static const bool f = [] { const char* e = getenv("DMH_HEAD_TILE"); return e && e[0] == '1'; }();
+    return f;
+}
+
 struct WrwGeo { int sx, sy, cg; long long strips; };
 inline WrwGeo wrw_geo(int B, int C, int Ho, int Wo) {
     WrwGeo g;
@@ -260,11 +346,32 @@ int dmh_conv3x3_head_wrw(const float* x, const float* g, int B, int C, int H, in
 int dmh_conv3x3_head(const float* x, const float* w, const float* bias, int B, int C, int H, int W, int pad, float* y,
                      void* stream) {
     DMH_REQUIRE(x && w && y, "null pointer");
-    DMH_REQUIRE(B > 0 && C > 0 && C % KC == 0, "input channels must be a multiple of 16");
     DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
+    DMH_REQUIRE(B > 0 && C > 0 && (C % KC == 0 || (pad == 0 && C % 4 == 0 && !force_tile_kernel())),
+                "input channels must be a multiple of 16 (pad 0: of 4)");
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     DMH_REQUIRE(Ho >= 1 && Wo >= 1, "image smaller than the filter");
     DMH_REQUIRE((int64_t)C * H * W < ((int64_t)1 << 31), "image too large");
+    if (pad == 0 && (int64_t)C * H * W < ((int64_t)1 << 29) && !force_tile_kernel()) {     // the strip kernel
+        HFArgs a;
+        a.x = x;
+        a.w = w;
+        a.bias = bias;
+        a.y = y;
+        a.B = B;
+        a.C = C;
+        a.H = H;
+        a.W = W;
+        a.Ho = Ho;
+        a.Wo = Wo;
+        a.sx = (Wo + FCOLS - 1) / FCOLS;
+        a.sy = (Ho + FR - 1) / FR;
+        a.sigmoid = 0;
+        const long long strips = (long long)B * a.sx * a.sy;
+        DMH_REQUIRE(strips < (1ll << 31), "grid too large");
+        hipLaunchKernelGGL(head_fwd_strip_kernel, dim3((unsigned)strips), dim3(NT), 0, (hipStream_t)stream, a);
+        return check_launch("dmh_conv3x3_head");
+    }
     const int gx = (Wo + TW - 1) / TW, gy = (Ho + TH - 1) / TH;
     const long long blocks = (long long)B * gx * gy;
     DMH_REQUIRE(blocks < (1ll << 31), "grid too large");

@@ -883,8 +883,8 @@ class _Conv3x3(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         if _wino_ok(B, Cc, K, H + 2 * pad - 2, W + 2 * pad - 2):
             return _wino_conv(x, _wino_filter(weight, False), None if bias is None else _c(bias.detach()), K, pad)
-        if (WINO_ENABLED and K == 1 and Cc % 16 == 0 and Cc >= 32      # disparity head: K13 (16 channels: K11 is level)
-                and B * -(-(H + 2 * pad - 2) // 8) * -(-(W + 2 * pad - 2) // 64) >= 512):
+        if WINO_ENABLED and K == 1 and ((pad == 0 and Cc % 4 == 0) or (      # disparity head: K13 (strip kernel at pad 0)
+                Cc % 16 == 0 and Cc >= 32 and B * -(-(H + 2 * pad - 2) // 8) * -(-(W + 2 * pad - 2) // 64) >= 512)):
             lib = N.lib()
             y = torch.empty((B, 1, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
             N.check(_timed("conv3x3_head", lambda: lib.dmh_conv3x3_head(

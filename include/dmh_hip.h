@@ -326,7 +326,8 @@ int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int C
 /* ------------------------------------------------------------------------------------
  * K13 disparity head: 3x3 stride-1 convolution to ONE output channel (MD2/networks/depth_decoder.py:43-44 dispconv),
  *     forward: y[B,1,H+2pad-2,W+2pad-2] = corr3x3(zero_pad(x[B,C,H,W], pad), w[1][C][3][3]) + bias[0].
- *     Vector FMAs on an LDS tile, filter through scalar loads; C a multiple of 16.
+ *     pad 0 (the heads on the reflection-padded features): strips of 62 columns x 40 rows per wave, one load per input
+ *     row, neighbours by DPP, C a multiple of 4; otherwise vector FMAs on an LDS tile, C a multiple of 16.
  * ---------------------------------------------------------------------------------- */
 int dmh_conv3x3_head(const float* x, const float* w, const float* bias, int B, int C, int H, int W, int pad, float* y,
                      void* stream);

@@ -451,7 +451,8 @@ def test_conv3x3_bn_act_fused_matches_unfused(use_res):
     torch.testing.assert_close(gw, gw_ref, rtol=1e-4, atol=1e-5 * float(gw_ref.abs().max()))
 
 
-@pytest.mark.parametrize("shape", [(2, 16, 20, 130, 0), (1, 32, 9, 64, 1), (2, 64, 12, 33, 0), (1, 128, 6, 70, 2)])
+@pytest.mark.parametrize("shape", [(2, 16, 20, 130, 0), (1, 32, 9, 64, 1), (2, 64, 12, 33, 0), (1, 128, 6, 70, 2),
+                                   (3, 32, 85, 190, 0), (1, 4, 41, 62, 0), (2, 128, 40, 128, 0)])
 def test_head_conv3x3_kernel_vs_aten(shape):
     """K13 (3x3 convolution to one output channel, the disparity heads) == ATen conv2d; ops.conv3x3 routes K = 1 to it."""
     import torch.nn.functional as F
@@ -472,7 +473,7 @@ def test_head_conv3x3_kernel_vs_aten(shape):
     wt = torch.rand(ref.shape, device="cuda", generator=g)
     for a_, b_ in zip(torch.autograd.grad((got * wt).sum(), [x, w, b]), torch.autograd.grad((ref * wt).sum(), [x, w, b])):
         torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-5 * float(b_.abs().max()))
-    assert lib.dmh_conv3x3_head(N.ptr(x.detach()), N.ptr(w.detach()), None, B, 24, H, W, pad, N.ptr(y), N.stream()) != 0
+    assert lib.dmh_conv3x3_head(N.ptr(x.detach()), N.ptr(w.detach()), None, B, 22, H, W, pad, N.ptr(y), N.stream()) != 0
 
 
 def test_train_mode_fused_batchnorm_matches_modules():
