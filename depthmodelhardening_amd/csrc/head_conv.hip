@@ -175,6 +175,68 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4))) void he
     }
 }
 
+// ---------------------------------------------------------------------------------------------- backward-data, strips
+// g_x[b][c][iy][ix] = sum_{ky,kx} w[c][ky][kx] * g[b][iy - ky][ix - kx]   (pad 0: g_x is (Ho + 2) x (Wo + 2)), a pure
+// streaming write of C planes from one gradient plane.  A wave owns 62 columns x BR rows of g_x and a quarter of the
+// channels: the BR + 2 gradient rows of the strip and their two lane-shifted copies stay in registers, every channel is
+// 9 FMAs and one coalesced store per row.
+constexpr int BR = 20;
+
+struct HBArgs {
+    const float *g, *w;
+    float* gx;
+    int B, C, H, W, Ho, Wo, sx, sy, nsplit, nwaves;     // nsplit: waves that share a strip (channel split), 1 or 4
+};
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void head_bwd_strip_kernel(const HBArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int gw = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (NT / 64) + (threadIdx.x >> 6)));
+    if (gw >= a.nwaves) return;
+    const int wv = gw % a.nsplit;
+    int s = gw / a.nsplit;
+    const int xs = s % a.sx;
+    s /= a.sx;
+    const int ys = s % a.sy, b = s / a.sy;
+    const int ix0 = xs * FCOLS, iy0 = ys * BR;
+    // lane L holds gradient column ix0 - 2 + L; output column ix0 + L uses lanes L + 2, L + 1, L for kx = 0, 1, 2
+    const int gc = ix0 - 2 + lane;
+    const bool cok = gc >= 0 && gc < a.Wo;
+    const float* gb = a.g + (size_t)b * a.Ho * a.Wo + min(max(gc, 0), a.Wo - 1);
+    float g0[BR + 2], g1[BR + 2], g2[BR + 2];     // rows iy0 - 2 .. iy0 + BR - 1 of g; shifted by 0 / 1 / 2 lanes
+#pragma unroll
+    for (int j = 0; j < BR + 2; ++j) {
+        const int gr = iy0 - 2 + j;
+        const float v = gb[(size_t)min(max(gr, 0), a.Ho - 1) * a.Wo];
+        g0[j] = (cok && gr >= 0 && gr < a.Ho) ? v : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < BR + 2; ++j) {
+        g1[j] = lane_next(g0[j]);
+        g2[j] = lane_next(g1[j]);
+    }
+    const int ix = ix0 + lane;
+    const bool st = lane < FCOLS && ix < a.W;
+    const int cpg = a.C / a.nsplit;
+    const size_t HW = (size_t)a.H * a.W;
+    for (int c = wv * cpg; c < (wv + 1) * cpg; ++c) {
+        float wt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[t] = a.w[c * 9 + t];         // wave-uniform
+        float* out = a.gx + ((size_t)b * a.C + c) * HW + ix;
+#pragma unroll
+        for (int r = 0; r < BR; ++r) {
+            // output row iy0 + r: gradient rows iy0 + r - ky = register j = r + 2 - ky
+            float v = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int j = r + 2 - ky;
+                v = fmaf(wt[ky * 3 + 2], g0[j], fmaf(wt[ky * 3 + 1], g1[j], fmaf(wt[ky * 3], g2[j], v)));
+            }
+            if (st && iy0 + r < a.H) out[(size_t)(iy0 + r) * a.W] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- weight gradient
 constexpr int WRB = 40;                 // rows per strip (gradient values kept in registers)
 
@@ -303,6 +365,31 @@ inline WrwGeo wrw_geo(int B, int C, int Ho, int Wo) {
 }  // namespace
 
 extern "C" {
+
+int dmh_conv3x3_head_bwd_data(const float* g, const float* w, int B, int C, int H, int W, float* g_x, void* stream) {
+    DMH_REQUIRE(g && w && g_x, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && H >= 3 && W >= 3, "C must be a multiple of 4, the input at least 3 x 3");
+    DMH_REQUIRE((int64_t)B * C * H * W < ((int64_t)1 << 40), "tensor too large");
+    HBArgs a;
+    a.g = g;
+    a.w = w;
+    a.gx = g_x;
+    a.B = B;
+    a.C = C;
+    a.H = H;
+    a.W = W;
+    a.Ho = H - 2;
+    a.Wo = W - 2;
+    a.sx = (W + FCOLS - 1) / FCOLS;
+    a.sy = (H + BR - 1) / BR;
+    const long long strips = (long long)B * a.sx * a.sy;
+    a.nsplit = strips >= 2048 ? 1 : 4;          // few strips: split the channels over four waves to fill the chip
+    DMH_REQUIRE(strips * a.nsplit < (1ll << 31), "grid too large");
+    a.nwaves = (int)(strips * a.nsplit);
+    hipLaunchKernelGGL(head_bwd_strip_kernel, dim3((unsigned)((a.nwaves + NT / 64 - 1) / (NT / 64))), dim3(NT), 0,
+                       (hipStream_t)stream, a);
+    return check_launch("dmh_conv3x3_head_bwd_data");
+}
 
 int64_t dmh_conv3x3_head_wrw_partials_size(int B, int C, int H, int W, int pad) {
     if (B <= 0 || C <= 0 || pad < 0 || pad > 2 || H + 2 * pad - 2 < 1 || W + 2 * pad - 2 < 1) return 0;

@@ -910,6 +910,12 @@ class _Conv3x3(torch.autograd.Function):
             # backward-data = the same convolution on g with the flipped/transposed filter and pad' = 2 - pad
             g_x = _wino_conv(g, _wino_filter(weight, True), None, Cc, 2 - pad)
             need_x = False
+        elif need_x and K == 1 and pad == 0 and Cc % 4 == 0 and Cc <= 64 and H >= 3 and W >= 3 and WINO_ENABLED:
+            lib = N.lib()           # disparity head: one gradient plane in registers, C planes streamed out
+            g_x = torch.empty_like(x)
+            N.check(_timed("conv3x3_head_bwd", lambda: lib.dmh_conv3x3_head_bwd_data(
+                N.ptr(g), N.ptr(_c(weight.detach())), B, Cc, H, W, N.ptr(g_x), N.stream()), 4 * (g_x.numel() + g.numel())))
+            need_x = False
         elif need_x and _small_ok(K, Cc):
             g_x = _small_conv(g, weight, None, 2 - pad, True)
             need_x = False

@@ -331,6 +331,9 @@ int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int C
  * ---------------------------------------------------------------------------------- */
 int dmh_conv3x3_head(const float* x, const float* w, const float* bias, int B, int C, int H, int W, int pad, float* y,
                      void* stream);
+/* gradient w.r.t. the input of the same layer at pad 0: g_x[B,C,H,W] from g[B,1,H-2,W-2] (full correlation with the
+ * flipped filter); C a multiple of 4.  One gradient plane in registers, C planes streamed out. */
+int dmh_conv3x3_head_bwd_data(const float* g, const float* w, int B, int C, int H, int W, float* g_x, void* stream);
 /* weight and bias gradient of the same layer (train pass): g_w[1][C][3][3] = sum_{b,y,x} g[b,0,y,x] * zero_pad(x)[b,c,y+ky,x+kx],
  * g_b[0] = sum g (g_b may be NULL).  `partials`: dmh_conv3x3_head_wrw_partials_size(...) floats of workspace (per-strip
  * sums, added in a fixed order: deterministic).  Any C. */
