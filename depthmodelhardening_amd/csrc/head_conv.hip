@@ -9,9 +9,9 @@
 //
 // Weight gradient (train pass): dW[c][ky][kx] = sum_{b,y,x} g[b][y][x] * x[b][c][y+ky-pad][x+kx-pad] and db = sum g -- a
 // reduction over 10 M pixels per channel that MIOpen runs as a 1-output-channel implicit GEMM at 2 TFLOP/s (1.65 ms for
-// 16 -> 1 at 320x1024, batch 32; the four heads 3.0 ms per step).  head_wrw_kernel: a wave owns a strip of 64 columns
+// 16 -> 1 at 320x1024, batch 32; the four heads 3.0 ms per step).  head_wrw_kernel: a wave owns a strip of 62 columns
 // x 40 rows of one image with the strip's 40 output gradients in registers and walks the 42 input rows of the strip,
-// channel by channel, 14 rows per batch of loads (3 coalesced loads + 9 FMAs per row); nine wave sums per channel go to a
+// channel by channel, 14 rows per batch of loads (1 coalesced load, 2 DPP lane shifts and 9 FMAs per row); nine wave sums per channel go to a
 // per-strip partial, and head_wrw_reduce_kernel adds the partials in a fixed order (deterministic, no atomics).
 // Small maps split their channels over several waves per strip.
 #include <stdlib.h>
@@ -108,6 +108,26 @@ __device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned s_of
 // wave_shl:1 (GFX9 DPP): lane i reads lane i + 1, lane 63 reads 0
 __device__ __forceinline__ float lane_next(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
+// Sum over the 64 lanes in 11 instructions (wave_sum's six __shfl_down steps are LDS-crossbar permutes of ~100 cycles
+// each: nine sums per channel cost more than the channel's arithmetic): quad_perm / row_half_mirror / row_mirror DPP adds
+// leave every lane of a 16-lane row with the row's total; four readlanes add the rows.  Fixed order; uniform result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_perm(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_perm<0xB1>(v);         // quad_perm [1,0,3,2]
+    v += dpp_perm<0x4E>(v);         // quad_perm [2,3,0,1]
+    v += dpp_perm<0x141>(v);        // row_half_mirror
+    v += dpp_perm<0x140>(v);        // row_mirror
+    const int iv = __builtin_bit_cast(int, v);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 constexpr int FR = 40;                  // output rows per strip
@@ -256,8 +276,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void he
     if (wid >= a.B * a.sy * a.sx * a.cg) return;
     const int cgi = wid % a.cg, s = wid / a.cg;
     const int xs = s % a.sx, q = s / a.sx, ys = q % a.sy, b = q / a.sy;
-    const int ox = xs * 64 + lane, oy0 = ys * WRB;
-    const bool colok = ox < a.Wo;
+    const int ox = xs * FCOLS + lane, oy0 = ys * WRB;          // 62 output columns per strip: lanes 62, 63 only feed
+    const bool colok = lane < FCOLS && ox < a.Wo;              // their left neighbours' taps
     float gr[WRB];
     float sb = 0.f;
 #pragma unroll
@@ -269,17 +289,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void he
     const int stride = a.C * 9 + 1;
     float* pp = a.part + (size_t)s * stride;
     if (cgi == 0) {
-        sb = wave_sum(sb);
+        sb = wave_sum_dpp(sb);
         if (lane == 0) pp[a.C * 9] = sb;
     }
-    unsigned xo[3];
-    float xm[3];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-        const int ix = ox - a.pad + kx;
-        xm[kx] = (ix >= 0 && ix < a.W) ? 1.f : 0.f;
-        xo[kx] = (unsigned)min(max(ix, 0), a.W - 1) * 4u;
-    }
+    // lane L holds input column ox - pad of every row; the taps kx = 1, 2 are the next two lanes' values (DPP)
+    const int ixl = ox - a.pad;
+    const float xm = (ixl >= 0 && ixl < a.W) ? 1.f : 0.f;
+    const unsigned xo = (unsigned)min(max(ixl, 0), a.W - 1) * 4u;
     const rsrc_t rx = make_rsrc(a.x + (size_t)b * a.C * a.H * a.W, (unsigned)a.C * (unsigned)(a.H * a.W) * 4u);
     for (int c = cgi * a.cpg; c < (cgi + 1) * a.cpg; ++c) {
         float acc[9];
@@ -291,7 +307,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void he
         static_assert((WRB + 2) % RBATCH == 0, "row batches");
 #pragma unroll
         for (int i0 = 0; i0 < WRB + 2; i0 += RBATCH) {
-            float rows[RBATCH][3];
+            float rows[RBATCH];
 #pragma unroll
             for (int j = 0; j < RBATCH; ++j) {
                 const int iy = oy0 - a.pad + i0 + j;
@@ -301,29 +317,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void he
                 // buffer loads: the row offset is wave-uniform (SGPR), the lane part three fixed registers -- with plain
                 // pointers the compiler hoists 126 per-lane addresses out of the channel loop and spills them
                 const unsigned so = (unsigned)((c * a.H + min(max(iy, 0), a.H - 1)) * a.W) * 4u;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float t = ldb(rx, xo[kx], so);
-                    // (t * xm) * ym, not t * (xm * ym): the latter is invariant in c and would be hoisted into 126 registers
-                    rows[j][kx] = PADDED ? (t * xm[kx]) * ym : t;
-                }
+                const float t = ldb(rx, xo, so);
+                // (t * xm) * ym, not t * (xm * ym): the latter is invariant in c and would be hoisted into 42 registers
+                rows[j] = PADDED ? (t * xm) * ym : t;
             }
 #pragma unroll
-            for (int j = 0; j < RBATCH; ++j)
+            for (int j = 0; j < RBATCH; ++j) {
+                const float x0 = rows[j], x1 = lane_next(x0), x2 = lane_next(x1);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int r = i0 + j - ky;
                     if (r >= 0 && r < WRB) {
-#pragma unroll
-                        for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = fmaf(gr[r], rows[j][kx], acc[ky * 3 + kx]);
+                        acc[ky * 3] = fmaf(gr[r], x0, acc[ky * 3]);
+                        acc[ky * 3 + 1] = fmaf(gr[r], x1, acc[ky * 3 + 1]);
+                        acc[ky * 3 + 2] = fmaf(gr[r], x2, acc[ky * 3 + 2]);
                     }
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);      // keep the next batch's loads behind this batch's arithmetic: hoisting
                                                     // all 126 loads of a channel costs 512 registers (one wave per SIMD)
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const float v = wave_sum(acc[t]);
+            const float v = wave_sum_dpp(acc[t]);
             if (lane == 0) pp[c * 9 + t] = v;
         }
     }
@@ -354,7 +370,7 @@ inline bool force_tile_kernel() {
 struct WrwGeo { int sx, sy, cg; long long strips; };
 inline WrwGeo wrw_geo(int B, int C, int Ho, int Wo) {
     WrwGeo g;
-    g.sx = (Wo + 63) / 64;
+    g.sx = (Wo + FCOLS - 1) / FCOLS;
     g.sy = (Ho + WRB - 1) / WRB;
     g.strips = (long long)B * g.sx * g.sy;
     g.cg = 1;
