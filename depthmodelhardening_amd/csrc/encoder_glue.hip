@@ -171,6 +171,60 @@ __global__ __launch_bounds__(NT) void stem_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// The same with two horizontally adjacent quads per thread (W a multiple of 4): 16-byte accesses to feat / g_feat / g_x,
+// six argmax bytes instead of eight.
+__global__ __launch_bounds__(NT) void stem_bwd4_kernel(const float* __restrict__ feat, const unsigned char* __restrict__ argmax,
+                                                       const float* __restrict__ g_feat, const float* __restrict__ g_pool,
+                                                       const float* __restrict__ scale, int C, int H, int W,
+                                                       float* __restrict__ g_x) {
+    const int PH = H >> 1, PW = W >> 1, PW2 = PW >> 1;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if (t >= PH * PW2) return;
+    const int plane = blockIdx.y, c = plane % C;
+    const int i = t / PW2, j = (t - i * PW2) * 2;            // quads (i, j) and (i, j + 1)
+    const size_t base = (size_t)plane * H * W, pbase = (size_t)plane * PH * PW;
+    float acc[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // rows 2i, 2i+1; columns 2j .. 2j+3
+    if (g_pool) {
+#pragma unroll
+        for (int di = 0; di < 2; ++di) {
+            const int oi = i + di;
+            if (oi >= PH) continue;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {                 // pooling windows j, j + 1, j + 2 touch the four columns
+                const int oj = j + dj;
+                if (oj >= PW) continue;
+                const int a = argmax[pbase + (size_t)oi * PW + oj];
+                const int ky = a / 3, kx = a - ky * 3;
+                const int ry = 2 * di - 1 + ky, rx = 2 * dj - 1 + kx;   // position relative to the thread's 2 x 4 block
+                if (ry >= 0 && ry < 2 && rx >= 0 && rx < 4) {
+                    const float gp = g_pool[pbase + (size_t)oi * PW + oj];
+#pragma unroll
+                    for (int r = 0; r < 2; ++r)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (ry == r && rx == q) acc[r][q] += gp;         // compile-time indices keep acc in registers
+                }
+            }
+        }
+    }
+    const float s = scale[c];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const size_t o = base + (size_t)(2 * i + r) * W + 2 * j;
+        const float4 f = *reinterpret_cast<const float4*>(feat + o);
+        float g0 = acc[r][0], g1 = acc[r][1], g2 = acc[r][2], g3 = acc[r][3];
+        if (g_feat) {
+            const float4 gf = *reinterpret_cast<const float4*>(g_feat + o);
+            g0 += gf.x;
+            g1 += gf.y;
+            g2 += gf.z;
+            g3 += gf.w;
+        }
+        *reinterpret_cast<float4*>(g_x + o) = make_float4(f.x > 0.f ? g0 * s : 0.f, f.y > 0.f ? g1 * s : 0.f,
+                                                          f.z > 0.f ? g2 * s : 0.f, f.w > 0.f ? g3 * s : 0.f);
+    }
+}
+
 // ---- train-mode BatchNorm statistics (torchvision BasicBlock / stem under model.train(), MD2/trainer.py:335-375):
 // per-channel mean and biased variance over (B, H, W) in two launches, Welford / Chan in fp32.
 //   partial : grid (S, C); block (s, c) reduces every S-th 1024-element slab of channel c -> (count, mean, M2)
@@ -358,8 +412,12 @@ int dmh_stem_bn_relu_pool_bwd(const float* feat, const unsigned char* argmax, co
     DMH_REQUIRE(feat && argmax && scale && g_x, "null pointer");
     DMH_REQUIRE(B > 0 && C > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "H and W must be even and >= 2");
     DMH_REQUIRE((int64_t)B * C <= 65535 && (int64_t)H * W < (1 << 30), "tensor too large");
-    hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks_for((int64_t)(H / 2) * (W / 2)), B * C), dim3(NT), 0,
-                       (hipStream_t)stream, feat, argmax, g_feat, g_pooled, scale, C, H, W, g_x);
+    if ((W & 3) == 0)
+        hipLaunchKernelGGL(stem_bwd4_kernel, dim3(blocks_for((int64_t)(H / 2) * (W / 4)), B * C), dim3(NT), 0,
+                           (hipStream_t)stream, feat, argmax, g_feat, g_pooled, scale, C, H, W, g_x);
+    else
+        hipLaunchKernelGGL(stem_bwd_kernel, dim3(blocks_for((int64_t)(H / 2) * (W / 2)), B * C), dim3(NT), 0,
+                           (hipStream_t)stream, feat, argmax, g_feat, g_pooled, scale, C, H, W, g_x);
     return check_launch("dmh_stem_bn_relu_pool_bwd");
 }
 

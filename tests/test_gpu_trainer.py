@@ -192,7 +192,7 @@ def test_encoder_glue_ops_vs_aten():
                 for a, bb in zip(ga_k, gb):
                     torch.testing.assert_close(a, bb, rtol=1e-5, atol=1e-6)
                 assert all(torch.isfinite(a).all() for a in ga)
-    for (B, C, H, W) in [(2, 3, 4, 6), (1, 2, 2, 2), (2, 64, 32, 48), (1, 4, 10, 2)]:
+    for (B, C, H, W) in [(2, 3, 4, 6), (1, 2, 2, 2), (2, 64, 32, 48), (1, 4, 10, 2), (1, 3, 6, 8), (2, 2, 2, 4), (1, 2, 10, 12)]:
         x = (rnd(B, C, H, W) - 0.4).requires_grad_(True)
         w, b, mu, var = rnd(C) + 0.5, rnd(C) - 0.5, rnd(C) - 0.5, rnd(C) + 0.1
         scale = w / torch.sqrt(var + 1e-5)
