@@ -70,6 +70,28 @@ __device__ __forceinline__ float fast_rcp(float x) {
     return r * (2.0f - x * r);
 }
 
+// ---- buffer-resource loads and DPP lane shifts (K1, K13, K15, K16) -----------------------------------------------
+// One 128-bit descriptor in SGPRs per tensor, 32-bit byte offsets in VGPRs, a wave-uniform offset in an SGPR: no 64-bit
+// address arithmetic per load, and offsets >= the descriptor's size read 0 instead of faulting (zero padding for free).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+
+__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned s_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, s_off, 0));
+}
+// wave_shr:1 / wave_shl:1 DPP controls (GFX9): lane i reads lane i-1 / i+1; the edge lane reads 0.  The compiler folds
+// them into the consuming v_add_f32 / v_fma_f32.
+__device__ __forceinline__ float lane_prev(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_next(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
+}
+
 // Philox4x32-R counter-based generator (Salmon et al., SC'11); 7 rounds pass BigCrush.
 template <int ROUNDS = 7>
 struct Philox {

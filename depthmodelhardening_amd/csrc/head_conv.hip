@@ -96,19 +96,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3))) void he
 // and does 9 FMAs against taps held in registers into FR row accumulators; the four waves of a workgroup (channel
 // quarters) are added through LDS in a fixed order and the bias (and optionally the sigmoid of the disparity head) is
 // applied on the way out.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned s_off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, s_off, 0));
-}
-// wave_shl:1 (GFX9 DPP): lane i reads lane i + 1, lane 63 reads 0
-__device__ __forceinline__ float lane_next(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-}
 
 // Sum over the 64 lanes in 11 instructions (wave_sum's six __shfl_down steps are LDS-crossbar permutes of ~100 cycles
 // each: nine sums per channel cost more than the channel's arithmetic): quad_perm / row_half_mirror / row_mirror DPP adds

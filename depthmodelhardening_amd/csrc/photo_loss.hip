@@ -56,34 +56,13 @@ constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 constexpr float K81C1 = 81.f * C1, K81C2 = 81.f * C2, K9S = 9.f * SHIFT;
 
 // ---------------------------------------------------------------------------------------------- cross-lane
-// wave_shr:1 / wave_shl:1 DPP controls (GFX9): lane i reads lane i-1 / i+1; the edge lane reads 0.  The compiler
-// folds them into the consuming v_add_f32 / v_fma_f32.
-__device__ __forceinline__ float lane_prev(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float lane_next(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, false));
-}
+// lane_prev / lane_next (wave_shr:1 / wave_shl:1 DPP) and the buffer-resource loads make_rsrc / ldb: common.hpp
 __device__ __forceinline__ float hsum3(float v) { return (lane_prev(v) + v) + lane_next(v); }
 
 __device__ __forceinline__ float uni(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
 }
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// ---------------------------------------------------------------------------------------------- buffer loads
-// One 128-bit descriptor in SGPRs per image, 32-bit byte offsets in VGPRs, the colour-plane offset in an SGPR:
-// no 64-bit address arithmetic per load, and out-of-range offsets read 0 instead of faulting.
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned plane_off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, plane_off, 0));
-}
 
 // ---------------------------------------------------------------------------------------------- projection
 struct CamW {  // wave-uniform constants of one (image, frame): D = A - I, translation column, m = P23 + eps

@@ -20,16 +20,6 @@ using namespace dmh;
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef __amdgpu_buffer_rsrc_t rsrc_t;
-
-__device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    const unsigned long long v = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned s_off) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, s_off, 0));
-}
 
 constexpr int NT = 256, NWV = NT / 64;
 constexpr int TW = 64;
