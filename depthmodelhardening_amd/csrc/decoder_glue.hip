@@ -189,11 +189,28 @@ __device__ __forceinline__ void put_quad(float* __restrict__ op, const float4 v,
     }
 }
 
-// gradient of interior quad (Y, X..X+3): one unaligned 16-byte load away from the folded rows / columns
+// gradient of interior quad (Y, X..X+3): the adjoint of ReflectionPad2d(1) adds padded row 0 / H+1 onto interior row
+// 1 / H-2 and padded column 0 / W+1 onto interior column 1 / W-2.  Written as at most three row reads with one extra
+// element each at the row ends -- the generic per-element fold2d loops, taken by every wave that holds a first / last
+// quad of a row, made the four-wide backward kernels run at 3.7 TB/s.
+__device__ __forceinline__ float4 row_quad(const float* __restrict__ gp, int pr, int X, int W) {
+    const float* r = gp + (size_t)pr * (W + 2);
+    float4 q = load4u(r + X + 1);
+    if (X == 0) q.y += r[0];
+    if (X + 4 == W) q.z += r[W + 1];
+    return q;
+}
 __device__ __forceinline__ float4 fold_quad(const float* __restrict__ gp, int Y, int X, int H, int W) {
-    if (Y != 1 && Y != H - 2 && X != 0 && X + 4 != W) return load4u(gp + (size_t)(Y + 1) * (W + 2) + X + 1);
-    return make_float4(fold2d(gp, Y, X, H, W), fold2d(gp, Y, X + 1, H, W), fold2d(gp, Y, X + 2, H, W),
-                       fold2d(gp, Y, X + 3, H, W));
+    float4 v = row_quad(gp, Y + 1, X, W);
+    if (Y == 1) {
+        const float4 t = row_quad(gp, 0, X, W);
+        v = make_float4(v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w);
+    }
+    if (Y == H - 2) {
+        const float4 t = row_quad(gp, H + 1, X, W);
+        v = make_float4(v.x + t.x, v.y + t.y, v.z + t.z, v.w + t.w);
+    }
+    return v;
 }
 
 // blocks [0, nA): y planes, a thread = two source elements (i, j0), (i, j0+1) -> two output rows of four;
