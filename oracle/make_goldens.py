@@ -361,8 +361,8 @@ def gold_sup_loss(trainer_mod, layers):
     """MD2/trainer.py:546-577 with --adv_train --supervised_adv --contrastive_learning --no_original_train: the add-on
     losses alone (sup_loss = MSE(gt_model(color_ben), disp_0); contras_loss = SimSiam(features_aug, features_ben))."""
     import contrastive
-    B, H, W = 2, 32, 96
-    g = torch.Generator().manual_seed(61)
+    B, H, W = 8, 32, 96      # SimSiam's BatchNorm1d needs a real batch: over a batch of 2 every feature becomes +-1 and the
+    g = torch.Generator().manual_seed(61)   # feature gradient is ill-conditioned by construction
     color_ben = kitti_like(B, 3, H, W, g)
     disp = (torch.rand(B, 1, H, W, generator=g) * 0.3 + 0.01).requires_grad_(True)
     torch.manual_seed(62)

@@ -573,15 +573,13 @@ def test_addon_losses_match_reference_golden(tmp_path, golden):
     losses["loss"].backward()
     for k in ("sup_loss", "contras_loss", "loss"):
         ref = float(g[k])
-        # contras_loss is a mean cosine in [-1, 1] that happens to be ~0.009 here (BatchNorm1d over a batch of 2 maps
-        # every feature to +-1): 5e-6 absolute is fp32 noise of the GEMM accumulation order, not 1e-4 of a ~1 quantity
-        assert abs(float(losses[k]) - ref) <= 2e-5 * abs(ref) + (5e-6 if k != "sup_loss" else 0.0), (k, float(losses[k]), ref)
+        # contras_loss is a mean cosine in [-1, 1]: 2e-5 relative + 2e-6 absolute (fp32 GEMM accumulation order)
+        assert abs(float(losses[k]) - ref) <= 2e-5 * abs(ref) + (2e-6 if k != "sup_loss" else 0.0), (k, float(losses[k]), ref)
     assert_close_frac(d.grad, torch.from_numpy(np.asarray(g["g_disp"])), rtol=1e-4, atol=1e-9, name="d sup_loss / d disp")
-    # BatchNorm1d over a batch of TWO divides by |a - b| / 2 per feature: the feature gradient amplifies the GEMMs' fp32
-    # rounding by orders of magnitude (rel-L2 ~1e-2 between rocBLAS and the CPU).  SimSiam is a plain torch module (no
-    # kernel of this repo): direction and size of the gradient are what this wiring test can hold it to.
+    # SimSiam is a plain torch module (no kernel of this repo); with a real BatchNorm1d batch (8, the fixture of round 2
+    # had 2) its feature gradient is well conditioned: 1e-3 rel-L2 between rocBLAS on the GPU and the reference's CPU run
     ga, gr = fa[0].grad.double().cpu().flatten(), torch.from_numpy(np.asarray(g["g_feat_aug"])).double().flatten()
-    assert float((ga - gr).norm() / gr.norm()) < 0.05 and float(torch.dot(ga, gr) / (ga.norm() * gr.norm())) > 0.999
+    assert float((ga - gr).norm() / gr.norm()) < 1e-3, float((ga - gr).norm() / gr.norm())
 
 
 def test_eval_mode_with_trainable_batchnorm_takes_the_module_path():

@@ -236,7 +236,7 @@ def test_simsiam(golden, which):
 def addon_case():
     """Inputs of tests/golden/addon_losses.npz, regenerated from its seeds (same draw order as oracle/make_goldens.py)."""
     from oracle.dataset_ref import SimSiamRef
-    B, H, W = 2, 32, 96
+    B, H, W = 8, 32, 96
     gen = torch.Generator().manual_seed(61)
     color_ben = kitti_like(B, 3, H, W, gen)
     disp = (torch.rand(B, 1, H, W, generator=gen) * 0.3 + 0.01).requires_grad_(True)
