@@ -30,13 +30,42 @@ sys.path.insert(0, REPO)
 MFMA_F32_PEAK_TFLOPS = 157.3   # dense fp32 MFMA peak of MI355X (MI355X_MICROARCH.md)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling is 6290
 
-# HBM bytes per launch measured with rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate passes) for the profiled
-# shape, keyed by (B, H, W); see profiles/README.md.  FETCH_SIZE is taken 1:1: these kernels read one dword per lane,
-# and the x2 correction of MI355X_MICROARCH.md section HBM is for 16-byte-per-lane streaming reads only ("other access
-# widths are uncalibrated: calibrate on a known byte count in your own access pattern") -- calibrated on
-# smooth_fwd_kernel, which reads its 222.9 MB exactly once and reports FETCH_SIZE = 198.8 MB.  The backward reports
-# fewer bytes than its algorithmic reads because the images are still in the 256 MB Infinity Cache from the forward.
-MEASURED_TRAFFIC = {(32, 320, 1024): {"photo_fwd": 328.9e6, "photo_bwd": 218.9e6, "source": "profiles/r02_k1k2_pmc.csv"}}
+BASELINE_CONFIGS = {      # BASELINE.json "configs" (index = position in that list), and the flags each one sets here
+    2: ("Monodepth2 ResNet18, 1024x320, 10-step PGD-L_inf, bs32, 1xMI355X", {}),
+    3: ("Monodepth2 --adv_train --norm_type l_0 + supervised_adv, 1024x320, bs32, 8xMI355X DDP",
+        {"norm_type": "l_0", "supervised_adv": True}),
+    4: ("DepthHints DH_MS_320_1024, 20-step PGD + contrastive_learning, bs64, 8xMI355X",
+        {"batch_size": 64, "atk_steps": 20, "loss_variant": "dh", "contrastive_learning": True}),
+    5: ("physical_adv_training.py patch-attack (physicalTrans EOT) on Monodepth2, 1024x320, bs32, 8xMI355X",
+        {"harness": "physical"}),
+}
+
+
+def measured_traffic(B, H, W):
+    """HBM bytes per launch of the K1 kernels from the newest committed rocprofv3 PMC summary (profiles/rNN_k1k2_pmc.csv:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes by tools/collect_profiles.sh, unit KiB), valid for the
+    shape that summary was taken at (profiles/rNN_k1k2_shape.json).  FETCH_SIZE is taken 1:1: these kernels read one
+    dword per lane, and the x2 correction of MI355X_MICROARCH.md section HBM is for 16-byte-per-lane streaming reads
+    only ("other access widths are uncalibrated: calibrate on a known byte count in your own access pattern") --
+    calibrated on smooth_fwd_kernel, which reads its 222.9 MB exactly once and reports FETCH_SIZE = 198.8 MB.  The
+    backward reports fewer bytes than its algorithmic reads when the images are still in the 256 MB Infinity Cache from
+    the forward."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_k1k2_pmc.csv")))
+    if not files:
+        return {}
+    f = files[-1]
+    shape_file = f.replace("_pmc.csv", "_shape.json")
+    shape = json.load(open(shape_file)) if os.path.exists(shape_file) else {"B": 32, "H": 320, "W": 1024}
+    if (shape["B"], shape["H"], shape["W"]) != (B, H, W):
+        return {}
+    out = {"source": os.path.relpath(f, REPO)}
+    for r in csv.DictReader(open(f)):
+        for key in ("photo_fwd", "photo_bwd"):
+            if key + "_kernel" in r["Kernel"]:
+                out[key] = (float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+    return out
 
 
 def k1_bytes(B, H, W, scales=4):
@@ -119,6 +148,64 @@ def cpu_baseline(height, width, atk_steps, batch, gpu_loss_ms=None):
     return out
 
 
+def unet_flops(height, width):
+    """FLOPs of ONE image through the ResNet-18 U-Net at this resolution, measured with torch.utils.flop_counter on the
+    reference module path (meta tensors: nothing is computed): forward, backward to the input only (what an attack
+    step runs: the weights are constants), and the full training backward (data + weight gradients)."""
+    import torch
+    from torch.utils.flop_counter import FlopCounterMode
+    from depthmodelhardening_amd.depth_model import import_depth_model
+    with torch.device("meta"):
+        model = import_depth_model((width, height))
+    model.eval()
+    x = torch.empty(1, 3, height, width, device="meta", requires_grad=True)
+    with FlopCounterMode(display=False) as fc:
+        y = model(x)
+    fwd = fc.get_total_flops()
+    for p in model.parameters():
+        p.requires_grad_(False)
+    y = model(x)
+    with FlopCounterMode(display=False) as fc:
+        y.sum().backward()
+    bwd_data = fc.get_total_flops()
+    for p in model.parameters():
+        p.requires_grad_(True)
+    model.train()
+    y = model(torch.empty(1, 3, height, width, device="meta"))
+    with FlopCounterMode(display=False) as fc:
+        y.sum().backward()
+    return {"fwd": fwd, "bwd_data": bwd_data, "bwd_full": fc.get_total_flops()}
+
+
+class FlopMeter(object):
+    """Counts the U-Net passes of one step by hooking every ResnetEncoder: images x (forward [+ backward to the input if
+    the weights are frozen (attack), + full backward if they train]) -> FLOPs per step with unet_flops()."""
+
+    def __init__(self, modules):
+        import torch
+        from depthmodelhardening_amd import ops
+        self.images = {"fwd_only": 0, "fwd_bwd_data": 0, "fwd_bwd_full": 0}
+        self.on = False
+
+        def hook(mod, args):
+            if not self.on:
+                return
+            x = args[0]
+            if not torch.is_grad_enabled():
+                kind = "fwd_only"
+            elif ops.weights_frozen() or not any(p.requires_grad for p in mod.parameters()):
+                kind = "fwd_bwd_data" if x.requires_grad else "fwd_only"
+            else:
+                kind = "fwd_bwd_full"
+            self.images[kind] += int(x.shape[0])
+        self.handles = [m.register_forward_pre_hook(hook) for m in modules]
+
+    def flops(self, per_image):
+        n = self.images
+        return (n["fwd_only"] * per_image["fwd"] + n["fwd_bwd_data"] * (per_image["fwd"] + per_image["bwd_data"]) +
+                n["fwd_bwd_full"] * (per_image["fwd"] + per_image["bwd_full"]))
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # launcher (no GPU call may happen before this returns in the parent)
 # ---------------------------------------------------------------------------------------------------------------
@@ -131,21 +218,45 @@ def _free_port():
 
 
 def launch_ranks(n, argv, device_type="cuda"):
-    """Start ``n`` rank processes of this script (one per GPU), wait, relay rank 0's stdout.  Returns the exit code."""
+    """Start ``n`` rank processes of this script (one per GPU), watch ALL of them, relay rank 0's stdout.  If any rank
+    exits non-zero the others are terminated at once (they would otherwise sit in the rendezvous or a collective until the
+    process-group timeout) and the launcher exits non-zero: a fresh start is the only valid retry.  Returns the exit code."""
+    import tempfile
     port = int(os.environ.get("MASTER_PORT") or _free_port())
     procs = []
+    out0 = tempfile.TemporaryFile()
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port), DMH_BENCH_CHILD="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
+        out = out0 if r == 0 else subprocess.DEVNULL          # stderr of every rank goes to the launcher's stderr
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
-    line = procs[0].communicate()[0].decode() if procs else ""
     rc = 0
-    for p in procs:
-        p.wait()
-        rc = max(rc, abs(p.returncode))
-    sys.stdout.write(line)
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0:
+                rc = max(rc, abs(code))
+                print("[bench launcher] rank %d exited with %d: stopping the other ranks" % (r, code), file=sys.stderr, flush=True)
+                for q in live:
+                    procs[q].terminate()
+                deadline = time.time() + 10
+                for q in list(live):
+                    try:
+                        procs[q].wait(timeout=max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        procs[q].kill()
+                        procs[q].wait()
+                live.clear()
+                break
+        if live:
+            time.sleep(0.2)
+    out0.seek(0)
+    sys.stdout.write(out0.read().decode())
     sys.stdout.flush()
     return rc
 
@@ -155,7 +266,11 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch_size", type=int, default=32)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(BASELINE_CONFIGS),
+                    help="BASELINE.json configs[N-1]: sets the flags of that workload (2 = the headline metric's)")
+    ap.add_argument("--batch_size", type=int, default=32, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--global_batch", type=int, default=0,
+                    help="strong scaling: total batch, split evenly over the ranks (SURVEY 8d: global 32 = 32/N per GPU)")
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--atk_steps", type=int, default=10)
@@ -171,7 +286,12 @@ def parse(argv=None):
     ap.add_argument("--device", type=str, default="cuda", choices=["cuda", "cpu"],
                     help="cpu: launcher / collective plumbing test only (gloo); no kernels run")
     ap.add_argument("--phases", action="store_true", help="also print a per-phase GPU-time breakdown to stderr")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    explicit = {x.split("=")[0].lstrip("-") for x in (sys.argv[1:] if argv is None else argv) if x.startswith("--")}
+    for k, v in BASELINE_CONFIGS[a.config][1].items():
+        if k not in explicit:           # an explicit flag wins over the config's preset
+            setattr(a, k, v)
+    return a
 
 
 def main():
@@ -190,6 +310,8 @@ def plumbing_only(a):
     import torch
     import torch.distributed as dist
     from depthmodelhardening_amd.ddp import init_distributed
+    if os.environ.get("DMH_BENCH_FAIL_RANK") == os.environ.get("RANK", "0"):     # test hook: this rank dies before the rendezvous
+        raise SystemExit(3)
     rank, world, _ = init_distributed("cpu")
     if world != a.gpus:
         raise SystemExit("bench.py: --gpus %d but the job has %d ranks" % (a.gpus, world))
@@ -240,12 +362,18 @@ def run_rank(a):
     if rank == 0:
         threading.Thread(target=heartbeat, daemon=True).start()
 
+    scaling = "weak"
+    if a.global_batch:
+        if a.global_batch % world:
+            raise SystemExit("bench.py: --global_batch %d is not a multiple of %d ranks" % (a.global_batch, world))
+        a.batch_size, scaling = a.global_batch // world, "strong"
     if a.harness == "physical":
         from depthmodelhardening_amd import physical_adv_training as pat
         job = pat.BenchJob(a.batch_size, a.atk_steps, rank, world, device)
-        workload = ("physical_adv_training.py hardening loop: Phy_obj_atk (EOT patch attack, %d steps) on %d scenes/GPU "
-                    "-> frozen model disparity -> MSE -> Adam, Monodepth2 ResNet18 %dx%d" % (
-                        a.atk_steps, a.batch_size, a.width, a.height))
+        groups = [min(pat.MAX_POSE_GROUP, a.batch_size - lo) for lo in range(0, a.batch_size, pat.MAX_POSE_GROUP)]
+        workload = ("physical_adv_training.py hardening loop: ONE Phy_obj_atk (EOT patch attack, %d steps) over all %d "
+                    "scenes/GPU (poses drawn without replacement per group: %s) -> frozen model disparity -> MSE -> Adam, "
+                    "Monodepth2 ResNet18 %dx%d" % (a.atk_steps, a.batch_size, "+".join(map(str, groups)), a.width, a.height))
     else:
         argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", str(a.height), "--width",
                 str(a.width), "--batch_size", str(a.batch_size), "--learning_rate", "1e-5", "--adv_train", "--norm_type",
@@ -296,10 +424,17 @@ def run_rank(a):
     # ~10 us of dispatch latency around a launch, and a step has ~1,300 instrumented launches (timing all of them cost
     # 8.5 ms of a 174 ms step).  The other kernels' durations (roofline.others) come from ONE extra, untimed, fully
     # instrumented step BEFORE the timed region (so that the timed region is the tail of a kernel trace).
+    from depthmodelhardening_amd.networks import ResnetEncoder
+    holders = list(job.models.values()) + [getattr(job, "gt_model", None)] if a.harness == "trainer" else \
+        [job.model_rob, job.model_ori]
+    encoders = {id(m): m for h in holders if h is not None for m in h.modules() if isinstance(m, ResnetEncoder)}
+    meter = FlopMeter(list(encoders.values()))
     ops.enable_profile(True)
+    meter.on = True
     job.train_step()
     job._apply_pending_update()
     sync()
+    meter.on = False
     kbytes = ops.profile_bytes()
     ops.enable_profile(True, only=("photo_",))
     t0 = time.perf_counter()
@@ -311,10 +446,30 @@ def run_rank(a):
     note("timed region done: %.3fs for %d steps" % (elapsed, a.steps))
     kms = {k: v for k, v in ops.profile_ms().items() if k.startswith("photo_")}
     ops.enable_profile(False)
+    other_mode = None
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        if a.harness == "trainer":
+            # the same K steps once more in the OTHER ordering of attack and gradient exchange (both numbers in one line):
+            # overlapped = the attack is enqueued before the optimiser waits for the all-reduce (weights one step stale,
+            # north_star); sync_attack = the reference's strict order (results identical to the reference's)
+            job.opt.sync_attack = not job.opt.sync_attack
+            job.train_step()
+            job._apply_pending_update()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(a.steps):
+                job.train_step()
+            job._apply_pending_update()
+            sync()
+            t = torch.tensor([time.perf_counter() - t1], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            other_mode = {"mode": "sync_attack" if job.opt.sync_attack else "overlapped",
+                          "value": round(a.batch_size * world * a.steps / float(t.item()), 3),
+                          "ms_per_step": round(float(t.item()) / a.steps * 1e3, 3)}
+            job.opt.sync_attack = not job.opt.sync_attack
     loss_val = float(losses["loss"].detach())
 
     if a.phases and rank == 0 and a.harness == "trainer":
@@ -328,7 +483,7 @@ def run_rank(a):
         if dom:
             kname, nbytes = names[dom]
             achieved = nbytes / (kms[dom] * 1e-3) / 1e9
-            meas = MEASURED_TRAFFIC.get((a.batch_size, a.height, a.width), {})
+            meas = measured_traffic(a.batch_size, a.height, a.width)
             traffic = meas.get(dom)
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -351,22 +506,37 @@ def run_rank(a):
                                     "achieved": round(direct / 2.25, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(direct / 2.25 / MFMA_F32_PEAK_TFLOPS, 4),
                                     "note": "achieved = MFMA flops actually issued (Winograd F(2x2,3x3): direct / 2.25)"})
-                    elif fl > 0:                            # direct MFMA convolution (K14 stem): flops as counted
+                    elif fl > 0:                            # direct MFMA convolutions (K11 / K14 / K15 / K16): flops as counted
                         tf = fl / (ms * 1e-3) / 1e12
                         ent.update({"bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                     "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4)})
                     else:
-                        ent.update({"GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
+                        ent.update({"bound": "hbm", "GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
                                     "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
                     roof["others"][k + "_kernel"] = ent
+        # whole-step compute fraction: U-Net FLOPs per image measured with torch.utils.flop_counter, times the
+        # U-Net passes counted in the instrumented step (direct-convolution FLOPs: the Winograd kernels issue 2.25x fewer)
+        per_image = unet_flops(a.height, a.width)
+        step_flops = meter.flops(per_image)
+        step_tf = step_flops / (elapsed / a.steps) / 1e12
+        if roof is not None:
+            roof["step"] = {"bound": "mfma", "flops_per_step": step_flops, "TFLOP/s": round(step_tf, 2),
+                            "peak": MFMA_F32_PEAK_TFLOPS, "frac": round(step_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                            "unet_gflop_per_image": {k: round(v / 1e9, 3) for k, v in per_image.items()},
+                            "unet_images_per_step": dict(meter.images),
+                            "note": "direct-convolution FLOPs of every U-Net pass of one step (torch.utils.flop_counter, "
+                                    "reference module path) / measured step time, against the dense fp32 MFMA peak"}
         out = {"metric": "adv-train images/sec @1024x320, 10-step PGD, bs32", "value": round(a.batch_size * world * a.steps / elapsed, 3),
                "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(elapsed / a.steps * 1e3, 3), "higher_is_better": True, "scaling": scaling,
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": workload, "global_batch": a.batch_size * world, "parallelism": "dp%d" % world,
+               "config": {"workload": workload, "baseline_config": BASELINE_CONFIGS[a.config][0], "config_index": a.config,
+                          "global_batch": a.batch_size * world, "per_gpu_batch": a.batch_size, "parallelism": "dp%d" % world,
                           "attack_overlap": bool(world > 1 and not a.sync_attack and a.harness == "trainer"),
                           "final_loss": round(loss_val, 6)},
                "roofline": roof}
+        if other_mode is not None:
+            out["config"]["other_order"] = other_mode
         if world == 1 and not a.no_cpu_baseline:
             gpu_loss_ms = round(sum(kms.values()), 4) if kms else None
             out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.atk_steps, a.batch_size, gpu_loss_ms)

@@ -140,15 +140,16 @@ class SyntheticKITTIDataset(object):
         Returns (color_aug_0, color_aug_s, color_ben_0, objmask_0)."""
         dev = self.device
         n = raw_l.shape[0]
-        is_l = torch.tensor([s == "l" for s in geo["side"]], device=dev).view(n, 1, 1, 1)
-        frame0 = torch.where(is_l, raw_l, raw_r)
-        frame_s = torch.where(is_l, raw_r, raw_l)
+        frame0, frame_s = self._pick_sides(raw_l, raw_r, geo["side"])
         K, T = self.adv_K, self.stereo_T
         far = np.array([1, 0, 1e7, 0, 1, 1e7, 0, 0], dtype=np.float32)      # object lands outside the frame: no synthesis
-        c0_adv = self.adv_trans.coeffs_for(geo["z0"], geo["alpha"], K=K)
-        c0_adv_T = self.adv_trans.coeffs_for(geo["z0"], geo["alpha"], K=K, T=T)
-        cs_ben = self.ben_trans.coeffs_for(geo["z0"], geo["alpha"], K=K)
-        cs_ben_T = self.ben_trans.coeffs_for(geo["z0"], geo["alpha"], K=K, T=T)
+        # coefficient tables only for the cameras this batch uses (all-left batches never need the frame-0 table through
+        # stereo_T, all-right ones never the plain one)
+        any_l, any_r = any(sd == "l" for sd in geo["side"]), any(sd != "l" for sd in geo["side"])
+        c0_adv = self.adv_trans.coeffs_for(geo["z0"], geo["alpha"], K=K) if any_l else None
+        c0_adv_T = self.adv_trans.coeffs_for(geo["z0"], geo["alpha"], K=K, T=T) if any_r else None
+        cs_ben = self.ben_trans.coeffs_for(geo["z0"], geo["alpha"], K=K) if any_r else None
+        cs_ben_T = self.ben_trans.coeffs_for(geo["z0"], geo["alpha"], K=K, T=T) if any_l else None
         c0, cs = np.empty((n, 8), dtype=np.float32), np.empty((n, 8), dtype=np.float32)
         for i in range(n):
             left = geo["side"][i] == "l"
@@ -163,6 +164,16 @@ class SyntheticKITTIDataset(object):
             aug_s, _ = ops.eot_paste(frame_s, self.obj_img_ben, self.obj_mask, cs, lp, tp, out_size, flip)
             ben0, mask0 = ops.eot_paste(frame0, self.obj_img_ben, self.obj_mask, c0, lp, tp, out_size, flip)
         return aug0, aug_s, ben0, mask0
+
+    def _pick_sides(self, raw_l, raw_r, sides):
+        """(frame 0, opposite view) per sample.  With every sample on the same side (--no_flip_sides: always "l") the raw
+        tensors are used as they are -- no blocking host-list upload, no two full-resolution select passes."""
+        if all(sd == "l" for sd in sides):
+            return raw_l, raw_r
+        if all(sd != "l" for sd in sides):
+            return raw_r, raw_l
+        is_l = to_device_async([sd == "l" for sd in sides], self.device, torch.bool).view(len(sides), 1, 1, 1)
+        return torch.where(is_l, raw_l, raw_r), torch.where(is_l, raw_r, raw_l)
 
     def next_batch(self, batch_size):
         dev, H, W = self.device, self.height, self.width
@@ -179,11 +190,11 @@ class SyntheticKITTIDataset(object):
                 inputs[("objdepth", 0, 0)] = to_device_async(geo["z0"], dev, torch.float32).view(batch_size, 1)
             left, right = ben0, aug_s           # inputs[("color",0,-1)] = color_ben, ("color","s",-1) = color_aug("s"), :252-253
         else:
-            is_l = torch.tensor([s == "l" for s in geo["side"]], device=dev).view(batch_size, 1, 1, 1)
-            left = F.interpolate(torch.where(is_l, raw_l, raw_r), [H, W], mode="bilinear", align_corners=False)
-            right = F.interpolate(torch.where(is_l, raw_r, raw_l), [H, W], mode="bilinear", align_corners=False)
+            f0, fs = self._pick_sides(raw_l, raw_r, geo["side"])
+            left = F.interpolate(f0, [H, W], mode="bilinear", align_corners=False)
+            right = F.interpolate(fs, [H, W], mode="bilinear", align_corners=False)
             if any(geo["flip"]):
-                fl = torch.tensor(geo["flip"], device=dev).view(batch_size, 1, 1, 1)
+                fl = to_device_async(geo["flip"], dev, torch.bool).view(batch_size, 1, 1, 1)
                 left, right = torch.where(fl, left.flip(3), left), torch.where(fl, right.flip(3), right)
             inputs[("color_aug", 0, 0)] = left
         for s in range(self.num_scales):

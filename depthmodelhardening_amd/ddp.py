@@ -26,12 +26,15 @@ def init_distributed(device_type="cuda"):
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("DMH_DIST_FORCE_INIT")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # nccl (= RCCL on ROCm) for GPUs; DMH_DIST_BACKEND=gloo lets several ranks share ONE GPU in tests
         backend = os.environ.get("DMH_DIST_BACKEND") or ("nccl" if device_type == "cuda" else "gloo")
         kw = {"device_id": device} if backend == "nccl" else {}
+        # generous: rank 0 may spend minutes compiling MIOpen kernels on a fresh box while the others wait in a barrier
+        import datetime
+        kw["timeout"] = datetime.timedelta(minutes=int(os.environ.get("DMH_DIST_TIMEOUT_MIN", "60")))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, world, device
 
@@ -43,7 +46,10 @@ class GradBucket(object):
     unused ``fc``, MD2/trainer.py:85) should be excluded by the caller.
     """
 
-    def __init__(self, params, world_size=None, group=None):
+    def __init__(self, params, world_size=None, group=None, force_collective=False):
+        """``force_collective``: issue the all-reduce even with one rank (a 1-rank RCCL communicator) -- lets a single-GPU
+        box exercise the real nccl + side-stream + event path (tests/test_gpu_ddp.py)."""
+        self.force = bool(force_collective)
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise RuntimeError("GradBucket: no trainable parameters")
@@ -85,7 +91,7 @@ class GradBucket(object):
 
     def start_all_reduce(self):
         """Enqueue sum-all-reduce + 1/N of the bucket; returns immediately."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -100,7 +106,7 @@ class GradBucket(object):
 
     def finish_all_reduce(self):
         """Make the averaged gradients visible to the current stream (call before optimizer.step())."""
-        if self.world <= 1:
+        if self.world <= 1 and not self.force:
             return
         if self.stream is not None:
             if self._event is not None:

@@ -868,7 +868,8 @@ def _small_conv(x, weight, bias, pad, backward):
     y = torch.empty((B, n_out, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
     nb = 4 * (x.numel() + y.numel())
     N.check(_timed("conv3x3_small", lambda: lib.dmh_conv3x3_small(N.ptr(x), N.ptr(_c(weight.detach())), N.ptr(bias), B, Kw,
-                                                                 Cw, H, W, pad, int(backward), N.ptr(y), N.stream()), nb))
+                                                                 Cw, H, W, pad, int(backward), N.ptr(y), N.stream()), nb,
+                   18 * x.shape[1] * y.numel()))
     return y
 
 
@@ -919,7 +920,7 @@ class _Conv3x3(torch.autograd.Function):
         elif need_x and _small_ok(K, Cc):
             g_x = _small_conv(g, weight, None, 2 - pad, True)
             need_x = False
-        if need_w and K == 1 and WINO_ENABLED:
+        if need_w and K == 1 and WINO_ENABLED and Cc * H * W < (1 << 29):
             # disparity head (one output channel): K13's strip reduction instead of MIOpen's 1-row implicit GEMM
             lib = N.lib()
             part = torch.empty(lib.dmh_conv3x3_head_wrw_partials_size(B, Cc, H, W, pad), device=g.device, dtype=torch.float32)
@@ -929,7 +930,7 @@ class _Conv3x3(torch.autograd.Function):
                 N.ptr(x), N.ptr(g), B, Cc, H, W, pad, N.ptr(part), N.ptr(g_w), N.ptr(g_b), N.stream()),
                 4 * (x.numel() + g.numel())))
             need_w = need_b = False
-        if need_w and K == 16 and Cc in (16, 32) and WINO_ENABLED:
+        if need_w and K == 16 and Cc in (16, 32) and WINO_ENABLED and Cc * H * W < (1 << 28):
             # last decoder stage: K16 (pixel axis on the MFMA, persistent workgroups) instead of MIOpen's implicit GEMM
             lib = N.lib()
             part = torch.empty(lib.dmh_conv3x3_small_wrw_partials_size(Cc), device=g.device, dtype=torch.float32)
@@ -1168,7 +1169,10 @@ def down_convs_ok(x, w3, wd):
     return (WINO_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and w3.dim() == 4 and wd.dim() == 4
             and tuple(w3.shape[2:]) == (3, 3) and tuple(wd.shape[2:]) == (1, 1) and w3.shape[:2] == wd.shape[:2]
             and w3.shape[1] == x.shape[1] and x.shape[1] % 64 == 0 and w3.shape[0] % 64 == 0
-            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and x.shape[2] >= 2 and x.shape[3] >= 2
+            # the kernel's own 32-bit index limits (DMH_REQUIRE in csrc/down_conv.hip): beyond them the caller falls back
+            and x.shape[0] * max(x.shape[1], w3.shape[0]) * x.shape[2] * x.shape[3] < (1 << 29)
+            and x.shape[1] * w3.shape[0] < (1 << 24))
 
 
 def down_convs(x, w3, wd):

@@ -44,44 +44,23 @@ def make_attack(model_rob, attack, device, steps=atk_step, eps=atk_eps, alpha=at
     return Phy_obj_atk(model_rob, obj_tensor, mask_tensor, eps=eps, alpha=alpha, steps=steps)
 
 
-MAX_OBJ_BATCH = 12      # physicalTrans.py:150,155 draw (z0, alpha) WITHOUT replacement from 25 / 13 values: at most 13 scenes
+MAX_POSE_GROUP = 13     # physicalTrans.py:150,155 draw (z0, alpha) WITHOUT replacement from 25 distances / 13 angles
 
 
 def attack_scenes(depth_atk, attack, scene_img, batch_size, eval=False):
     """-> (adversarial [B,3,320,1024], benign [B,3,320,1024], object mask or None).
 
-    The object attack cannot take more than 13 scenes (its poses are drawn without replacement from 13 angles; the
-    reference's own loops use batch 6).  BASELINE config 5 asks for batch 32: the patch is then optimised on the first
-    12 scenes and pasted into the remaining ones in groups of <= 12 by further zero-step calls (fresh pose draws per
-    group), i.e. one attack per iteration as in the reference, applied to all scenes."""
+    The reference's object attack cannot take more than 13 scenes (``random.sample`` of 13 angles raises; its own loops
+    use batch 6).  BASELINE config 5 asks for batch 32: ONE attack over all 32 scenes -- every PGD step pastes the patch
+    into every scene (one K3 launch), runs the model on the whole batch and takes one sign step on the patch gradient
+    summed over the batch -- with the poses drawn without replacement per run of 13 scenes (13 + 13 + 6,
+    ``Phy_obj_atk.pose_group``).  The returned adversarial / benign scenes share one final pose draw per scene."""
     if attack == "image":
         adv, ben = depth_atk(scene_img)
         return adv, ben, None
-    if batch_size <= MAX_OBJ_BATCH + 1:
-        adv, ben, masks, _ = depth_atk(scene_img, batch_size, eval=eval)
-        return adv, ben, masks
-    outs, steps = [], depth_atk.steps
-    first = scene_img[:MAX_OBJ_BATCH]
-    adv, ben, masks, patch = depth_atk(first, MAX_OBJ_BATCH, eval=eval)
-    outs.append((adv, ben, masks))
-    saved_obj, saved_rs = depth_atk.obj_img, depth_atk.random_start
-    try:
-        # paste-only passes: the optimised patch is the "object", zero steps, no random start; the benign view of
-        # these groups is pasted from the original object afterwards
-        for lo in range(MAX_OBJ_BATCH, batch_size, MAX_OBJ_BATCH):
-            grp = scene_img[lo:lo + MAX_OBJ_BATCH]
-            depth_atk.steps, depth_atk.random_start = 0, False
-            depth_atk.obj_img = patch.detach()
-            import random as _r
-            state = _r.getstate()
-            adv_g, _, masks_g, _ = depth_atk(grp, grp.shape[0])
-            _r.setstate(state)                      # same pose draws for the benign paste of this group
-            depth_atk.obj_img = saved_obj
-            _, ben_g, _, _ = depth_atk(grp, grp.shape[0])
-            outs.append((adv_g, ben_g, masks_g))
-    finally:
-        depth_atk.steps, depth_atk.random_start, depth_atk.obj_img = steps, saved_rs, saved_obj
-    return tuple(torch.cat([o[i] for o in outs], 0) for i in range(3))
+    depth_atk.pose_group = MAX_POSE_GROUP if batch_size > MAX_POSE_GROUP else None
+    adv, ben, masks, _ = depth_atk(scene_img, batch_size, eval=eval)
+    return adv, ben, masks
 
 
 def eval_atk_perf(model_gt, model, data, depth_atk, attack, batch_size, eval_count=100):

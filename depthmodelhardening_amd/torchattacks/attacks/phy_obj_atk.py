@@ -48,11 +48,28 @@ class Phy_obj_atk(Attack):
         self._targeted = True
         self.scene_size = [320, 1024]
         self.random_start_noise = None  # test hook: a tensor here replaces the uniform_(-eps, eps) draw
+        # (z0, alpha) are drawn WITHOUT replacement from 25 distances / 13 angles (physicalTrans.py:150,155), so the
+        # reference raises ValueError beyond 13 scenes.  pose_group = g (<= 13) lifts that for larger batches: every run
+        # of g consecutive scenes gets its own draw without replacement (physical_adv_training at batch 32: 13 + 13 + 6).
+        # None = the reference's behaviour.
+        self.pose_group = None
         conf = {'path': f'{object_dataset_root}/training/calib/003086.txt'}
         self.phy_trans_adv = PhysicalTrans(self.obj_img.clone(), self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
         self.phy_trans_ben = PhysicalTrans(self.obj_img, self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
+
+    def _draw(self, batch_size, explicit=False):
+        """One set of (z0, alpha) for ``batch_size`` scenes in the reference's RNG order: project()'s draw
+        (physicalTrans.py:146-155), or with ``explicit`` the two ``sample`` calls of phy_obj_atk.py:108-109."""
+        pt, g = self.phy_trans_ben, self.pose_group
+        sizes = [batch_size] if not g or batch_size <= g else [min(g, batch_size - lo) for lo in range(0, batch_size, g)]
+        z0s, als = [], []
+        for n in sizes:
+            z0, al = (sample(pt.dist_range, n), sample(pt.angle_range, n)) if explicit else pt.draw_samples(n)
+            z0s += list(z0)
+            als += list(al)
+        return z0s, als
 
     def _coeffs(self, samples):
         """One device tensor [len(samples), B, 8] for a list of (z0, alpha) sample lists."""
@@ -79,9 +96,8 @@ class Phy_obj_atk(Attack):
         # every (z0, alpha) draw of the attack, in the reference's order: one project() per step
         # (physicalTrans.py:150,155), then the two explicit draws for the returned scenes (:108-109)
         pt = self.phy_trans_ben
-        draws = [pt.draw_samples(batch_size) for _ in range(self.steps)]
-        z0_sample = sample(pt.dist_range, batch_size)
-        alpha_sample = sample(pt.angle_range, batch_size)
+        draws = [self._draw(batch_size) for _ in range(self.steps)]
+        z0_sample, alpha_sample = self._draw(batch_size, explicit=True)
         if eval:
             z0_sample[0] = 7
             alpha_sample[0] = 0

@@ -124,10 +124,14 @@ def paste(scene_imgs, trans, batch_size, z0_sample=None, alpha_sample=None):
 
 
 def phy_obj_atk(model, obj_img, obj_mask, images, batch_size, eps=0.3, alpha=2 / 255, steps=40,
-                random_start=True, dist_range=None, eval=False, P2=KITTI_P2, start_noise=None, record=None):
+                random_start=True, dist_range=None, eval=False, P2=KITTI_P2, start_noise=None, record=None,
+                draws=None, final_draw=None):
     """Phy_obj_atk.forward (phy_obj_atk.py:59-123) wrapped as Attack.__call__ does
     (attack.py:296-312: model.eval() during the attack, train mode restored).
-    ``record``: optional list that receives the patch after every step."""
+    ``record``: optional list that receives the patch after every step.
+    ``draws`` / ``final_draw``: explicit (z0_sample, alpha_sample) per step / for the returned scenes, handed to
+    project() through its own z0_sample / alpha_sample arguments (physicalTrans.py:130,146-155) instead of its
+    ``random.sample`` -- used for batches beyond the 13 poses one draw without replacement can give."""
     dist_range = list(range(5, 31, 2)) if dist_range is None else dist_range
     given_training = model.training
     model.eval()
@@ -140,10 +144,11 @@ def phy_obj_atk(model, obj_img, obj_mask, images, batch_size, eps=0.3, alpha=2 /
         noise = torch.empty_like(adv).uniform_(-eps, eps) if start_noise is None else start_noise
         adv = torch.clamp(adv + noise, min=0, max=1).detach()
     target = torch.zeros((batch_size, 1, SCENE_SIZE[0], SCENE_SIZE[1]), dtype=obj_img.dtype)
-    for _ in range(steps):
+    for step in range(steps):
         adv.requires_grad_()
         trans_adv.reset_img(adv, obj_mask)
-        adv_scenes, masks, _, _, _ = paste(scene_imgs, trans_adv, batch_size)
+        z0_i, al_i = draws[step] if draws is not None else (None, None)
+        adv_scenes, masks, _, _, _ = paste(scene_imgs, trans_adv, batch_size, z0_i, al_i)
         cost = -loss(model(adv_scenes) * masks, target)
         grad = torch.autograd.grad(cost, adv, retain_graph=False, create_graph=False)[0]
         with torch.no_grad():
@@ -153,8 +158,11 @@ def phy_obj_atk(model, obj_img, obj_mask, images, batch_size, eps=0.3, alpha=2 /
         if record is not None:
             record.append(adv.detach().clone())
     trans_adv.reset_img(adv, obj_mask)
-    z0 = random.sample(trans_ben.dist_range, batch_size)
-    al = random.sample(trans_ben.angle_range, batch_size)
+    if final_draw is not None:
+        z0, al = list(final_draw[0]), list(final_draw[1])
+    else:
+        z0 = random.sample(trans_ben.dist_range, batch_size)
+        al = random.sample(trans_ben.angle_range, batch_size)
     if eval:
         z0[0], al[0] = 7, 0
     adv_scenes, _, full_mask, _, _ = paste(scene_imgs, trans_adv, batch_size, z0, al)

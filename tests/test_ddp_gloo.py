@@ -97,6 +97,17 @@ def test_bench_launcher_starts_the_ranks_itself():
     assert out["n_gpus"] == 2 and out["max_over_ranks"] == 2.0
 
 
+def test_bench_launcher_stops_the_job_when_one_rank_dies():
+    """A rank that dies before the rendezvous must not leave the others waiting for the process-group timeout: the launcher
+    polls every child, terminates the survivors and exits non-zero within seconds."""
+    import time
+    t0 = time.time()
+    r = _run_bench(["--gpus", "2", "--device", "cpu"], {"DMH_BENCH_FAIL_RANK": "1"}, timeout=120)
+    assert r.returncode != 0
+    assert "rank 1 exited with 3" in r.stderr
+    assert time.time() - t0 < 60
+
+
 def test_bench_refuses_a_world_size_that_does_not_match_gpus():
     """Under a torchrun-style environment with the wrong world size bench.py exits non-zero instead of measuring one rank
     and reporting it as N."""

@@ -79,7 +79,7 @@ def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
         losses, maps, outputs, grads = _oracle_loss(loss_ref, inputs, disps, noise, variant)
         in64, disps64 = synth.make_loss_case(B, H, W, seed, dtype=torch.float64)
         noise64 = None if noise is None else {s: z.double() for s, z in noise.items()}
-        _, _, _, grads64 = _oracle_loss(loss_ref, in64, disps64, noise64, variant)
+        losses64, _, _, grads64 = _oracle_loss(loss_ref, in64, disps64, noise64, variant)
 
         d_in = to_dev(inputs)
         d_disps = [d.cuda().requires_grad_(True) for d in disps]
@@ -91,13 +91,21 @@ def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
         fin[N.FIN_LOSS].backward()
         torch.cuda.synchronize()
         f = fin.detach().cpu()
-        # md2's mean(min(.)) is continuous in the inputs: 2e-5.  dh's masked-sum / mask-count jumps by
-        # (value - mean)/count whenever an fp32 near-tie flips the argmin, so small images get 2e-4.
-        srtol = 2e-5 if variant == "md2" else max(2e-4, 2.0 / (B * H * W))
-        assert abs(f[N.FIN_LOSS].item() - losses["loss"].item()) <= srtol * abs(losses["loss"].item())
+        # md2's mean(min(.)) is continuous in the inputs: 2e-5 against the fp32 oracle.  dh's masked-sum / mask-count jumps
+        # by (value - mean)/count whenever an fp32 near-tie flips the argmin -- in the fp32 oracle as much as in the kernel
+        # -- so it is anchored on the fp64 oracle like the gradients: HIP may be 1.5x as far from fp64 as the fp32 oracle
+        # is, plus two flips.
+
+        def scalar_ok(got, key):
+            if variant == "md2":
+                return abs(got - losses[key].item()) <= 2e-5 * abs(losses[key].item())
+            ref64 = losses64[key].item()
+            return abs(got - ref64) <= 1.5 * abs(losses[key].item() - ref64) + max(2e-5, 2.0 / (B * H * W)) * abs(ref64)
+        assert scalar_ok(f[N.FIN_LOSS].item(), "loss"), (f[N.FIN_LOSS].item(), losses["loss"].item(), losses64["loss"].item())
         for s in range(4):
-            ref = losses["loss/%d" % s].item()
-            assert abs(f[N.FIN_LOSS_S + s].item() - ref) <= srtol * abs(ref), (s, f[N.FIN_LOSS_S + s].item(), ref)
+            key = "loss/%d" % s
+            assert scalar_ok(f[N.FIN_LOSS_S + s].item(), key), (s, f[N.FIN_LOSS_S + s].item(), losses[key].item(),
+                                                               losses64[key].item())
             sel_ref = outputs["identity_selection/%d" % s].reshape(B, H, W)
             sel = out.sel[s].cpu()
             if variant == "dh":
@@ -199,7 +207,7 @@ def test_photo_loss_two_frames_and_options():
             ins = {k: v.to(dtype) for k, v in inputs.items()}
             outs, leaves = {("cam_T_cam", 0, -1): T2.to(dtype)}, []   # the fp32-rounded pose on both sides
             for s, d in enumerate(disps):
-                d = d.to(dtype).requires_grad_(True)
+                d = d.detach().clone().to(dtype).requires_grad_(True)
                 leaves.append(d)
                 outs[("disp", s)] = d
             loss_ref.generate_images_pred(ins, outs, frame_ids=fids)
