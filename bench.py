@@ -436,7 +436,8 @@ def run_rank(a):
     sync()
     meter.on = False
     kbytes = ops.profile_bytes()
-    ops.enable_profile(True, only=("photo_",))
+    hot = ("photo_",) if a.harness == "trainer" else ("paste_",)      # the kernels of the roofline entry carry events
+    ops.enable_profile(True, only=hot)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = job.train_step()
@@ -444,7 +445,8 @@ def run_rank(a):
     sync()
     elapsed = time.perf_counter() - t0
     note("timed region done: %.3fs for %d steps" % (elapsed, a.steps))
-    kms = {k: v for k, v in ops.profile_ms().items() if k.startswith("photo_")}
+    kms = {k: v for k, v in ops.profile_ms().items() if k.startswith(hot)}
+    kb_timed = ops.profile_bytes()
     ops.enable_profile(False)
     other_mode = None
     if world > 1:
@@ -478,27 +480,35 @@ def run_rank(a):
     if rank == 0:
         fwd_b, bwd_b = k1_bytes(a.batch_size, a.height, a.width)
         names = {"photo_fwd": ("photo_fwd_kernel", fwd_b), "photo_bwd": ("photo_bwd_kernel", bwd_b)}
+        if a.harness != "trainer":
+            # physical_adv_training has no photometric loss: its hot-path kernel is K3 (EOT paste); launches differ in
+            # size (32-scene attack steps, the two final pastes), so bytes and time are totals over the timed region
+            names = {k: (k.replace("paste_", "paste_") + "_kernel", v[2] / max(1, v[0])) for k, v in kb_timed.items()
+                     if k.startswith("paste_")}
+            kms = {k: kb_timed[k][1] / max(1, kb_timed[k][0]) for k in names}
         dom = max(kms, key=lambda k: kms[k]) if kms else None
         roof = None
         if dom:
             kname, nbytes = names[dom]
             achieved = nbytes / (kms[dom] * 1e-3) / 1e9
-            meas = measured_traffic(a.batch_size, a.height, a.width)
+            meas = measured_traffic(a.batch_size, a.height, a.width) if a.harness == "trainer" else {}
             traffic = meas.get(dom)
             roof = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "traffic_over_algorithmic": round(traffic / nbytes, 3) if traffic else None,
                     "traffic_source": meas.get("source"),
-                    "note": "algorithmic bytes = SURVEY 8d fused-variant figure; the fused loss does ~1,000 VALU instructions "
-                            "per pixel on 30 B of traffic, so it sits on the VALU-issue roof, far below the HBM roof "
-                            "(profiles/README.md)",
+                    "note": ("algorithmic bytes = SURVEY 8d fused-variant figure; the fused loss does ~1,000 VALU instructions "
+                             "per pixel on 30 B of traffic, so it sits on the VALU-issue roof, far below the HBM roof "
+                             "(profiles/README.md)") if a.harness == "trainer" else
+                            "K3 EOT paste (the hot-path kernel of this harness): SURVEY 8d bytes per launch, averaged over the "
+                            "launches of the timed region",
                     "avg_ms": round(kms[dom], 4), "algorithmic_bytes": nbytes,
                     "others": {names[k][0]: {"avg_ms": round(v, 4), "GB/s": round(names[k][1] / (v * 1e-3) / 1e9, 1),
                                              "algorithmic_bytes": names[k][1], "traffic": meas.get(k)}
                                for k, v in kms.items() if k != dom}}
             # streaming kernels of the decoder glue: shapes vary per launch, so total bytes / total time
             for k, (cnt, ms, nb, fl) in sorted(kbytes.items()):
-                if not k.startswith("photo_") and ms > 0:
+                if not k.startswith("photo_") and k not in names and ms > 0:
                     ent = {"launches_per_step": cnt, "ms_per_step": round(ms, 3)}      # the one instrumented step
                     if fl > 0 and k.startswith("wino_"):    # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe
                         direct = fl / (ms * 1e-3) / 1e12
@@ -513,6 +523,9 @@ def run_rank(a):
                     else:
                         ent.update({"bound": "hbm", "GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
                                     "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
+                        if k == "stem_conv_bwd":
+                            ent["note"] = ("vector-ALU gather (147 FMAs per gradient channel and pixel block, filter in SGPRs): "
+                                           "bound by VALU issue, not by the HBM roof it is listed against")
                     roof["others"][k + "_kernel"] = ent
         # whole-step compute fraction: U-Net FLOPs per image measured with torch.utils.flop_counter, times the
         # U-Net passes counted in the instrumented step (direct-convolution FLOPs: the Winograd kernels issue 2.25x fewer)
@@ -539,7 +552,8 @@ def run_rank(a):
             out["config"]["other_order"] = other_mode
         if world == 1 and not a.no_cpu_baseline:
             gpu_loss_ms = round(sum(kms.values()), 4) if kms else None
-            out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.atk_steps, a.batch_size, gpu_loss_ms)
+            out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.atk_steps, a.batch_size,
+                                               gpu_loss_ms if a.harness == "trainer" else None)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

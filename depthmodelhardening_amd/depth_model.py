@@ -16,7 +16,10 @@ class DepthModelWrapper(torch.nn.Module):
         self.decoder = decoder
 
     def forward(self, input_image):
-        return self.decoder(self.encoder(input_image))[("disp", 0)]
+        feats = self.encoder(input_image)
+        if feats[-1].is_cuda and hasattr(self.decoder, "_forward_fused"):
+            return self.decoder(feats, only_scales=(0,))[("disp", 0)]     # the heads nobody reads are not computed
+        return self.decoder(feats)[("disp", 0)]
 
 
 def import_depth_model(scene_size, model_type='monodepth2', pre_model_path=None):

@@ -30,12 +30,15 @@ class DepthDecoder(nn.Module):
         self.decoder = nn.ModuleList(list(self.convs.values()))
         self.sigmoid = nn.Sigmoid()
 
-    def forward(self, input_features):
+    def forward(self, input_features, only_scales=None):
+        """``only_scales``: compute only these disparity heads (the stages themselves always run).  DepthModelWrapper
+        reads ("disp", 0) alone (depth_model.py:19), so inside an attack the other three heads -- which the reference
+        computes and throws away 21 times per training step -- are skipped; the returned entries are unchanged."""
         if input_features[-1].is_cuda and self.use_skips and self.upsample_mode == 'nearest':
-            return self._forward_fused(input_features)
+            return self._forward_fused(input_features, only_scales)
         return self._forward_reference(input_features)
 
-    def _forward_fused(self, input_features):
+    def _forward_fused(self, input_features, only_scales=None):
         """Same arithmetic as the reference forward, with the element-wise passes between the convolutions fused
         into the HIP glue kernels (ops.up_cat_pad / ops.elu_pad) and the convolutions run un-padded on pre-padded
         tensors (ops.conv3x3: the Winograd-MFMA kernel where the shape fills the chip, MIOpen otherwise).  Identical
@@ -53,7 +56,7 @@ class DepthDecoder(nn.Module):
             p = ops.up_cat_pad(y, input_features[i - 1] if i > 0 else None)
             z = conv(self.convs[("upconv", i, 1)].conv, p)
             p = ops.elu_pad(z)                      # feeds both the next stage and this scale's disparity head
-            if i in self.scales:
+            if i in self.scales and (only_scales is None or i in only_scales):
                 self.outputs[("disp", i)] = self.sigmoid(conv(self.convs[("dispconv", i)], p))
         return self.outputs
 

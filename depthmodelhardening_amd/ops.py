@@ -339,7 +339,10 @@ class _EotPaste(torch.autograd.Function):
         a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, flip)
         adv = torch.empty((a.N, 3, OH, OW), device=scene.device, dtype=torch.float32)
         mask_out = torch.empty((a.N, 1, OH, OW), device=scene.device, dtype=torch.float32)
-        N.check(lib.dmh_eot_paste_fwd(C.byref(a), N.ptr(adv), N.ptr(mask_out), N.stream()))
+        # algorithmic bytes: the scene read once (one copy when it is broadcast) + patch and mask + the two outputs
+        nb = 4 * (scene.numel() + patch.numel() + pmask.numel() + adv.numel() + mask_out.numel()) if mode == N.PASTE_COMPOSITE \
+            else 4 * (patch.numel() + pmask.numel() + adv.numel() + mask_out.numel())
+        N.check(_timed("paste_fwd", lambda: lib.dmh_eot_paste_fwd(C.byref(a), N.ptr(adv), N.ptr(mask_out), N.stream()), nb))
         ctx.save_for_backward(scene, patch, pmask, coeffs)
         ctx.geo = (l_pad, t_pad, OH, OW, mode)
         ctx.flip = flip
@@ -353,7 +356,9 @@ class _EotPaste(torch.autograd.Function):
         lib = N.lib()
         a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, ctx.flip)
         g_patch = torch.empty_like(patch)
-        N.check(lib.dmh_eot_paste_bwd(C.byref(a), N.ptr(_c(g_adv)), N.ptr(g_patch), N.stream()))
+        g_adv = _c(g_adv)
+        N.check(_timed("paste_bwd", lambda: lib.dmh_eot_paste_bwd(C.byref(a), N.ptr(g_adv), N.ptr(g_patch), N.stream()),
+                       4 * (g_adv.numel() + g_patch.numel())))
         return None, g_patch, None, None, None, None, None, None, None, None
 
 
