@@ -510,7 +510,7 @@ def run_rank(a):
             for k, (cnt, ms, nb, fl) in sorted(kbytes.items()):
                 if not k.startswith("photo_") and k not in names and ms > 0:
                     ent = {"launches_per_step": cnt, "ms_per_step": round(ms, 3)}      # the one instrumented step
-                    if fl > 0 and k.startswith("wino_"):    # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe
+                    if fl > 0 and k.startswith("wino"):    # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe
                         direct = fl / (ms * 1e-3) / 1e12
                         ent.update({"bound": "mfma", "TFLOP/s_direct_equivalent": round(direct, 1),
                                     "achieved": round(direct / 2.25, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

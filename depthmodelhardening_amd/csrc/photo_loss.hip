@@ -335,16 +335,25 @@ struct FRow {   // row sums of one image row: target (y, y^2) and per stream (x,
 };
 
 // ------------------------------------------------------------------------------------------------ forward
-// NF source frames, SPP scales per pass (NF * (1 + SPP) streams of rolling row sums live in registers).
+// NF source frames, SPP + SPL scales per pass.  The rolling row sums of the identity term, of the (optional) hint view and
+// of the first SPP scales live in registers (NF * (1 + SPP) streams); those of the next SPL scales live in LDS, private to
+// the wave (2 records x 3 x 16 B per lane and stream, lane-linear 16-byte words: conflict-free ds_read/write_b128, no
+// barrier).  With one source frame that allows ONE pass of four scales (target sums, identity term and tie-break noise
+// formed once instead of twice) -- measured slower than two passes of two scales, see the launch site; kept selectable.
 // HINT: DepthHints' extra candidate (DH/trainer.py:510-525,629-636,700-725): the source view warped with the depth
 // HINT is one more stream (formed per pass, like the identity term), the per-pixel argmin runs over [reprojection,
 // identity, hint], and where the hint wins the proxy log-L1 term is accumulated.
-template <int NF, int SPP, bool HINT>
-__global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArgs k) {
-    constexpr int NSTR = NF * (1 + SPP) + (HINT ? 1 : 0);
+template <int NF, int SPP, int SPL, bool HINT, int MINW = DMH_FWD_WAVES>
+__global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
+    constexpr int NSTR = NF * (1 + SPP) + (HINT ? 1 : 0);      // streams with register-resident row sums
     constexpr int ST_HINT = NF * (1 + SPP);
+    constexpr int SPT = SPP + SPL;                             // scales per pass
+    constexpr int NVAL = NSTR + NF * SPL;                      // candidates per pixel: val[] slots
+    constexpr int LREC = 3 * WAVE;                             // float4 words of one LDS record (one stream, one row)
+    __shared__ float4 s_rec[SPL > 0 ? WPB * SPL * NF * 2 * LREC : 1];
     const dmh_photo_args& a = k.a;
     const int lane = threadIdx.x & (WAVE - 1);
+    float4* const lrec = s_rec + (SPL > 0 ? (threadIdx.x >> 6) * (SPL * NF * 2 * LREC) : 0) + lane;
     const int tile = wave_item();
     if (tile >= k.ntiles) return;
     const int H = a.H, W = a.W, NS = a.num_scales;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
     }
     const bool automask = a.automask != 0, no_ssim = a.no_ssim != 0, md2 = a.variant == DMH_VARIANT_MD2;
     const int nf_noise = md2 ? NF : 1;
-    const int npass = (NS + SPP - 1) / SPP;
+    const int npass = (NS + SPT - 1) / SPT;
     const Philox<7> rng(a.seed);
     const rsrc_t rhint = make_rsrc(HINT ? a.depth_hint + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
     const rsrc_t rhmask = make_rsrc(HINT ? a.depth_hint_mask + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
@@ -379,30 +388,33 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
     const float hsx = (float)W / (float)(W - 1), hsy = (float)H / (float)(H - 1);
     const float hox = (float)xr / (float)(W - 1) - 0.5f;
 
-    for (int s0 = 0, pass = 0; s0 < NS; s0 += SPP, ++pass) {
+    for (int s0 = 0, pass = 0; s0 < NS; s0 += SPT, ++pass) {
         DispGeo dg[SPP];
         DispRow dr[SPP];
-        rsrc_t rd[SPP];
+        rsrc_t rd[SPT];
 #pragma unroll
-        for (int j = 0; j < SPP; ++j) {
+        for (int j = 0; j < SPT; ++j) {
             const int s = min(s0 + j, NS - 1);
-            dg[j] = disp_geo(a.Hs[s], a.Ws[s], H, W, xr);
-            dr[j].y0 = -1;
-            dr[j].dA = dr[j].dB = 0.f;
+            if (j < SPP) {
+                dg[j] = disp_geo(a.Hs[s], a.Ws[s], H, W, xr);
+                dr[j].y0 = -1;
+                dr[j].dA = dr[j].dB = 0.f;
+            }
             rd[j] = make_rsrc(a.disp[s] + (size_t)b * a.Hs[s] * a.Ws[s], (unsigned)(a.Hs[s] * a.Ws[s]) * 4u);
         }
         FRow<NSTR> rowA, rowB;
         float l1p[NSTR];       // L1 of the previous row (the centre row of the next window)
-        float acc1[SPP], acc2[SPP], acc3[SPP], acc4[SPP];
-        float sd_prev[SPP];    // scaled disparity of the previous row (depth of the centre row, for the hint term)
+        float acc1[SPT], acc2[SPT], acc3[SPT], acc4[SPT];
+        float sd_prev[SPT];    // scaled disparity of the previous row (depth of the centre row, for the hint term)
 #pragma unroll
-        for (int j = 0; j < SPP; ++j) acc1[j] = acc2[j] = acc3[j] = acc4[j] = sd_prev[j] = 0.f;
+        for (int j = 0; j < SPT; ++j) acc1[j] = acc2[j] = acc3[j] = acc4[j] = sd_prev[j] = 0.f;
 #pragma unroll
         for (int i = 0; i < NSTR; ++i) l1p[i] = 0.f;
 
         // One image row: `older` / `newer` are the row sums of the two rows above; the finished centre row is
-        // the one in between; the current row's sums replace `older`.
-        auto step = [&](const int kk, FRow<NSTR>& older, const FRow<NSTR>& newer) __attribute__((always_inline)) {
+        // the one in between; the current row's sums replace `older`.  `par` = kk & 1 as a literal: the LDS-resident
+        // streams keep `older` in record par and `newer` in record par ^ 1.
+        auto step = [&](const int kk, FRow<NSTR>& older, const FRow<NSTR>& newer, const int par) __attribute__((always_inline)) {
             const int r = Y0 - 1 + kk;
             const int yr = reflect_idx(r, H);
             const unsigned rowoff = (unsigned)(yr * W + xr) * 4u;
@@ -418,7 +430,7 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                 older.ty[c] = hy;
                 older.tyy[c] = hyy;
             }
-            float val[NSTR];
+            float val[NVAL];
             // accumulate one stream: xv = this row's (shifted) values of the stream
             auto stream = [&](const int st, const float (&xv)[3]) __attribute__((always_inline)) {
                 float ss = 0.f, l1 = 0.f;
@@ -436,6 +448,24 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                 // compute_reprojection_loss (MD2/trainer.py:525-537) of the centre row: its L1 was formed one row ago
                 val[st] = no_ssim ? l1p[st] * (1.f / 3.f) : (0.85f / 3.f) * ss + (0.15f / 3.f) * l1p[st];
                 l1p[st] = l1;
+            };
+            // the same for a stream whose two row-sum records live in LDS (slot ls), candidate slot vi: one 16-byte word per
+            // channel (sx, sxx, sxy, l1 of the row) read just before use; same association of the sums as above
+            auto stream_lds = [&](const int ls, const int vi, const float (&xv)[3]) __attribute__((always_inline)) {
+                float4* const ro = lrec + (ls * 2 + par) * LREC;
+                const float4* const rn = lrec + (ls * 2 + (par ^ 1)) * LREC;
+                float ss = 0.f, l1 = 0.f, l1prev = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float4 o = ro[c * WAVE], n = rn[c * WAVE];
+                    const float hx = hsum3(xv[c]), hxx = hsum3(xv[c] * xv[c]), hxy = hsum3(xv[c] * tv[c]);
+                    if (emit && !no_ssim) ss += ssim_val(o.x + n.x + hx, o.y + n.y + hxx, o.z + n.z + hxy, tw[c]);
+                    const float l1c = fabsf(tv[c] - xv[c]);
+                    l1 += l1c;
+                    l1prev += n.w;
+                    ro[c * WAVE] = make_float4(hx, hxx, hxy, l1c);
+                }
+                val[vi] = no_ssim ? l1prev * (1.f / 3.f) : (0.85f / 3.f) * ss + (0.15f / 3.f) * l1prev;
             };
             if (automask) {
 #pragma unroll
@@ -476,14 +506,20 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                 }
                 stream(ST_HINT, xv);
             }
-            float sd_centre[SPP];
+            float sd_centre[SPT];
 #pragma unroll
-            for (int j = 0; j < SPP; ++j) {
-                sd_centre[j] = sd_prev[j];
+            for (int j = 0; j < SPT; ++j) {
+                if constexpr (HINT) sd_centre[j] = sd_prev[j];
                 if (s0 + j >= NS) break;
-                const float d = disp_value_cached(rd[j], dg[j], dr[j], yr);
+                float d;
+                if (j < SPP) {
+                    d = disp_value_cached(rd[j], dg[j], dr[j], yr);
+                } else {    // LDS-resident scale: its up-sampling geometry is re-formed per row instead of held in registers
+                    const int s = s0 + j;
+                    d = disp_value(rd[j], disp_geo(a.Hs[s], a.Ws[s], H, W, xr), yr);
+                }
                 const float sd = fmaf(k.dmul, d, k.min_disp);
-                sd_prev[j] = sd;
+                if constexpr (HINT) sd_prev[j] = sd;
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
                     const float rden = fast_rcp(fmaf(sd, cam[f].m, rp[f].az));
@@ -498,7 +534,8 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                         xv[c] = (ldb(rsrc[f], t.o00, po) * w00 + ldb(rsrc[f], t.o01, po) * w01 + ldb(rsrc[f], t.o10, po) * w10 +
                                  ldb(rsrc[f], t.o11, po) * w11) - SHIFT;
                     }
-                    stream(NF + j * NF + f, xv);
+                    if (j < SPP) stream(NF + j * NF + f, xv);
+                    else stream_lds((j - SPP) * NF + f, NSTR + (j - SPP) * NF + f, xv);
                 }
             }
             if (!emit) return;
@@ -522,14 +559,14 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
             }
             unsigned bits = 0u;
 #pragma unroll
-            for (int j = 0; j < SPP; ++j) {
+            for (int j = 0; j < SPT; ++j) {
                 if (s0 + j >= NS) break;
                 const int s = s0 + j;
                 float best = 3.0e38f;
                 int bestf = 0;
 #pragma unroll
                 for (int f = 0; f < NF; ++f) {
-                    const float v = val[NF + j * NF + f];
+                    const float v = val[j < SPP ? NF + j * NF + f : NSTR + (j - SPP) * NF + f];
                     if (v < best) {
                         best = v;
                         bestf = f;
@@ -576,8 +613,10 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
                     if (k.to_opt[s]) k.to_opt[s][pix] = v;
                     acc1[j] += v;
                     acc2[j] += chosen ? 1.f : 0.f;
-                    acc3[j] += hl;
-                    acc4[j] += hint_wins ? 1.f : 0.f;
+                    if constexpr (HINT) {
+                        acc3[j] += hl;
+                        acc4[j] += hint_wins ? 1.f : 0.f;
+                    }
                     bits |= (hint_wins ? 3u : (chosen ? (unsigned)(1 + bestf) : 0u)) << (2 * s);
                 }
             }
@@ -587,12 +626,12 @@ __global__ __launch_bounds__(NT, DMH_FWD_WAVES) void photo_fwd_kernel(const KArg
             }
         };
         for (int kk = 0; kk < nrows; kk += 2) {
-            step(kk, rowA, rowB);
-            if (kk + 1 < nrows) step(kk + 1, rowB, rowA);
+            step(kk, rowA, rowB, 0);
+            if (kk + 1 < nrows) step(kk + 1, rowB, rowA, 1);
         }
         // fixed-order wave sums -> one partial pair per (scale, strip)
 #pragma unroll
-        for (int j = 0; j < SPP; ++j) {
+        for (int j = 0; j < SPT; ++j) {
             if (s0 + j >= NS) break;
             const float t1 = wave_sum(acc1[j]), t2 = wave_sum(acc2[j]);
             const float t3 = HINT ? wave_sum(acc3[j]) : 0.f, t4 = HINT ? wave_sum(acc4[j]) : 0.f;
@@ -610,8 +649,10 @@ struct BRow {   // record of one processed row: its row sums, the coefficient ro
     float xv[3], yv[3], J[3];
     float sdv;               // scaled disparity of this row (depth = 1/sdv, for the depth-hint proxy term)
     unsigned sel;            // selection field of this row for the wave's scale
-    // operands of THIS row, fetched while the previous row was processed
-    DispPre pd;
+    // operands of THIS row, requested while the previous row was processed: the warp is evaluated one row ahead, so the
+    // twelve gathered source texels are in flight for a whole row of arithmetic before their first use
+    float g[3][4];           // source texels at the four bilinear taps, per channel
+    float tx, ty, jx, jy;    // bilinear fractions; d ix / d disp, d iy / d disp (0 where the coordinate is clamped)
     float ptv[3];
     unsigned psel;           // selection byte of the row above (the coefficient row)
 };
@@ -682,44 +723,57 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
 
         // One image row r = Y0 - 2 + kk.  `cur` receives this row's record; `newer` / `older` are the records of the
         // rows one / two above.  STAGE 0: rows only; 1: + coefficient fields of row r-1; 2: + gradient of row r-2.
-        auto prefetch = [&](const int kk, BRow& rec) __attribute__((always_inline)) {
+        // issue(kk, rec): everything row kk needs from memory.  Its disparity texels were requested one row earlier still
+        // (`pdn`), so disparity -> projection -> taps runs on registers and ends in the twelve gathers, which then stay in
+        // flight while the PREVIOUS row is processed (round 2 issued them inside the row that consumed them: 28 % of the
+        // wave cycles waited on memory).
+        DispPre pdn = disp_fetch(rd, dg, reflect_idx(Y0 - 2, H));
+        auto issue = [&](const int kk, BRow& rec) __attribute__((always_inline)) {
             const int r = Y0 - 2 + kk;
             const int yr = reflect_idx(r, H);
+            const float d = disp_finish(pdn, dg, yr);
+            pdn = disp_fetch(rd, dg, reflect_idx(r + 1, H));
             const unsigned rowoff = (unsigned)(yr * W + xr) * 4u;
-            rec.pd = disp_fetch(rd, dg, yr);
 #pragma unroll
             for (int c = 0; c < 3; ++c) rec.ptv[c] = ldb(rt, rowoff, plane * (unsigned)c);
             const int rc = r - 1;
             const bool p_in = col_in && rc >= 0 && rc < H;
             rec.psel = p_in ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsel, (unsigned)(rc * W + col), 0, 0) : 0u;
-        };
-        auto step = [&](const int kk, BRow& older, const BRow& newer, BRow& cur, auto stage_tag) __attribute__((always_inline)) {
-            constexpr int STAGE = decltype(stage_tag)::value;
-            const int r = Y0 - 2 + kk;
-            const int yr = reflect_idx(r, H);
-            // (1) this row: target, warp, chain factors J_c = d warped_c / d disp
-            const float d = disp_finish(cur.pd, dg, yr);
-            prefetch(kk + 1, older);        // `older` is the record of the next row; its sums are still read below
             const float sd = fmaf(k.dmul, d, k.min_disp);
-            const float sd_rq = older.sdv;  // of the row two above (read before the prefetch target is reused below)
-            cur.sdv = sd;
+            rec.sdv = sd;
             const RowProj rp = row_proj(cam, lp, yr);
             const float rden = fast_rcp(fmaf(sd, cam.m, rp.az));
             const float dx = fmaf(sd, lp.nx, rp.ex) * rden, dy = fmaf(sd, rp.ny, rp.ey) * rden;
             const Tap t = make_tap(dx, dy, xr, yr, W, H);
             const float rd2 = rden * rden * k.dmul;
-            const float jx = t.gx_ok ? fmaf(lp.nx, rp.az, -rp.ex * cam.m) * rd2 : 0.f;   // d ix / d disp
-            const float jy = t.gy_ok ? fmaf(rp.ny, rp.az, -rp.ey * cam.m) * rd2 : 0.f;   // d iy / d disp
-            const float gx = 1.f - t.tx, gy = 1.f - t.ty;
-            const float w00 = gx * gy, w01 = t.tx * gy, w10 = gx * t.ty, w11 = t.tx * t.ty;
+            rec.jx = t.gx_ok ? fmaf(lp.nx, rp.az, -rp.ex * cam.m) * rd2 : 0.f;   // d ix / d disp
+            rec.jy = t.gy_ok ? fmaf(rp.ny, rp.az, -rp.ey * cam.m) * rd2 : 0.f;   // d iy / d disp
+            rec.tx = t.tx;
+            rec.ty = t.ty;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const unsigned po = plane * (unsigned)c;
-                const float v00 = ldb(rs, t.o00, po), v01 = ldb(rs, t.o01, po), v10 = ldb(rs, t.o10, po), v11 = ldb(rs, t.o11, po);
+                rec.g[c][0] = ldb(rs, t.o00, po);
+                rec.g[c][1] = ldb(rs, t.o01, po);
+                rec.g[c][2] = ldb(rs, t.o10, po);
+                rec.g[c][3] = ldb(rs, t.o11, po);
+            }
+        };
+        auto step = [&](const int kk, BRow& older, const BRow& newer, BRow& cur, auto stage_tag) __attribute__((always_inline)) {
+            constexpr int STAGE = decltype(stage_tag)::value;
+            const int r = Y0 - 2 + kk;
+            // (1) this row: warped values and chain factors J_c = d warped_c / d disp from the operands requested a row ago
+            const float sd_rq = older.sdv;  // of the row two above (read before `older` becomes the next row's record)
+            issue(kk + 1, older);           // only the request fields of `older` are written; its sums are still read below
+            const float gx = 1.f - cur.tx, gy = 1.f - cur.ty;
+            const float w00 = gx * gy, w01 = cur.tx * gy, w10 = gx * cur.ty, w11 = cur.tx * cur.ty;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float v00 = cur.g[c][0], v01 = cur.g[c][1], v10 = cur.g[c][2], v11 = cur.g[c][3];
                 cur.xv[c] = (v00 * w00 + v01 * w01 + v10 * w10 + v11 * w11) - SHIFT;
                 cur.yv[c] = cur.ptv[c] - SHIFT;
-                const float dvx = (v01 - v00) * gy + (v11 - v10) * t.ty, dvy = (v10 - v00) * gx + (v11 - v01) * t.tx;
-                cur.J[c] = dvx * jx + dvy * jy;
+                const float dvx = (v01 - v00) * gy + (v11 - v10) * cur.ty, dvy = (v10 - v00) * gx + (v11 - v01) * cur.tx;
+                cur.J[c] = dvx * cur.jx + dvy * cur.jy;
                 // (2) row sums
                 cur.hx[c] = hsum3(cur.xv[c]);
                 cur.hxx[c] = hsum3(cur.xv[c] * cur.xv[c]);
@@ -824,7 +878,8 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
         using S1 = std::integral_constant<int, 1>;
         using S2 = std::integral_constant<int, 2>;
         // record of row kk lives in rec[kk % 3]: no copies between rows
-        prefetch(0, recA);
+        recB.sdv = recC.sdv = 1.f;
+        issue(0, recA);
         step(0, recB, recC, recA, S0());
         step(1, recC, recA, recB, S0());
         step(2, recA, recB, recC, S1());
@@ -994,14 +1049,20 @@ int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_op
     k.partials = partials;
     const dim3 grid((k.ntiles + WPB - 1) / WPB), block(NT);
     switch (a->num_frames) {
-        // one source frame: two passes of two scales (3 streams, ~160 VGPRs, 3 waves/SIMD) beat one pass of four (5 streams,
-        // 229 VGPRs, 2 waves/SIMD) by 10 % although the identity and target sums are formed twice (profiles/README.md)
-        case 1:
-            if (a->depth_hint) hipLaunchKernelGGL((photo_fwd_kernel<1, 2, true>), grid, block, 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((photo_fwd_kernel<1, 2, false>), grid, block, 0, (hipStream_t)stream, k);
+        // one source frame: two passes of two scales (3 streams of row sums in registers, 160 VGPRs, 3 waves/SIMD).  Measured
+        // alternatives (profiles/README.md): one pass of four scales with all five streams in registers (229 VGPRs, 2
+        // waves/SIMD; round 2) +10 %; one pass with the row sums of scales 2-3 in wave-private LDS (round 3, this kernel with
+        // SPL = 2: 10 % fewer VALU instructions, but 194 VGPRs = 2 waves/SIMD, or 168 with scratch spills) +20 %:
+        // DMH_K1_FWD_VARIANT=2 selects it for timing comparisons.
+        case 1: {
+            static const int variant = getenv("DMH_K1_FWD_VARIANT") ? atoi(getenv("DMH_K1_FWD_VARIANT")) : 0;
+            if (a->depth_hint) hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 0, true>), grid, block, 0, (hipStream_t)stream, k);
+            else if (variant == 2) hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 2, false>), grid, block, 0, (hipStream_t)stream, k);
+            else hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 0, false>), grid, block, 0, (hipStream_t)stream, k);
             break;
-        case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, 2, false>), grid, block, 0, (hipStream_t)stream, k); break;
-        default: hipLaunchKernelGGL((photo_fwd_kernel<3, 1, false>), grid, block, 0, (hipStream_t)stream, k); break;
+        }
+        case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, 2, 0, false>), grid, block, 0, (hipStream_t)stream, k); break;
+        default: hipLaunchKernelGGL((photo_fwd_kernel<3, 1, 0, false>), grid, block, 0, (hipStream_t)stream, k); break;
     }
     return check_launch("dmh_photo_loss_fwd");
 }

@@ -1,0 +1,379 @@
+// K17 -- the 32-output-channel form of K10: 3x3 stride-1 convolution, Winograd F(2x2, 3x3) on v_mfma_f32_32x32x2_f32, for
+// layers whose output channel count is a multiple of 32 but not of 64 (MD2/networks/depth_decoder.py:51-63: upconv(1,0)
+// 64 -> 32 and upconv(1,1) 96 -> 32 forward, and the 32 -> 96 backward-data pass of the latter).  K10's work item is 64
+// output channels x 64 tiles; with 32 channels half of its MFMA rows multiply zeros, which is why these layers stayed on
+// MIOpen's vector-ALU Winograd through round 2 (16.5 ms of a 158 ms step).
+//
+//   * work item   : 32 output channels x 128 Winograd tiles (4 rows x 32 columns of tiles = 8 x 64 output pixels) x all
+//                   input channels.  4 waves, one per SIMD; wave w owns tile row w: 32 channels x 32 tiles x all 16 transform
+//                   positions = 16 accumulators of 32x32 (256 registers per lane), so the output transform A^T M A is
+//                   per-lane register arithmetic exactly as in K10.
+//   * LDS         : the transformed-input image V of a chunk is 64 KB for 128 tiles, so it is SINGLE-buffered: a chunk is
+//                   an MFMA phase (64 MFMAs per wave on U[cur], V) and a transform phase (raw[next] -> V) separated by two
+//                   barriers.  The fp32 MFMA shares the vector pipe (tools/micro/mfma_shadow.hip), so de-interleaving the
+//                   transform from the MFMAs costs barrier skew only.  U (16 KB per chunk: 32 channels) and the raw input
+//                   region (8 channels x 10 x 66) stay double-buffered: 32 + 64 + 43 KB = 139 KB.
+//   * per chunk   : filter chunk by LDS-DMA (global_load_lds_dwordx4), raw region through registers one chunk ahead of the
+//                   LDS write and two ahead of its transform; loads of chunk g+3 in flight during the MFMAs of chunk g; the
+//                   staging runs across item boundaries (the next item's offsets are kept beside the current ones).
+//   * traffic     : per 8 input channels a CU fetches 16 KB of filter + 21 KB of input for 4096 MFMA cycles = 9 B/cycle
+//                   (K10: 32 + 13 KB = 11 B/cycle).
+// Filter layout: U[C/8][16 positions][2 halves][Kp][4 floats], Kp = K rounded up to 32 (dmh_wino32_weight_transform).
+#include <stdlib.h>
+
+#include "common.hpp"
+
+using namespace dmh;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int CK = 8;                       // input channels per chunk
+constexpr int NT = 256;
+constexpr int TRW = 32, TRH = 4;            // tile region of an item
+constexpr int RW = 2 * TRW + 2, RH = 2 * TRH + 2;
+constexpr int RAW_N = CK * RH * RW;         // 5280 floats
+constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;   // 21
+constexpr int RAW_BUF = RAW_PER_T * NT;     // floats per raw buffer
+constexpr int UBUF = 16 * 2 * 32;           // f32x4 words of one U chunk image (16 KB)
+constexpr int VBUF = 16 * 2 * 128;          // f32x4 words of the V image (64 KB)
+
+struct W32Args {
+    const float* x;
+    const f32x4* U;
+    const float* bias;
+    float* y;
+    int B, C, K, Kp, H, W, Ho, Wo, pad;
+    int gx, gy, kg;              // tile-region groups along x / y, output-channel groups of 32
+    int nitems;                  // B * gy * gx * kg
+};
+
+struct Item { int b, ty0, tx0, k0; };
+
+__device__ __forceinline__ Item decode_item(const W32Args& a, int item) {
+    Item it;
+    it.k0 = (item % a.kg) * 32;  item /= a.kg;          // channel groups fastest: the groups of a region run back to back
+    it.tx0 = (item % a.gx) * TRW;  item /= a.gx;
+    it.ty0 = (item % a.gy) * TRH;
+    it.b = item / a.gy;
+    return it;
+}
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino32_conv_kernel(W32Args a) {
+    extern __shared__ f32x4 smem[];
+    f32x4* U_lds = smem;                                        // [2][16][2][32]
+    f32x4* V_lds = smem + 2 * UBUF;                             // [16][2][128]
+    float* raw = reinterpret_cast<float*>(smem + 2 * UBUF + VBUF);   // [2][CK][RH][RW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    const size_t HW = (size_t)a.H * a.W;
+    const int nch = a.C / CK;
+
+    const int q = a.nitems / (int)gridDim.x, r = a.nitems % (int)gridDim.x;
+    const int item0 = (int)blockIdx.x * q + min((int)blockIdx.x, r);
+    const int nmine = q + ((int)blockIdx.x < r ? 1 : 0);
+    const int item_last = item0 + nmine - 1;
+
+    // transform role: wave wv owns chunk channels {2wv, 2wv+1} = (h = wv>>1, s = 2(wv&1) + {0,1}); a lane transforms
+    // tiles `lane` and `lane + 64` of the region (tile t = row t/32, column t%32)
+    const int tl0y = lane >> 5, tlx = lane & 31;
+    const float* rsrc0 = raw + (2 * wv) * (RH * RW) + (2 * tl0y) * RW + 2 * tlx;          // tile `lane`; +4*RW: tile lane+64
+    float* vdst0 = reinterpret_cast<float*>(V_lds + (wv >> 1) * 128 + lane) + 2 * (wv & 1);   // +64 words: tile lane+64
+    // MFMA role: wave wv multiplies the 32 channels by tiles [32 wv, 32 wv + 32)
+    const int aidx = (lane >> 5) * 32 + (lane & 31);
+    const int bidx = (lane >> 5) * 128 + wv * 32 + (lane & 31);
+
+    unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
+    unsigned rvalid = 0, rvalid_n = 0;
+    const float* xb = a.x;
+    const float* xb_n = a.x;
+    const f32x4* usrc = a.U;
+    const f32x4* usrc_n = a.U;
+    // raw-load constants of an item: clamped offsets inside one channel chunk + validity bits (zero padding = clamped
+    // address + masked value).  The thread index is rebuilt from v_mbcnt so that nothing of this is hoisted and spilled.
+#define DMH_W32_ITEM_CONSTS(ITEM, ROFF, RVALID, XB, USRC)                                          \
+    {                                                                                             \
+        const Item it = decode_item(a, ITEM);                                                     \
+        const int ix0 = 2 * it.tx0 - a.pad, iy0 = 2 * it.ty0 - a.pad;                             \
+        int tid_o;                                                                                \
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_o)); \
+        tid_o += wv_s * 64;                                                                       \
+        XB = a.x + (size_t)it.b * a.C * HW;                                                       \
+        USRC = a.U + (size_t)it.k0;                                                               \
+        RVALID = 0;                                                                               \
+        _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
+            const int e = tid_o + NT * k;                                                         \
+            const int c = e / (RH * RW), rem = e - c * (RH * RW), rr = rem / RW, xx = rem - rr * RW; \
+            const int iy = iy0 + rr, ix = ix0 + xx;                                               \
+            const bool ok = e < RAW_N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;              \
+            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);               \
+            ROFF[k] = (unsigned)((e < RAW_N ? c : 0) * (int)HW + cy * a.W + cx);                  \
+            RVALID |= ok ? (1u << k) : 0u;                                                        \
+        }                                                                                         \
+    }
+    float rreg[RAW_PER_T];
+#define DMH_W32_LOAD_RAW(XC, ROFF)                                                                \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = (XC)[ROFF[k]];
+#define DMH_W32_WRITE_RAW(BUFI, RVALID)                                                           \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k)                                         \
+        raw[(BUFI) * RAW_BUF + tid + NT * k] = ((RVALID) >> k) & 1u ? rreg[k] : 0.f;
+    // filter chunk: 16 positions x (2 halves x 32 channels x 16 B = 1 KB, contiguous in LDS): one LDS-DMA instruction per
+    // position, four per wave.  asm: see K10 (hipcc would drain vmcnt(0) at every later LDS read); completion is counted
+    // by hand before the barriers below.
+#define DMH_W32_GLDS_U_ROW(UC, BUFI, Q)                                                           \
+    {                                                                                             \
+        const int p_ = wv + 4 * (Q);                                                              \
+        const f32x4* gsrc = (UC) + (size_t)(p_ * 2 + (lane >> 5)) * a.Kp + (lane & 31);           \
+        const unsigned ldst = __builtin_amdgcn_readfirstlane(                                     \
+            (unsigned)(uintptr_t)(U_lds + (BUFI) * UBUF + p_ * 64));                              \
+        unsigned keep;                                                                            \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");                             \
+    }
+    // input transform B^T d B of this thread's two channels for one tile: raw patch at RS -> V words at VD
+#define DMH_W32_TRANSFORM_TILE(RS, VD)                                                            \
+    {                                                                                             \
+        float t_[2][4][4];                                                                        \
+        _Pragma("unroll") for (int ch_ = 0; ch_ < 2; ++ch_) {                                     \
+            float d_[4][4];                                                                       \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+                const float2 lo = *reinterpret_cast<const float2*>((RS) + ch_ * (RH * RW) + i * RW);     \
+                const float2 hi = *reinterpret_cast<const float2*>((RS) + ch_ * (RH * RW) + i * RW + 2); \
+                d_[i][0] = lo.x; d_[i][1] = lo.y; d_[i][2] = hi.x; d_[i][3] = hi.y;               \
+            }                                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                       \
+                t_[ch_][0][j] = d_[0][j] - d_[2][j];                                              \
+                t_[ch_][1][j] = d_[1][j] + d_[2][j];                                              \
+                t_[ch_][2][j] = d_[2][j] - d_[1][j];                                              \
+                t_[ch_][3][j] = d_[1][j] - d_[3][j];                                              \
+            }                                                                                     \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                           \
+            *reinterpret_cast<float2*>((VD) + (i * 4 + 0) * 1024) = make_float2(t_[0][i][0] - t_[0][i][2], t_[1][i][0] - t_[1][i][2]); \
+            *reinterpret_cast<float2*>((VD) + (i * 4 + 1) * 1024) = make_float2(t_[0][i][1] + t_[0][i][2], t_[1][i][1] + t_[1][i][2]); \
+            *reinterpret_cast<float2*>((VD) + (i * 4 + 2) * 1024) = make_float2(t_[0][i][2] - t_[0][i][1], t_[1][i][2] - t_[1][i][1]); \
+            *reinterpret_cast<float2*>((VD) + (i * 4 + 3) * 1024) = make_float2(t_[0][i][1] - t_[0][i][3], t_[1][i][1] - t_[1][i][3]); \
+        }                                                                                         \
+    }
+#define DMH_W32_TRANSFORM(BUFI)                                                                   \
+    {                                                                                             \
+        DMH_W32_TRANSFORM_TILE(rsrc0 + (BUFI) * RAW_BUF, vdst0)                                   \
+        DMH_W32_TRANSFORM_TILE(rsrc0 + (BUFI) * RAW_BUF + 4 * RW, vdst0 + 64 * 4)                 \
+    }
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+
+    // Pipeline over the flattened (item, chunk) sequence.  Iteration g runs
+    //   M(g)    64 MFMAs on U[g&1] and V; interleaved: LDS-DMA of filter chunk g+1 -> U[(g+1)&1]; registers (raw chunk
+    //           g+2) -> raw[g&1]; global loads of raw chunk g+3 into the registers just freed
+    //   barrier, T(g+1): raw[(g+1)&1] -> V, barrier
+    DMH_W32_ITEM_CONSTS(item0, roff, rvalid, xb, usrc)
+    DMH_W32_LOAD_RAW(xb, roff)
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) DMH_W32_GLDS_U_ROW(usrc, 0, k4)
+    DMH_W32_WRITE_RAW(0, rvalid)
+    DMH_W32_LOAD_RAW(xb + (size_t)CK * HW, roff)
+    __syncthreads();
+    DMH_W32_TRANSFORM(0)
+    DMH_W32_WRITE_RAW(1, rvalid)
+    DMH_W32_LOAD_RAW(xb + (size_t)2 * CK * HW, roff)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_PER_T) : "memory");   // the LDS-DMA of U[0] has landed
+    __syncthreads();
+
+    int g = 0;
+    for (int mi = 0; mi < nmine; ++mi) {
+        const int item = item0 + mi;
+        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, rvalid_n, xb_n, usrc_n)
+        for (int ch = 0; ch < nch; ++ch, ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            const f32x4* Uc = U_lds + cur * UBUF + aidx;
+            const f32x4* Vc = V_lds + bidx;
+            const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
+            const float* xc = (r_next ? xb_n + (size_t)(ch + 3 - nch) * CK * HW : xb + (size_t)(ch + 3) * CK * HW);
+            const f32x4* uc = (u_next ? usrc_n : usrc + (size_t)(ch + 1) * 32 * a.Kp);
+            const unsigned rv = (ch + 2 >= nch) ? rvalid_n : rvalid;
+            f32x4 ua[16], vb[16];
+            ua[0] = Uc[0]; vb[0] = Vc[0];
+            ua[1] = Uc[64]; vb[1] = Vc[256];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sl = 0; sl < 32; ++sl) {
+                const int p0 = 2 * (sl >> 2), p1 = p0 + 1, ks = sl & 3;
+                acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], acc[p0], 0, 0, 0);
+                acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], acc[p1], 0, 0, 0);
+                if (p0 + 2 < 16) {                          // operands of the next position pair, one read per slot
+                    if (ks == 0) ua[p0 + 2] = Uc[(p0 + 2) * 64];
+                    if (ks == 1) vb[p0 + 2] = Vc[(p0 + 2) * 256];
+                    if (ks == 2) ua[p1 + 2] = Uc[(p1 + 2) * 64];
+                    if (ks == 3) vb[p1 + 2] = Vc[(p1 + 2) * 256];
+                }
+                if (sl < 4) {                               // filter chunk g+1 -> U[nxt] by LDS-DMA, one position per slot
+                    DMH_W32_GLDS_U_ROW(uc, nxt, sl)
+                } else if (sl >= 8 && sl < 8 + RAW_PER_T) {  // raw registers (chunk g+2) -> raw[cur], then refill (chunk g+3)
+                    const int k = sl - 8;
+                    raw[cur * RAW_BUF + tid + NT * k] = (rv >> k) & 1u ? rreg[k] : 0.f;
+                    rreg[k] = xc[r_next ? roff_n[k] : roff[k]];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // every wave has read V; U[nxt] has landed when only this iteration's raw loads are outstanding
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RAW_PER_T) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            DMH_W32_TRANSFORM(nxt)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        // ---- item done: output transform Y = A^T M A, store, clear the accumulators; lane -> tile, register -> channel
+        {
+            const Item it = decode_item(a, item);
+            int lane_o;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
+            const int oy = 2 * (it.ty0 + wv_s), ox = 2 * (it.tx0 + (lane_o & 31));
+            const bool inside = oy < a.Ho && ox < a.Wo;
+            float* yb = a.y + (size_t)it.b * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
+            const int kbase = it.k0 + 4 * (lane_o >> 5);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int ko = kbase + (v & 3) + 8 * (v >> 2);
+                float s0[4], s1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    s0[j] = acc[j][v] + acc[4 + j][v] + acc[8 + j][v];
+                    s1[j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
+                }
+                if (inside && ko < a.K) {
+                    const float bs = a.bias ? a.bias[ko] : 0.f;
+                    const float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
+                    const float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
+                    float* yp = yb + (size_t)ko * a.Ho * a.Wo;
+                    *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
+                    *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one output channel at a time: hoisted accumulator reads spill
+            }
+#pragma unroll
+            for (int pp = 0; pp < 16; ++pp)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[pp][v] = 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
+        rvalid = rvalid_n;
+        xb = xb_n;
+        usrc = usrc_n;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+// same transform as K10's (U = G g G^T, chunked layout), with the channel rows padded to a multiple of 32
+__global__ __launch_bounds__(NT) void wino32_weight_kernel(const float* __restrict__ w, int Kw, int Cw, int mode,
+                                                           float* __restrict__ U, int Kp) {
+    const int n_out = mode ? Cw : Kw, n_in = mode ? Kw : Cw;
+    const int i = blockIdx.x * NT + threadIdx.x;       // over Kp * n_in
+    if (i >= Kp * n_in) return;
+    const int ko = i % Kp, ci = i / Kp;
+    float g[3][3];
+#pragma unroll
+    for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) g[aa][b] = 0.f;
+    if (ko < n_out) {
+        // mode 0: u[k][c] from w[k][c][ky][kx];  mode 1 (backward-data): u[c][k] from w[k][c][2-ky][2-kx]
+        const float* src = mode ? w + ((size_t)ci * Cw + ko) * 9 : w + ((size_t)ko * Cw + ci) * 9;
+#pragma unroll
+        for (int aa = 0; aa < 3; ++aa)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) g[aa][b] = mode ? src[(2 - aa) * 3 + (2 - b)] : src[aa * 3 + b];
+    }
+    float t[4][3];
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        t[0][b] = g[0][b];
+        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+        t[3][b] = g[2][b];
+    }
+    const int cc = ci / CK, cl = ci % CK, h = cl >> 2, s = cl & 3;
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        const float u[4] = {t[aa][0], 0.5f * (t[aa][0] + t[aa][1] + t[aa][2]), 0.5f * (t[aa][0] - t[aa][1] + t[aa][2]), t[aa][2]};
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int p = aa * 4 + b;
+            U[((((size_t)cc * 16 + p) * 2 + h) * Kp + ko) * 4 + s] = u[b];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dmh_wino32_weight_size(int n_out, int n_in) {
+    if (n_out <= 0 || n_in <= 0 || n_in % CK) return -1;
+    const int64_t Kp = ((int64_t)n_out + 31) / 32 * 32;
+    return (int64_t)(n_in / CK) * 16 * 2 * Kp * 4;
+}
+
+int dmh_wino32_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream) {
+    DMH_REQUIRE(w && U, "null pointer");
+    const int n_out = backward ? C : K, n_in = backward ? K : C;
+    DMH_REQUIRE(K > 0 && C > 0 && n_in % CK == 0, "the pass's input channel count must be a multiple of 8");
+    const int Kp = (n_out + 31) / 32 * 32;
+    const long long n = (long long)Kp * n_in;
+    hipLaunchKernelGGL(wino32_weight_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, w, K, C,
+                       backward ? 1 : 0, U, Kp);
+    return check_launch("dmh_wino32_weight_transform");
+}
+
+int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                       float* y, void* stream) {
+    DMH_REQUIRE(x && U && y, "null pointer");
+    DMH_REQUIRE(B > 0 && C >= 3 * CK && K > 0 && C % CK == 0, "input channels must be a multiple of 8, at least 24");
+    DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
+    const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
+    DMH_REQUIRE(Ho >= 2 && Wo >= 2 && (Ho & 1) == 0 && (Wo & 1) == 0, "output height and width must be even");
+    DMH_REQUIRE((int64_t)C * H * W < ((int64_t)1 << 31) && (int64_t)K * Ho * Wo < ((int64_t)1 << 31), "image too large");
+    W32Args a;
+    a.x = x; a.U = reinterpret_cast<const f32x4*>(U); a.bias = bias; a.y = y;
+    a.B = B; a.C = C; a.K = K; a.Kp = (K + 31) / 32 * 32; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
+    a.kg = a.Kp / 32;
+    const int Ht = Ho / 2, Wt = Wo / 2;
+    a.gx = (Wt + TRW - 1) / TRW;
+    a.gy = (Ht + TRH - 1) / TRH;
+    const int64_t items = (int64_t)B * a.gx * a.gy * a.kg;
+    DMH_REQUIRE(items < ((int64_t)1 << 30), "too many work items");
+    a.nitems = (int)items;
+    constexpr size_t smem = (size_t)(2 * UBUF + VBUF) * 16 + (size_t)2 * RAW_BUF * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino32_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino32_conv3x3");
+        configured = true;
+    }
+    const int grid = a.nitems < num_cus() ? a.nitems : num_cus();
+    hipLaunchKernelGGL(wino32_conv_kernel, dim3((unsigned)grid), dim3(NT), smem, (hipStream_t)stream, a);
+    return check_launch("dmh_wino32_conv3x3");
+}
+
+}  // extern "C"

@@ -27,6 +27,8 @@
 //                   instruction count low and evenly spread.
 //   * variants    : FLAT (4 x 16 regions whose tile rows are taken from the whole batch, for 10x32-sized images), EPI
 //                   (conv + eval BatchNorm + identity + ReLU in one launch), 2-way channel split for small launches.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 using namespace dmh;
@@ -499,7 +501,11 @@ int launch(WArgs& a, hipStream_t st) {
     }
     // persistent: one workgroup per CU (its 154 KB of LDS and 512 registers per lane fill the CU), each walking a
     // contiguous range of work items
-    const int grid = a.nitems < num_cus() ? a.nitems : num_cus();
+    // DMH_K10_RESERVE_CUS=n leaves n CUs without a K10 workgroup: a contingency for multi-GPU runs, where RCCL's kernels
+    // cannot become resident on a CU this kernel occupies; default 0
+    static const int reserve = getenv("DMH_K10_RESERVE_CUS") ? atoi(getenv("DMH_K10_RESERVE_CUS")) : 0;
+    const int cus = num_cus() - (reserve > 0 && reserve < num_cus() ? reserve : 0);
+    const int grid = a.nitems < cus ? a.nitems : cus;
     hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, EPI>), dim3((unsigned)grid), dim3(NT), smem, st, a);
     return check_launch("dmh_wino_conv3x3");
 }

@@ -850,6 +850,43 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     return regions * split >= 200
 
 
+def _wino32_ok(B, n_in, n_out, Ho, Wo):
+    """Shapes of K17, the 32-output-channel form of K10 (work item 32 channels x 4 x 32 tiles): output channels a multiple
+    of 32 that K10's 64-channel items would half-fill, enough items to cover the chip and few empty tiles."""
+    if not WINO_ENABLED or n_in % 8 or n_in < 64 or n_out % 32 or n_out % 64 == 0 or n_out > 96 or Ho % 2 or Wo % 2:
+        return False        # n_in < 64: items of <= 7 chunks do not amortise their epilogue (32 -> 96 backward-data of
+                            # upconv(1,1): 559 us against MIOpen's 558, tools/wino32_bench.py) -- those stay on MIOpen
+    ht, wt = Ho // 2, Wo // 2
+    rows, cols = -(-ht // 4) * 4, -(-wt // 32) * 32
+    if ht * wt < 0.8 * rows * cols:
+        return False
+    return B * (rows // 4) * (cols // 32) * (n_out // 32) >= 400
+
+
+def _wino32_filter(weight, backward):
+    lib = N.lib()
+    K, Cc = weight.shape[0], weight.shape[1]
+    key = (weight.data_ptr(), weight._version, bool(backward), "k17")
+    if _wino_frozen and key in _wino_cache:
+        return _wino_cache[key]
+    n_out, n_in = (Cc, K) if backward else (K, Cc)
+    U = torch.empty(lib.dmh_wino32_weight_size(n_out, n_in), device=weight.device, dtype=torch.float32)
+    N.check(lib.dmh_wino32_weight_transform(N.ptr(_c(weight.detach())), K, Cc, int(backward), N.ptr(U), N.stream()))
+    if _wino_frozen:
+        _wino_cache[key] = U
+    return U
+
+
+def _wino32_conv(x, U, bias, K, pad):
+    lib = N.lib()
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
+    nb = 4 * (x.numel() + y.numel()) + 4 * U.numel()
+    N.check(_timed("wino32_conv3x3", lambda: lib.dmh_wino32_conv3x3(N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad,
+                                                                   N.ptr(y), N.stream()), nb, 18 * Cc * y.numel()))
+    return y
+
+
 def _wino_conv(x, U, bias, K, pad):
     lib = N.lib()
     B, Cc, H, W = x.shape
@@ -889,6 +926,8 @@ class _Conv3x3(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         if _wino_ok(B, Cc, K, H + 2 * pad - 2, W + 2 * pad - 2):
             return _wino_conv(x, _wino_filter(weight, False), None if bias is None else _c(bias.detach()), K, pad)
+        if _wino32_ok(B, Cc, K, H + 2 * pad - 2, W + 2 * pad - 2):
+            return _wino32_conv(x, _wino32_filter(weight, False), None if bias is None else _c(bias.detach()), K, pad)
         if WINO_ENABLED and K == 1 and ((pad == 0 and Cc % 4 == 0) or (      # disparity head: K13 (strip kernel at pad 0)
                 Cc % 16 == 0 and Cc >= 32 and B * -(-(H + 2 * pad - 2) // 8) * -(-(W + 2 * pad - 2) // 64) >= 512)):
             lib = N.lib()
@@ -915,6 +954,9 @@ class _Conv3x3(torch.autograd.Function):
         if need_x and _wino_ok(B, K, Cc, H, W):
             # backward-data = the same convolution on g with the flipped/transposed filter and pad' = 2 - pad
             g_x = _wino_conv(g, _wino_filter(weight, True), None, Cc, 2 - pad)
+            need_x = False
+        elif need_x and _wino32_ok(B, K, Cc, H, W):
+            g_x = _wino32_conv(g, _wino32_filter(weight, True), None, Cc, 2 - pad)
             need_x = False
         elif need_x and K == 1 and pad == 0 and Cc % 4 == 0 and Cc <= 64 and H >= 3 and W >= 3 and WINO_ENABLED:
             lib = N.lib()           # disparity head: one gradient plane in registers, C planes streamed out

@@ -77,9 +77,15 @@ class Trainer:
             raise NotImplementedError("pose networks (monocular frames -1/+1) are outside the hot-path scope; "
                                       "train with --frame_ids 0 --use_stereo as the paper's command does "
                                       "(reference README.md:87-91)")
-        for flag in ("v1_multiscale", "avg_reprojection", "predictive_mask", "gt_depth"):
+        for flag in ("predictive_mask", "gt_depth"):
             if getattr(self.opt, flag):
                 raise NotImplementedError("--%s is not supported by the fused photometric kernel" % flag)
+        # --avg_reprojection (MD2/trainer.py:593,617-621,636-639) replaces the min over the source frames by their mean;
+        # with the one (stereo) source frame this trainer supports the two are the same number, so the flag is accepted
+        if self.opt.avg_reprojection and len(self.opt.frame_ids) > 2:
+            raise NotImplementedError("--avg_reprojection over several source frames is not in the fused kernel")
+        if self.opt.v1_multiscale and (self.opt.loss_variant != "md2" or self.opt.use_depth_hints):
+            raise NotImplementedError("--v1_multiscale is Monodepth2's option (MD2/trainer.py:478-483,593-596)")
         if self.opt.use_depth_hints and (self.opt.loss_variant != "dh" or self.opt.disable_automasking):
             raise RuntimeError("--use_depth_hints is the DepthHints trainer's option: use --loss_variant dh with "
                                "auto-masking (DH/trainer.py:71-75,557-590)")
@@ -320,6 +326,8 @@ class Trainer:
             return losses
 
         frames = self.opt.frame_ids[1:]
+        if self.opt.v1_multiscale:
+            return self._losses_v1_multiscale(inputs, outputs, losses, total_loss, frames)
         out = ops.photometric_smooth_loss(
             inputs[("color", 0, 0)], [inputs[("color", f, 0)] for f in frames],
             [self._frame_T(inputs, outputs, f) for f in frames], inputs[("K", 0)], inputs[("inv_K", 0)],
@@ -358,6 +366,32 @@ class Trainer:
                 else:
                     outputs[key] = selection()
         total_loss = total_loss + out.fin[N.FIN_LOSS]
+        losses["loss"] = total_loss
+        return losses
+
+    def _losses_v1_multiscale(self, inputs, outputs, losses, total_loss, frames):
+        """--v1_multiscale (MD2/trainer.py:478-483,593-596: Monodepth v1's multi-scale loss): scale s is a problem of its
+        own at the resolution of scale s -- the source view ("color", f, s) is warped with disp_s as it is (no up-sampling)
+        through K / inv_K of that scale, against the target ("color", 0, s); loss = mean_s(reproj_s + wt * smooth_s / 2^s).
+        One fused K1 + K2 call per scale (single-scale launches: the disparity has the image's resolution)."""
+        per_scale = []
+        for i, scale in enumerate(self.opt.scales):
+            out = ops.photometric_smooth_loss(
+                inputs[("color", 0, scale)], [inputs[("color", f, scale)] for f in frames],
+                [self._frame_T(inputs, outputs, f) for f in frames], inputs[("K", scale)], inputs[("inv_K", scale)],
+                [outputs[("disp", scale)]], [inputs[("color", 0, scale)]], min_depth=self.opt.min_depth,
+                max_depth=self.opt.max_depth, variant="md2", automask=not self.opt.disable_automasking,
+                no_ssim=self.opt.no_ssim, smooth_wt=self.opt.disparity_smoothness / (2 ** scale), noise="philox")
+            losses["loss/{}".format(scale)] = out.fin[N.FIN_LOSS_S]
+            per_scale.append(out.fin[N.FIN_LOSS_S])
+            if not self.opt.disable_automasking:
+                sel = out.sel
+                key = "identity_selection/{}".format(scale)
+                if isinstance(outputs, LazyOutputs):
+                    outputs.lazy(key, lambda sel=sel: sel[0] if len(frames) == 1 else (sel[0] > 0).float())
+                else:
+                    outputs[key] = sel[0] if len(frames) == 1 else (sel[0] > 0).float()
+        total_loss = total_loss + sum(per_scale) / self.num_scales
         losses["loss"] = total_loss
         return losses
 

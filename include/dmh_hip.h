@@ -305,6 +305,17 @@ int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, cons
                          int K, int H, int W, int pad, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K17 the 32-output-channel form of K10 (work item 32 channels x 128 tiles): the decoder layers whose output channel
+ *     count is a multiple of 32 but not of 64 -- upconv(1,0) 64 -> 32 and upconv(1,1) 96 -> 32 forward, 32 -> 96
+ *     backward-data (MD2/networks/depth_decoder.py:51-63 via MD2/layers.py:127-141 Conv3x3).  Same contract as
+ *     dmh_wino_conv3x3; its own filter layout (channel rows padded to 32 instead of 64): weight_size / weight_transform.
+ * ---------------------------------------------------------------------------------- */
+int64_t dmh_wino32_weight_size(int n_out, int n_in);
+int dmh_wino32_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream);
+int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                       float* y, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K11 3x3 stride-1 convolution with few channels (<=4 -> <=32, 16 -> <=32 or 32 -> <=16) at full resolution, direct implicit
  *     GEMM on v_mfma_f32_16x16x4_f32 with the filter held in registers: the last decoder stage and the disparity heads
  *     (MD2/networks/depth_decoder.py:38-44).  w is the FORWARD filter [Kw][Cw][3][3] in both directions:

@@ -198,3 +198,23 @@ def compute_losses(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), noi
         losses["loss/{}".format(scale)] = loss
     losses["loss"] = total / len(scales)
     return losses, maps
+
+
+def v1_multiscale_losses(inputs, disps, noise=None, smooth_wt=SMOOTH_WT):
+    """--v1_multiscale (trainer.py:478-483,593-596): every scale is warped, compared and smoothed at its own resolution
+    with the intrinsics of that scale; loss = mean_s(loss_s), loss_s = mean(min(identity, reprojection)) + wt *
+    smooth_s / 2^s.  ``disps``: four leaf tensors.  Returns (losses dict, per-scale outputs dicts)."""
+    losses, outs = {}, []
+    total = 0
+    for s in range(4):
+        sub = {("color", 0, 0): inputs[("color", 0, s)], ("color", "s", 0): inputs[("color", "s", s)],
+               ("K", 0): inputs[("K", s)], ("inv_K", 0): inputs[("inv_K", s)], "stereo_T": inputs["stereo_T"]}
+        o = {("disp", 0): disps[s]}
+        generate_images_pred(sub, o, scales=(0,))
+        ls, _ = compute_losses(sub, o, scales=(0,), noise=None if noise is None else {0: noise[s]},
+                               smooth_wt=smooth_wt / (2 ** s))
+        losses["loss/%d" % s] = ls["loss/0"]
+        total = total + ls["loss/0"]
+        outs.append(o)
+    losses["loss"] = total / 4
+    return losses, outs

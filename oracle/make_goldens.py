@@ -144,11 +144,11 @@ def gold_layers(layers):
 
 
 # --------------------------------------------------------------------------- losses
-def _fake_trainer(trainer_mod, layers, B, H, W, module_name, use_depth_hints=False):
-    opt = SimpleNamespace(scales=[0, 1, 2, 3], v1_multiscale=False, height=H, width=W, min_depth=0.1,
+def _fake_trainer(trainer_mod, layers, B, H, W, module_name, use_depth_hints=False, v1_multiscale=False):
+    opt = SimpleNamespace(scales=[0, 1, 2, 3], v1_multiscale=v1_multiscale, height=H, width=W, min_depth=0.1,
                           max_depth=100.0, frame_ids=[0, "s"], pose_model_type="separate_resnet",
                           disable_automasking=False, no_ssim=False, adv_train=False, supervised_adv=False,
-                          contrastive_learning=False, no_original_train=False, avg_reprojection=False,
+                          contrastive_learning=False, no_original_train=False, avg_reprojection=v1_multiscale,
                           predictive_mask=False, disparity_smoothness=1e-3, use_depth_hints=use_depth_hints)
     self = SimpleNamespace(opt=opt, num_scales=4, ssim=layers.SSIM(), backproject_depth={}, project_3d={})
     for s in opt.scales:
@@ -162,12 +162,12 @@ def _fake_trainer(trainer_mod, layers, B, H, W, module_name, use_depth_hints=Fal
     return self, T
 
 
-def _run_loss(trainer_mod, layers, case, noise, variant, use_depth_hints=False):
+def _run_loss(trainer_mod, layers, case, noise, variant, use_depth_hints=False, v1_multiscale=False):
     """Run the reference generate_images_pred + compute_losses + backward.  ``noise`` is a list of four
     standard-normal tensors (one per scale) that the patched torch.randn hands out, or None -> zeros."""
     inputs, disps = case
     B, _, H, W = inputs[("color", 0, 0)].shape
-    self, T = _fake_trainer(trainer_mod, layers, B, H, W, variant, use_depth_hints)
+    self, T = _fake_trainer(trainer_mod, layers, B, H, W, variant, use_depth_hints, v1_multiscale)
     outputs = {}
     leaves = []
     for s, d in enumerate(disps):
@@ -238,6 +238,27 @@ def gold_losses(trainer_mod, layers, tag):
                 keep[k + "_sum"] = g0.double().sum((1, 2, 3))
                 keep[k + "_abssum"] = g0.double().abs().sum((1, 2, 3))
         save("loss_%s_%s" % (tag, name), **keep)
+
+
+def gold_v1_multiscale(trainer_mod, layers):
+    """MD2 with --v1_multiscale --avg_reprojection (trainer.py:478-483,593-596,617-621): per-scale warps at the scale's
+    own resolution and intrinsics; with the one stereo source frame the average over frames is the frame itself."""
+    from oracle.synth import add_pyramid
+    B, H, W, seed = 2, 64, 192, 27
+    inputs, disps = make_loss_case(B, H, W, seed)
+    add_pyramid(inputs, B, H, W)
+    g = torch.Generator().manual_seed(seed + 100)
+    noise = [torch.randn(B, 1, H >> s, W >> s, generator=g) for s in range(4)]
+    keep = {"shape": np.array([B, H, W, seed])}
+    for tag, nz in (("nonoise", None), ("noise", noise)):
+        res = _run_loss(trainer_mod, layers, (inputs, disps), nz, "md2", v1_multiscale=True)
+        for k, v in res.items():
+            if k.startswith(("sample", "depth_0", "warped")):
+                continue
+            if "identity_selection" in k:
+                v = np.packbits(v.numpy().astype(np.uint8))
+            keep[tag + "_" + k] = v
+    save("loss_md2_v1ms", **keep)
 
 
 def gold_depth_hints(trainer_mod, layers):
@@ -457,6 +478,7 @@ def main():
     gold_layers(layers)
     import trainer as md2_trainer
     gold_losses(md2_trainer, layers, "md2")
+    gold_v1_multiscale(md2_trainer, layers)
     import physicalTrans
     gold_geometry(physicalTrans.PhysicalTrans, calib)
     import torchattacks as ta

@@ -76,6 +76,18 @@ def make_loss_case(B, H, W, seed, disp_lo=0.01, disp_hi=0.35, dtype=torch.float3
     return inputs, disps
 
 
+def add_pyramid(inputs, B, H, W):
+    """("color","s",s), ("K",s), ("inv_K",s) for s = 1..3 (MD2/datasets/mono_dataset.py:333-342 scales the normalised
+    intrinsics by the size of each scale; the colour pyramid here is an average pool like ("color",0,s) above):
+    what --v1_multiscale reads."""
+    dtype = inputs[("color", 0, 0)].dtype
+    for s in range(1, 4):
+        inputs[("color", "s", s)] = F.avg_pool2d(inputs[("color", "s", 0)], 2 ** s).contiguous()
+        K, inv_K = make_intrinsics(B, H // 2 ** s, W // 2 ** s)
+        inputs[("K", s)], inputs[("inv_K", s)] = K.to(dtype), inv_K.to(dtype)
+    return inputs
+
+
 def make_depth_hint(B, H, W, seed):
     """Synthetic depth hints (DepthHints' SGM stereo estimates, depth-hints/datasets/mono_dataset.py:368-388): a smooth
     depth field in metres-of-the-0.1-baseline units with holes (hint == 0 where no estimate), and its validity mask."""

@@ -59,6 +59,9 @@ def test_convolution_entry_points_reject_bad_shapes_without_gpu():
     assert lib.dmh_wino_weight_size(64, 64) == (64 // 8) * 16 * 2 * 64 * 4
     assert lib.dmh_wino_weight_size(96, 32) == (32 // 8) * 16 * 2 * 128 * 4      # output channels padded to 64s
     assert lib.dmh_wino_weight_size(64, 12) == -1
+    assert lib.dmh_wino32_weight_size(32, 96) == (96 // 8) * 16 * 2 * 32 * 4
+    assert lib.dmh_wino32_weight_size(96, 32) == (32 // 8) * 16 * 2 * 96 * 4       # output channels padded to 32s
+    assert lib.dmh_wino32_conv3x3(one, one, None, 1, 16, 32, 8, 8, 1, one, None) != 0        # < 24 input channels
     assert lib.dmh_wino_conv3x3(one, one, None, 1, 16, 64, 8, 8, 1, one, None) != 0          # < 24 input channels
     assert b"multiple of 8" in lib.dmh_last_error()
     assert lib.dmh_wino_conv3x3(one, one, None, 1, 32, 64, 9, 8, 1, one, None) != 0          # odd output height

@@ -305,6 +305,77 @@ def test_wino_conv3x3_kernel_vs_aten(shape):
         torch.testing.assert_close(ggot, gref, rtol=1e-5, atol=2e-6 * float(gref.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [
+    # B, C, K, Ho, Wo, pad      (Ho, Wo = output size)
+    (2, 96, 32, 16, 128, 0),    # upconv(1,1)-like forward: un-padded input, two full 4x32 tile regions per image row band
+    (2, 64, 32, 8, 64, 0),      # upconv(1,0)-like forward
+    (2, 32, 96, 18, 130, 2),    # backward-data geometry of upconv(1,1): three channel groups, 4 chunks, ragged 9x65 tiles
+    (1, 24, 32, 6, 10, 1),      # minimum channel count (3 chunks), one ragged region, pad 1
+    (3, 40, 32, 10, 70, 1),     # 5 rows / 35 columns of tiles: ragged in both directions; chunk count 5
+    (1, 32, 48, 4, 64, 0),      # K = 48: the second channel group is half empty (ko < K guard)
+])
+def test_wino32_conv3x3_kernel_vs_aten(shape):
+    """K17 (32-output-channel Winograd-MFMA convolution) through the C ABI == ATen conv2d, and where the channel roles
+    allow it the backward-data pass (the same kernel on the flipped filter) == autograd of conv2d; launched twice: bitwise
+    reproducible (no atomics, no split)."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    B, C, K, Ho, Wo, pad = shape
+    H, W = Ho + 2 - 2 * pad, Wo + 2 - 2 * pad
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + C + K)
+    x = torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5
+    w = (torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.2
+    b = torch.rand(K, device="cuda", generator=g) - 0.5
+    gy = torch.rand(B, K, Ho, Wo, device="cuda", generator=g) - 0.5
+
+    def run(inp, wt, bias, n_out, p, backward):
+        Bn, Ci, Hi, Wi = inp.shape
+        U = torch.empty(lib.dmh_wino32_weight_size(n_out, Ci), device="cuda")
+        N.check(lib.dmh_wino32_weight_transform(N.ptr(wt), wt.shape[0], wt.shape[1], int(backward), N.ptr(U), N.stream()))
+        y = torch.full((Bn, n_out, Hi + 2 * p - 2, Wi + 2 * p - 2), float("nan"), device="cuda")
+        N.check(lib.dmh_wino32_conv3x3(N.ptr(inp), N.ptr(U), N.ptr(bias), Bn, Ci, n_out, Hi, Wi, p, N.ptr(y), N.stream()))
+        return y
+
+    ref = F.conv2d(x, w, b, padding=pad)
+    got = run(x, w, b, K, pad, False)
+    assert torch.equal(got, run(x, w, b, K, pad, False))
+    torch.testing.assert_close(got, ref, rtol=1e-5, atol=2e-6 * float(ref.abs().max()))
+    if K >= 24 and K % 8 == 0 and H % 2 == 0 and W % 2 == 0:
+        xr = x.clone().requires_grad_(True)
+        gref = torch.autograd.grad(F.conv2d(xr, w, None, padding=pad), xr, gy)[0]
+        ggot = run(gy, w, None, C, 2 - pad, True)
+        torch.testing.assert_close(ggot, gref, rtol=1e-5, atol=2e-6 * float(gref.abs().max()))
+
+
+def test_conv3x3_op_takes_k17_for_the_32_channel_decoder_layers():
+    """ops.conv3x3 dispatch: 96 -> 32 at a shape with enough work items goes to K17 in the forward pass; results and all three
+    gradients == ATen."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    B, C, K, H, W = 12, 96, 32, 82, 258
+    assert ops._wino32_ok(B, C, K, H - 2, W - 2) and not ops._wino_ok(B, C, K, H - 2, W - 2)
+    assert not ops._wino32_ok(B, K, C, H, W)            # the 32 -> 96 backward-data pass stays on MIOpen (no gain measured)
+    x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    w = ((torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.1).requires_grad_(True)
+    bias = (torch.rand(K, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    ops.enable_profile(True)
+    y = ops.conv3x3(x, w, bias, 0)
+    gy = torch.rand(y.shape, device="cuda", generator=g) - 0.5
+    gx, gw, gb = torch.autograd.grad(y, (x, w, bias), gy)
+    launches = ops.profile_bytes()
+    ops.enable_profile(False)
+    assert launches["wino32_conv3x3"][0] == 1          # the forward pass
+    xr, wr, br = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br)
+    gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), gy)
+    torch.testing.assert_close(y, yr, rtol=1e-5, atol=2e-6 * float(yr.abs().max()))
+    torch.testing.assert_close(gx, gxr, rtol=1e-5, atol=2e-6 * float(gxr.abs().max()))
+    torch.testing.assert_close(gw, gwr, rtol=1e-4, atol=1e-5 * float(gwr.abs().max()))
+    torch.testing.assert_close(gb, gbr, rtol=1e-4, atol=1e-5 * float(gbr.abs().max()))
+
+
 def test_network_kernels_vs_formulation_oracle():
     """K10 / K11 / K12 through the C ABI == oracle/conv_ref.py (fp64 numpy restatement of the same formulations:
     Winograd tiles, backward filter, parity gather), on seeded inputs small enough for the oracle's Python loops."""

@@ -328,3 +328,29 @@ def test_depth_hints_loss_path(golden, name):
             torch.testing.assert_close(mine, ref_g, rtol=1e-4, atol=1e-9)
         if name == "small" and tag == "nonoise":
             torch.testing.assert_close(outputs[("color_depth_hint", "s", 0)], t(g["nonoise_warped_hint"]), rtol=1e-5, atol=1e-6)
+
+
+def test_v1_multiscale_oracle_vs_reference(golden):
+    """--v1_multiscale --avg_reprojection (MD2/trainer.py:478-483,593-596,617-621): the per-scale restatement against the
+    reference's own run (tests/golden/loss_md2_v1ms.npz), with and without the tie-break noise."""
+    from oracle import loss_ref
+    from oracle.synth import add_pyramid, make_loss_case
+    g = golden("loss_md2_v1ms")
+    B, H, W, seed = [int(v) for v in g["shape"]]
+    inputs, disps = make_loss_case(B, H, W, seed)
+    add_pyramid(inputs, B, H, W)
+    gen = torch.Generator().manual_seed(seed + 100)
+    noise = [torch.randn(B, 1, H >> s, W >> s, generator=gen) * 0.00001 for s in range(4)]
+    for tag, nz in (("nonoise", None), ("noise", noise)):
+        leaves = [d.clone().requires_grad_(True) for d in disps]
+        losses, outs = loss_ref.v1_multiscale_losses(inputs, leaves, noise=nz)
+        losses["loss"].backward()
+        torch.testing.assert_close(losses["loss"].detach(), t(g[tag + "_loss"]), rtol=1e-6, atol=0)
+        for s in range(4):
+            torch.testing.assert_close(losses["loss/%d" % s].detach(), t(g["%s_loss_%d" % (tag, s)]), rtol=1e-6, atol=0)
+            hs, ws = H >> s, W >> s
+            sel = np.unpackbits(g["%s_identity_selection_%d" % (tag, s)])[:B * hs * ws].reshape(B, hs, ws)
+            assert (outs[s]["identity_selection/0"].numpy() != sel).mean() <= 1e-3
+            ref = t(g["%s_grad_disp_%d" % (tag, s)])
+            bad = ((leaves[s].grad - ref).abs() > 1e-5 * ref.abs().max() + 1e-4 * ref.abs()).float().mean().item()
+            assert bad <= 2e-3, (tag, s, bad)

@@ -4,7 +4,7 @@
 # PMC passes are separate runs (gpurun refuses --pmc combined with trace domains); FETCH_SIZE and WRITE_SIZE do not
 # fit one pass (TCC has 4 slots: 3 + 2).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -27,6 +27,18 @@ echo "k3 passes done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k15_trace -- python3 tools/down_bench.py > $OUT/k15_trace.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k14_trace -- python3 tools/stem_bench.py > $OUT/k14_trace.log 2>&1
 echo "k14/k15 passes done"
+# K10 (Winograd-MFMA convolution) at three layer shapes of the attack pass (12 scenes): layer1 64->64 @80x256, layer3 256->256
+# @20x64, upconv(2,1) 128->64 @80x256 (pad 0 on the pre-padded tensor).  Kernel trace + MFMA / traffic counters, one shape per
+# run so that per-kernel averages are per shape.
+for shp in "l1 64 64 80 256 1 12" "l3 256 256 20 64 1 12" "up21 128 64 80 256 0 12"; do
+  set -- $shp; tagk=$1; shift
+  K10="python3 tools/wino_prof.py $*"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k10_${tagk}_trace -- $K10 5 > $OUT/k10_${tagk}_trace.log 2>&1
+  rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/k10_${tagk}_pmc_a -- $K10 2 > $OUT/k10_${tagk}_pmc_a.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/k10_${tagk}_fetch -- $K10 2 > $OUT/k10_${tagk}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/k10_${tagk}_write -- $K10 2 > $OUT/k10_${tagk}_write.log 2>&1
+done
+echo "k10 passes done"
 if [ "${2:-bench}" = "bench" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline > $OUT/bench.json 2> $OUT/bench.err
   tail -1 $OUT/bench.json

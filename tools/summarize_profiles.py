@@ -8,7 +8,7 @@ import os
 import shutil
 import sys
 
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G = "gpurun_out/prof_%s/" % tag
 os.makedirs("profiles", exist_ok=True)
 
@@ -44,6 +44,8 @@ for d in ["k1_pmc_a", "k1_pmc_b", "k1_fetch", "k1_write", "k1_tcc"]:
             tabs.setdefault(k, {}).update(v)
             tabs[k]["_meta"] = meta[k]
 cols = sorted({c for v in tabs.values() for c in v if c != "_meta"})
+if tabs:    # the shape tools/prof_k1.py runs: bench.py uses the traffic figures only for this shape
+    json.dump({"B": 32, "H": 320, "W": 1024, "scales": 4, "tool": "tools/prof_k1.py"}, open("profiles/%s_k1k2_shape.json" % tag, "w"))
 with open("profiles/%s_k1k2_pmc.csv" % tag, "w") as f:
     w = csv.writer(f)
     w.writerow(["Kernel", "VGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"] + cols)
@@ -87,28 +89,46 @@ for kk in ("k14", "k15"):
             if "anonymous" in r["Name"]:
                 print("%s: %-70s %4s calls avg %.1f us" % (kk, r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
 
-ks10 = first(G + "k10_trace/*/*_kernel_stats.csv")
-if ks10:
-    shutil.copy(ks10, "profiles/%s_k10_kernel_stats.csv" % tag)
-tabs10 = {}
-for d in ["k10_pmc_a", "k10_fetch", "k10_write"]:
-    t, meta = pmc(d)
-    for k, v in t.items():
-        if "wino_" in k:
-            tabs10.setdefault(k, {}).update(v)
-            tabs10[k]["_meta"] = meta[k]
-if tabs10:
-    cols = sorted({c for v in tabs10.values() for c in v if c != "_meta"})
+# K10 at three layer shapes: one row per shape in profiles/<tag>_k10_pmc.csv, kernel-trace averages alongside
+SHAPES10 = {"l1": (64, 64, 80, 256, 1, 12), "l3": (256, 256, 20, 64, 1, 12), "up21": (128, 64, 80, 256, 0, 12)}
+rows10 = []
+for tk, (C_, K_, Ho_, Wo_, pad_, B_) in SHAPES10.items():
+    tr = first(G + "k10_%s_trace/*/*_kernel_stats.csv" % tk)
+    avg_us = None
+    if tr:
+        for r in csv.DictReader(open(tr)):
+            if "wino_conv_kernel" in r["Name"]:
+                avg_us = float(r["AverageNs"]) / 1e3
+    vals = {}
+    for d in ["k10_%s_pmc_a" % tk, "k10_%s_fetch" % tk, "k10_%s_write" % tk]:
+        t, meta = pmc(d)
+        for kname, v in t.items():
+            if "wino_conv_kernel" in kname:
+                vals.update(v)
+    if avg_us is None and not vals:
+        continue
+    direct = 2.0 * 9 * C_ * K_ * Ho_ * Wo_ * B_
+    algo = 4.0 * (B_ * C_ * (Ho_ + 2 - 2 * pad_) * (Wo_ + 2 - 2 * pad_) + B_ * K_ * Ho_ * Wo_ + 16 * C_ * K_)
+    row = {"shape": "%s C=%d K=%d %dx%d pad=%d B=%d" % (tk, C_, K_, Ho_, Wo_, pad_, B_), "avg_us": avg_us,
+           "direct_GFLOP": direct / 1e9, "TFLOPs_direct_equivalent": direct / (avg_us * 1e-6) / 1e12 if avg_us else None,
+           "TFLOPs_mfma_issued": direct / 2.25 / (avg_us * 1e-6) / 1e12 if avg_us else None,
+           "algorithmic_MB": algo / 1e6,
+           # 16-byte-per-lane streaming reads (LDS-DMA, float4 rows): FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM)
+           "fetch_MB_x2": 2 * vals.get("FETCH_SIZE", 0) * 1024 / 1e6, "write_MB": vals.get("WRITE_SIZE", 0) * 1024 / 1e6}
+    for c in ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES",
+              "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+        row[c] = vals.get(c)
+    if vals.get("SQ_BUSY_CU_CYCLES"):
+        row["mfma_busy_frac"] = vals.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4.0 * vals["SQ_BUSY_CU_CYCLES"])
+    rows10.append(row)
+    print("k10 %s: %s" % (tk, {k_: (round(v_, 3) if isinstance(v_, float) else v_) for k_, v_ in row.items()}))
+if rows10:
+    cols = list(rows10[0].keys())
     with open("profiles/%s_k10_pmc.csv" % tag, "w") as f:
         w = csv.writer(f)
-        w.writerow(["Kernel", "VGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"] + cols)
-        for k, v in tabs10.items():
-            w.writerow([k] + list(v["_meta"]) + [round(v.get(c, 0)) for c in cols])
-            if "conv_kernel" in k:
-                rd, wr = 2 * v.get("FETCH_SIZE", 0) * 1024, v.get("WRITE_SIZE", 0) * 1024
-                print("%-60s HBM traffic %.1f MB read + %.1f MB written; MFMA busy %.1f %% of CU-cycles" % (
-                    k[:60], rd / 1e6, wr / 1e6,
-                    100.0 * v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(1.0, 4.0 * v.get("SQ_BUSY_CU_CYCLES", 1))))
+        w.writerow(cols)
+        for r in rows10:
+            w.writerow([r.get(c) for c in cols])
 
 bs = first(G + "bench_trace/*/*_kernel_stats.csv")
 bt = first(G + "bench_trace/*/*_kernel_trace.csv")
