@@ -86,52 +86,48 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int aidx = (lane >> 5) * 32 + (lane & 31);
     const int bidx = (lane >> 5) * 128 + wv * 32 + (lane & 31);
 
+    // input and filter through buffer resources (see K10): 32-bit per-thread byte offsets + a wave-uniform SGPR offset per
+    // load; padded elements carry the offset 0xFFFFFFFF and read 0 (no clamp, no mask)
+    const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.C * HW * 4));
+    const rsrc_t urs = make_rsrc(a.U, (unsigned)((size_t)nch * 32 * a.Kp * 16));
     unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
-    unsigned rvalid = 0, rvalid_n = 0;
-    const float* xb = a.x;
-    const float* xb_n = a.x;
-    const f32x4* usrc = a.U;
-    const f32x4* usrc_n = a.U;
-    // raw-load constants of an item: clamped offsets inside one channel chunk + validity bits (zero padding = clamped
-    // address + masked value).  The thread index is rebuilt from v_mbcnt so that nothing of this is hoisted and spilled.
-#define DMH_W32_ITEM_CONSTS(ITEM, ROFF, RVALID, XB, USRC)                                          \
+    unsigned uoff = 0, uoff_n = 0;
+    // raw-load constants of an item.  The thread index is rebuilt from v_mbcnt so that nothing of this is hoisted and spilled.
+#define DMH_W32_ITEM_CONSTS(ITEM, ROFF, UOFF)                                                      \
     {                                                                                             \
         const Item it = decode_item(a, ITEM);                                                     \
         const int ix0 = 2 * it.tx0 - a.pad, iy0 = 2 * it.ty0 - a.pad;                             \
         int tid_o;                                                                                \
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_o)); \
         tid_o += wv_s * 64;                                                                       \
-        XB = a.x + (size_t)it.b * a.C * HW;                                                       \
-        USRC = a.U + (size_t)it.k0;                                                               \
-        RVALID = 0;                                                                               \
+        UOFF = (unsigned)it.k0 * 16u;                                                             \
+        const int cbase = it.b * a.C * (int)HW;                                                   \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
             const int c = e / (RH * RW), rem = e - c * (RH * RW), rr = rem / RW, xx = rem - rr * RW; \
             const int iy = iy0 + rr, ix = ix0 + xx;                                               \
             const bool ok = e < RAW_N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;              \
-            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);               \
-            ROFF[k] = (unsigned)((e < RAW_N ? c : 0) * (int)HW + cy * a.W + cx);                  \
-            RVALID |= ok ? (1u << k) : 0u;                                                        \
+            ROFF[k] = ok ? (unsigned)(cbase + c * (int)HW + iy * a.W + ix) * 4u : 0xFFFFFFFFu;    \
         }                                                                                         \
     }
     float rreg[RAW_PER_T];
-#define DMH_W32_LOAD_RAW(XC, ROFF)                                                                \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = (XC)[ROFF[k]];
-#define DMH_W32_WRITE_RAW(BUFI, RVALID)                                                           \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k)                                         \
-        raw[(BUFI) * RAW_BUF + tid + NT * k] = ((RVALID) >> k) & 1u ? rreg[k] : 0.f;
+#define DMH_W32_LOAD_RAW(CHB, ROFF)                                                               \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = ldb(xrs, ROFF[k], (CHB));
+#define DMH_W32_WRITE_RAW(BUFI)                                                                   \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) raw[(BUFI) * RAW_BUF + tid + NT * k] = rreg[k];
     // filter chunk: 16 positions x (2 halves x 32 channels x 16 B = 1 KB, contiguous in LDS): one LDS-DMA instruction per
-    // position, four per wave.  asm: see K10 (hipcc would drain vmcnt(0) at every later LDS read); completion is counted
-    // by hand before the barriers below.
-#define DMH_W32_GLDS_U_ROW(UC, BUFI, Q)                                                           \
+    // position, four per wave; lanes 0-31 read half 0, lanes 32-63 half 1 of the position's rows (Kp * 16 B apart).
+    // asm: see K10 (hipcc would drain vmcnt(0) at every later LDS read); completion is counted by hand before the barriers.
+    const unsigned lane_u = (unsigned)((lane >> 5) * a.Kp + (lane & 31)) * 16u;
+#define DMH_W32_GLDS_U_ROW(UCB, BUFI, Q)                                                          \
     {                                                                                             \
-        const int p_ = wv + 4 * (Q);                                                              \
-        const f32x4* gsrc = (UC) + (size_t)(p_ * 2 + (lane >> 5)) * a.Kp + (lane & 31);           \
+        const int p_ = wv_s + 4 * (Q);                                                            \
+        const unsigned srow = __builtin_amdgcn_readfirstlane((UCB) + (unsigned)(p_ * 2 * a.Kp) * 16u);   \
         const unsigned ldst = __builtin_amdgcn_readfirstlane(                                     \
-            (unsigned)(uintptr_t)(U_lds + (BUFI) * UBUF + p_ * 64));                              \
+            (unsigned)(uintptr_t)(U_lds + (BUFI) * UBUF) + (unsigned)(p_ * 64 * 16));              \
         unsigned keep;                                                                            \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep) : "v"(lane_u), "s"(urs), "s"(ldst), "s"(srow) : "memory");      \
     }
     // input transform B^T d B of this thread's two channels for one tile: raw patch at RS -> V words at VD
 #define DMH_W32_TRANSFORM_TILE(RS, VD)                                                            \
@@ -174,31 +170,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     //   M(g)    64 MFMAs on U[g&1] and V; interleaved: LDS-DMA of filter chunk g+1 -> U[(g+1)&1]; registers (raw chunk
     //           g+2) -> raw[g&1]; global loads of raw chunk g+3 into the registers just freed
     //   barrier, T(g+1): raw[(g+1)&1] -> V, barrier
-    DMH_W32_ITEM_CONSTS(item0, roff, rvalid, xb, usrc)
-    DMH_W32_LOAD_RAW(xb, roff)
+    const unsigned chunk_bytes = (unsigned)(CK * HW * 4);
+    const unsigned uchunk_bytes = (unsigned)(32 * a.Kp * 16);
+    DMH_W32_ITEM_CONSTS(item0, roff, uoff)
+    DMH_W32_LOAD_RAW(0u, roff)
 #pragma unroll
-    for (int k4 = 0; k4 < 4; ++k4) DMH_W32_GLDS_U_ROW(usrc, 0, k4)
-    DMH_W32_WRITE_RAW(0, rvalid)
-    DMH_W32_LOAD_RAW(xb + (size_t)CK * HW, roff)
+    for (int k4 = 0; k4 < 4; ++k4) DMH_W32_GLDS_U_ROW(uoff, 0, k4)
+    DMH_W32_WRITE_RAW(0)
+    DMH_W32_LOAD_RAW(chunk_bytes, roff)
     __syncthreads();
     DMH_W32_TRANSFORM(0)
-    DMH_W32_WRITE_RAW(1, rvalid)
-    DMH_W32_LOAD_RAW(xb + (size_t)2 * CK * HW, roff)
+    DMH_W32_WRITE_RAW(1)
+    DMH_W32_LOAD_RAW(2u * chunk_bytes, roff)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_PER_T) : "memory");   // the LDS-DMA of U[0] has landed
     __syncthreads();
 
     int g = 0;
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
-        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, rvalid_n, xb_n, usrc_n)
+        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n)
         for (int ch = 0; ch < nch; ++ch, ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
             const f32x4* Uc = U_lds + cur * UBUF + aidx;
             const f32x4* Vc = V_lds + bidx;
             const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
-            const float* xc = (r_next ? xb_n + (size_t)(ch + 3 - nch) * CK * HW : xb + (size_t)(ch + 3) * CK * HW);
-            const f32x4* uc = (u_next ? usrc_n : usrc + (size_t)(ch + 1) * 32 * a.Kp);
-            const unsigned rv = (ch + 2 >= nch) ? rvalid_n : rvalid;
+            const unsigned xcb = (unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes;
+            const unsigned ucb = u_next ? uoff_n : uoff + (unsigned)(ch + 1) * uchunk_bytes;
             f32x4 ua[16], vb[16];
             ua[0] = Uc[0]; vb[0] = Vc[0];
             ua[1] = Uc[64]; vb[1] = Vc[256];
@@ -215,11 +212,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     if (ks == 3) vb[p1 + 2] = Vc[(p1 + 2) * 256];
                 }
                 if (sl < 4) {                               // filter chunk g+1 -> U[nxt] by LDS-DMA, one position per slot
-                    DMH_W32_GLDS_U_ROW(uc, nxt, sl)
+                    DMH_W32_GLDS_U_ROW(ucb, nxt, sl)
                 } else if (sl >= 8 && sl < 8 + RAW_PER_T) {  // raw registers (chunk g+2) -> raw[cur], then refill (chunk g+3)
                     const int k = sl - 8;
-                    raw[cur * RAW_BUF + tid + NT * k] = (rv >> k) & 1u ? rreg[k] : 0.f;
-                    rreg[k] = xc[r_next ? roff_n[k] : roff[k]];
+                    raw[cur * RAW_BUF + tid + NT * k] = rreg[k];
+                    rreg[k] = ldb(xrs, r_next ? roff_n[k] : roff[k], xcb);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -267,9 +264,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
 #pragma unroll
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
-        rvalid = rvalid_n;
-        xb = xb_n;
-        usrc = usrc_n;
+        uoff = uoff_n;
     }
 }
 
@@ -353,6 +348,7 @@ int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B,
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     DMH_REQUIRE(Ho >= 2 && Wo >= 2 && (Ho & 1) == 0 && (Wo & 1) == 0, "output height and width must be even");
     DMH_REQUIRE((int64_t)C * H * W < ((int64_t)1 << 31) && (int64_t)K * Ho * Wo < ((int64_t)1 << 31), "image too large");
+    DMH_REQUIRE((int64_t)B * C * H * W < ((int64_t)1 << 30), "input larger than 4 GB (32-bit byte offsets of the buffer loads)");
     W32Args a;
     a.x = x; a.U = reinterpret_cast<const f32x4*>(U); a.bias = bias; a.y = y;
     a.B = B; a.C = C; a.K = K; a.Kp = (K + 31) / 32 * 32; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad = pad;

@@ -168,13 +168,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // ---- raw-load stage constants of an item: offsets inside one channel chunk + validity bits (zero padding =
     //      clamped address + masked value).  The load stages run ahead of the MFMAs across the item boundary, so the
     //      constants of the NEXT item are kept beside the current ones and selected per iteration (no branch).
+    // Input and filter are read through buffer resources: a 32-bit per-thread byte offset + a wave-uniform SGPR offset
+    // (chunk / filter row) per load, no 64-bit address arithmetic in the loop; an offset beyond the resource reads 0, which
+    // IS the zero padding -- padded elements get the offset 0xFFFFFFFF and need no mask (round 2 clamped the address and
+    // masked the value: ~55 vector instructions per chunk that the fp32 MFMA, sharing the vector pipe, could not shadow).
+    const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.C * HW * 4));
+    const rsrc_t urs = make_rsrc(a.U, (unsigned)((size_t)(a.C / CK) * 32 * a.Kp * 16));
     unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
-    unsigned rvalid = 0, rvalid_n = 0;
-    const float* xb = a.x;
-    const float* xb_n = a.x;
-    const f32x4* usrc = a.U;
-    const f32x4* usrc_n = a.U;
-#define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, RVALID, XB, USRC)                                        \
+    unsigned uoff = 0, uoff_n = 0;           // byte offset of the item's first filter chunk (uniform)
+#define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, UOFF)                                                    \
     {                                                                                             \
         const Item it = decode_item<TRW>(a, ITEM);                                                \
         const int ix0 = 2 * it.tx0 - a.pad;                                                       \
@@ -184,9 +186,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         int tid_o;      /* volatile asm: the builtin form is loop-invariant, gets hoisted and spilled all the same   */ \
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_o));           \
         tid_o += wv_s * 64;                                                                       \
-        XB = a.x + ((size_t)it.b * a.C + (size_t)it.c0 * CK) * HW;                                \
-        USRC = a.U + (size_t)it.k0 + (size_t)it.c0 * 32 * a.Kp;                                   \
-        RVALID = 0;                                                                               \
+        UOFF = (unsigned)(((size_t)it.k0 + (size_t)it.c0 * 32 * a.Kp) * 16);                      \
+        const int cbase = (it.b * a.C + it.c0 * CK) * (int)HW;    /* first element of the item's first chunk */ \
         /* FLAT: image and tile row of the region's 4 rows of tiles (uniform: scalar divisions) */ \
         int fb[4], fy[4];                                                                         \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                           \
@@ -197,50 +198,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
             const int c = e / (RH * RW), rem = e - c * (RH * RW), rr = rem / RW, xx = rem - rr * RW; \
-            int iy, bofs = 0;                                                                     \
+            int iy, bofs = cbase;                                                                 \
             bool okr = e < RAW_N;                                                                 \
             if (FLAT) {                                                                           \
                 const int t = rr >> 2;                                                            \
                 const int bb = t == 0 ? fb[0] : t == 1 ? fb[1] : t == 2 ? fb[2] : fb[3];          \
                 const int ty = t == 0 ? fy[0] : t == 1 ? fy[1] : t == 2 ? fy[2] : fy[3];          \
                 iy = 2 * ty - a.pad + (rr & 3);                                                   \
-                bofs = bb * a.C * (int)HW;                                                        \
+                bofs = (bb * a.C + it.c0 * CK) * (int)HW;                                         \
                 okr = okr && it.ty0 + t < NR;                                                     \
             } else {                                                                              \
                 iy = 2 * it.ty0 - a.pad + rr;                                                     \
             }                                                                                     \
             const int ix = ix0 + xx;                                                              \
             const bool ok = okr && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                    \
-            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);               \
-            ROFF[k] = (unsigned)(bofs + (e < RAW_N ? c : 0) * (int)HW + cy * a.W + cx);           \
-            RVALID |= ok ? (1u << k) : 0u;                                                        \
+            ROFF[k] = ok ? (unsigned)(bofs + c * (int)HW + iy * a.W + ix) * 4u : 0xFFFFFFFFu;     \
         }                                                                                         \
     }
 
     float rreg[RAW_PER_T];
-    // XC / UC: uniform chunk base pointers; ROFF: per-thread offsets
-#define DMH_WINO_LOAD_RAW(XC, ROFF)                                                               \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = (XC)[ROFF[k]];
+    // CHB: wave-uniform byte offset of the chunk inside the item (chunk index * 8 channels)
+#define DMH_WINO_LOAD_RAW(CHB, ROFF)                                                              \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = ldb(xrs, ROFF[k], (CHB));
     // filter chunk: 32 rows (p, h) of 64 x 16 B, lane-linear both in global memory and in the LDS image -> LDS-DMA
-    // (global_load_lds_dwordx4: no registers, no ds_write); wave wv moves rows wv, wv+4, ...; K = row slot 0..7
+    // (buffer_load_dwordx4 ... lds: no registers, no ds_write; the row's byte offset is an SGPR, the per-lane part
+    // lane * 16 a loop-invariant register); wave wv moves rows wv, wv+4, ...; K = row slot 0..7
     // Written as asm: through the builtin hipcc treats every later LDS read as a possible alias of the DMA and drains
     // vmcnt(0) -- the register-staged raw loads included -- a few slots later.  The asm DMA is invisible to hipcc's
     // s_waitcnt bookkeeping, so its completion is counted by hand (the vmcnt before each barrier below); hipcc's own
     // counted waits for the raw loads only become stricter (the DMAs are younger than the loads they wait for).
-#define DMH_WINO_GLDS_U_ROW(UC, BUFI, K)                                                          \
+    const unsigned lane16 = (unsigned)lane * 16u;
+#define DMH_WINO_GLDS_U_ROW(UCB, BUFI, K)                                                         \
     {                                                                                             \
-        const f32x4* gsrc = (UC) + (size_t)(wv + 4 * (K)) * a.Kp + lane;                          \
+        const unsigned srow = __builtin_amdgcn_readfirstlane((UCB) + (unsigned)((wv_s + 4 * (K)) * a.Kp) * 16u);   \
         const unsigned ldst = __builtin_amdgcn_readfirstlane(                                     \
-            (unsigned)(uintptr_t)(U_lds + (BUFI) * BUF + (wv + 4 * (K)) * 64));                   \
+            (unsigned)(uintptr_t)(U_lds + (BUFI) * BUF) + (unsigned)((wv_s + 4 * (K)) * 64 * 16)); \
         unsigned keep;                                                                            \
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" \
-                     : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");                             \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0" \
+                     : "=&s"(keep) : "v"(lane16), "s"(urs), "s"(ldst), "s"(srow) : "memory");      \
     }
-#define DMH_WINO_GLDS_U(UC, BUFI)                                                                 \
-    _Pragma("unroll") for (int k = 0; k < 8; ++k) DMH_WINO_GLDS_U_ROW(UC, BUFI, k)
-#define DMH_WINO_WRITE_RAW(BUFI, RVALID)                                                          \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k)                                         \
-        raw[(BUFI) * RAW_BUF + tid + NT * k] = ((RVALID) >> k) & 1u ? rreg[k] : 0.f;
+#define DMH_WINO_GLDS_U(UCB, BUFI)                                                                \
+    _Pragma("unroll") for (int k = 0; k < 8; ++k) DMH_WINO_GLDS_U_ROW(UCB, BUFI, k)
+#define DMH_WINO_WRITE_RAW(BUFI)                                                                  \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) raw[(BUFI) * RAW_BUF + tid + NT * k] = rreg[k];
 
     f32x16 acc[16];
 #pragma unroll
@@ -258,11 +258,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // The stages run across item boundaries (nch >= 3), so the next item's pipeline fill overlaps this item's last
     // chunks; only the output transform + store of an item is serial.  Past the last item the stages re-stage its
     // first chunks into buffers nobody reads any more.
-    DMH_WINO_ITEM_CONSTS(item0, roff, rvalid, xb, usrc)
-    DMH_WINO_LOAD_RAW(xb, roff)
-    DMH_WINO_GLDS_U(usrc, 0)
-    DMH_WINO_WRITE_RAW(0, rvalid)
-    DMH_WINO_LOAD_RAW(xb + (size_t)CK * HW, roff)
+    const unsigned chunk_bytes = (unsigned)(CK * HW * 4);          // one chunk of 8 input channels
+    const unsigned uchunk_bytes = (unsigned)(32 * a.Kp * 16);      // one filter chunk
+    DMH_WINO_ITEM_CONSTS(item0, roff, uoff)
+    DMH_WINO_LOAD_RAW(0u, roff)
+    DMH_WINO_GLDS_U(uoff, 0)
+    DMH_WINO_WRITE_RAW(0)
+    DMH_WINO_LOAD_RAW(chunk_bytes, roff)
     __syncthreads();
     {   // T(0)
         float t[2][4][4];
@@ -292,15 +294,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     }
     if (FLAT) __syncthreads();          // single raw buffer: every wave has transformed chunk 0 out of it
-    DMH_WINO_WRITE_RAW(1, rvalid)
-    DMH_WINO_LOAD_RAW(xb + (size_t)2 * CK * HW, roff)
+    DMH_WINO_WRITE_RAW(1)
+    DMH_WINO_LOAD_RAW(2u * chunk_bytes, roff)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_PER_T) : "memory");   // the LDS-DMA of U[0] has landed
     __syncthreads();
 
     int g = 0;
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
-        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), roff_n, rvalid_n, xb_n, usrc_n)
+        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n)
         for (int ch = 0; ch < nch; ++ch, ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
             const f32x4* Uc = U_lds + cur * BUF + aidx;
@@ -310,9 +312,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // load-stage operands of this iteration: raw chunk ch+3 and filter chunk ch+1, possibly of the next item;
             // the raw registers written to LDS in this iteration hold chunk ch+2
             const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
-            const float* xc = (r_next ? xb_n + (size_t)(ch + 3 - nch) * CK * HW : xb + (size_t)(ch + 3) * CK * HW);
-            const f32x4* uc = (u_next ? usrc_n : usrc + (size_t)(ch + 1) * 32 * a.Kp);
-            const unsigned rv = (ch + 2 >= nch) ? rvalid_n : rvalid;
+            const unsigned xcb = (unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes;   // raw chunk ch+3: byte offset in its item
+            const unsigned ucb = u_next ? uoff_n : uoff + (unsigned)(ch + 1) * uchunk_bytes;
             // The block is written in issue order and fenced (sched_barrier) per SLOT = 2 MFMAs on two alternating
             // accumulators (128 cycles of matrix pipe) + one operand read for the next position pair + a few
             // instructions of staging work, so that no gap between MFMAs carries more than the pipe can shadow.
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     if (ks == 3) vb[p1 + 2] = Vc[(p1 + 2) * 128];
                 }
                 if (sl < 8) {                               // filter chunk g+1 -> U[nxt] by LDS-DMA, one row per slot
-                    if (!(DMH_WINO_ABLATE & 1)) DMH_WINO_GLDS_U_ROW(uc, nxt, sl)
+                    if (!(DMH_WINO_ABLATE & 1)) DMH_WINO_GLDS_U_ROW(ucb, nxt, sl)
                 } else if (DMH_WINO_ABLATE & 2) {
                 } else if ((sl >= 8 && sl < 12) || (sl >= 14 && sl < 18)) {   // raw patch row of channel 0 / 1
                     const int c2 = sl >= 14, i = c2 ? sl - 14 : sl - 8;
@@ -371,8 +372,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (sl >= 28) {                             // raw registers -> LDS, then refill them (4 slots)
 #pragma unroll
                     for (int k = (sl - 28) * ((RAW_PER_T + 3) / 4); k < min((sl - 27) * ((RAW_PER_T + 3) / 4), RAW_PER_T); ++k) {
-                        if (!(DMH_WINO_ABLATE & 4)) raw[cur * RAW_BUF + tid + NT * k] = (rv >> k) & 1u ? rreg[k] : 0.f;
-                        if (!(DMH_WINO_ABLATE & 1)) rreg[k] = xc[r_next ? roff_n[k] : roff[k]];
+                        if (!(DMH_WINO_ABLATE & 4)) raw[cur * RAW_BUF + tid + NT * k] = rreg[k];
+                        if (!(DMH_WINO_ABLATE & 1)) rreg[k] = ldb(xrs, r_next ? roff_n[k] : roff[k], xcb);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -469,9 +470,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
 #pragma unroll
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
-        rvalid = rvalid_n;
-        xb = xb_n;
-        usrc = usrc_n;
+        uoff = uoff_n;
     }
 }
 
@@ -559,6 +558,7 @@ static int wino_conv_common(const float* x, const float* U, const float* bias, c
     const int Ho = H + 2 * pad - 2, Wo = W + 2 * pad - 2;
     DMH_REQUIRE(Ho >= 2 && Wo >= 2 && (Ho & 1) == 0 && (Wo & 1) == 0, "output height and width must be even");
     DMH_REQUIRE((int64_t)C * H * W < ((int64_t)1 << 31) && (int64_t)K * Ho * Wo < ((int64_t)1 << 31), "image too large");
+    DMH_REQUIRE((int64_t)B * C * H * W < ((int64_t)1 << 30), "input larger than 4 GB (32-bit byte offsets of the buffer loads)");
     WArgs a;
     a.x = x; a.U = reinterpret_cast<const f32x4*>(U); a.bias = bias; a.res = residual; a.relu = relu; a.y = y;
     a.B = B; a.C = C; a.K = K; a.Kp = (K + 63) / 64 * 64; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad = pad;

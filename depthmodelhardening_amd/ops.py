@@ -853,9 +853,8 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
 def _wino32_ok(B, n_in, n_out, Ho, Wo):
     """Shapes of K17, the 32-output-channel form of K10 (work item 32 channels x 4 x 32 tiles): output channels a multiple
     of 32 that K10's 64-channel items would half-fill, enough items to cover the chip and few empty tiles."""
-    if not WINO_ENABLED or n_in % 8 or n_in < 64 or n_out % 32 or n_out % 64 == 0 or n_out > 96 or Ho % 2 or Wo % 2:
-        return False        # n_in < 64: items of <= 7 chunks do not amortise their epilogue (32 -> 96 backward-data of
-                            # upconv(1,1): 559 us against MIOpen's 558, tools/wino32_bench.py) -- those stay on MIOpen
+    if not WINO_ENABLED or n_in % 8 or n_in < 32 or n_out % 32 or n_out % 64 == 0 or n_out > 96 or Ho % 2 or Wo % 2:
+        return False        # (32 -> 96, the backward-data pass of upconv(1,1): 509 us against MIOpen's 566, tools/wino32_bench.py)
     ht, wt = Ho // 2, Wo // 2
     rows, cols = -(-ht // 4) * 4, -(-wt // 32) * 32
     if ht * wt < 0.8 * rows * cols:

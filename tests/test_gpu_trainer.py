@@ -349,14 +349,14 @@ def test_wino32_conv3x3_kernel_vs_aten(shape):
 
 
 def test_conv3x3_op_takes_k17_for_the_32_channel_decoder_layers():
-    """ops.conv3x3 dispatch: 96 -> 32 at a shape with enough work items goes to K17 in the forward pass; results and all three
-    gradients == ATen."""
+    """ops.conv3x3 dispatch: 96 -> 32 at a shape with enough work items goes to K17, forward and backward-data; results and
+    all three gradients == ATen."""
     import torch.nn.functional as F
     from depthmodelhardening_amd import ops
     g = torch.Generator(device="cuda").manual_seed(4)
-    B, C, K, H, W = 12, 96, 32, 82, 258
+    B, C, K, H, W = 12, 96, 32, 162, 258
     assert ops._wino32_ok(B, C, K, H - 2, W - 2) and not ops._wino_ok(B, C, K, H - 2, W - 2)
-    assert not ops._wino32_ok(B, K, C, H, W)            # the 32 -> 96 backward-data pass stays on MIOpen (no gain measured)
+    assert ops._wino32_ok(B, K, C, H, W)                # ... and so does the 32 -> 96 backward-data pass
     x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
     w = ((torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.1).requires_grad_(True)
     bias = (torch.rand(K, device="cuda", generator=g) - 0.5).requires_grad_(True)
@@ -366,7 +366,7 @@ def test_conv3x3_op_takes_k17_for_the_32_channel_decoder_layers():
     gx, gw, gb = torch.autograd.grad(y, (x, w, bias), gy)
     launches = ops.profile_bytes()
     ops.enable_profile(False)
-    assert launches["wino32_conv3x3"][0] == 1          # the forward pass
+    assert launches["wino32_conv3x3"][0] == 2          # forward + backward-data
     xr, wr, br = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
     yr = F.conv2d(xr, wr, br)
     gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), gy)
