@@ -354,7 +354,7 @@ def test_conv3x3_op_takes_k17_for_the_32_channel_decoder_layers():
     import torch.nn.functional as F
     from depthmodelhardening_amd import ops
     g = torch.Generator(device="cuda").manual_seed(4)
-    B, C, K, H, W = 12, 96, 32, 162, 258
+    B, C, K, H, W = 12, 96, 32, 162, 514
     assert ops._wino32_ok(B, C, K, H - 2, W - 2) and not ops._wino_ok(B, C, K, H - 2, W - 2)
     assert ops._wino32_ok(B, K, C, H, W)                # ... and so does the 32 -> 96 backward-data pass
     x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
