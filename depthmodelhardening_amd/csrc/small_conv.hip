@@ -54,67 +54,49 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
     const float* xb = a.x + (size_t)b * a.n_in * HW;      // n_in <= C: missing channels are staged as zeros
 
     // ---- stage the input tile: rows oy0-pad .. +RH, cols ox0-pad .. +RW of every channel (zero outside the image).
-    //      All loads are issued before the first LDS write, so their latencies overlap.  Two index schemes, chosen by
-    //      measurement (tools/wino_bench.py): flat element index for 16 channels, one wave-load per (channel, row) with
-    //      scalar row arithmetic for 32.
-    if (NQ <= 4) {
-        constexpr int PER_T = (C * RH * RW + NT - 1) / NT;
-        float stage[PER_T];
-#pragma unroll
-        for (int k = 0; k < PER_T; ++k) {
-            const int e = tid + NT * k;
-            const int c = e / (RH * RW), rem = e - c * (RH * RW), r = rem / RW, xx = rem - r * RW;
-            const int iy = oy0 - a.pad + r, ix = ox0 - a.pad + xx;
-            const bool ok = e < C * RH * RW && c < a.n_in && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-            const int cy = min(max(iy, 0), a.H - 1), cx = min(max(ix, 0), a.W - 1);
-            const float v = (DMH_SMALL_ABLATE & 1) ? 1.f : xb[(size_t)(ok ? c : 0) * HW + (size_t)cy * a.W + cx];
-            stage[k] = ok ? v : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < PER_T; ++k) {
-            const int e = tid + NT * k;
-            const int c = e / (RH * RW), rem = e - c * (RH * RW);
-            if (e < C * RH * RW) tile[c * CS + rem] = stage[k];
-        }
-    } else {
-        constexpr int NROWS = C * RH, ROWS_PER_W = (NROWS + 3) / 4, TAILS = (2 * NROWS + NT - 1) / NT;
+    //      Wave w stages channels [NQ w, NQ w + NQ): one 64-column wave-load per (channel, row) through a buffer resource
+    //      -- the row's byte offset is SALU arithmetic in an SGPR, the per-lane column offset a loop-invariant register
+    //      whose out-of-range value (0xFFFFFFFF: reads 0) IS the zero padding -- and an LDS write at an immediate
+    //      offset from one per-lane base.  One vector instruction per row (the select between the column offset and the
+    //      out-of-range offset for rows outside the image); round 2's flat element index cost ~35 per ELEMENT (index
+    //      decomposition, clamps, 64-bit addresses, masks): 1,900 vector instructions per thread ahead of 288 MFMAs that
+    //      share the same pipe.  The two halo columns 64, 65 of every row: a flat pass of <= 3 elements per thread.
+    //      All loads are issued before the first LDS write, so their latencies overlap.
+    {
+        constexpr int RPW = NQ * RH;                               // rows staged per wave
+        constexpr int TAILS = (2 * C * RH + NT - 1) / NT;
         const int wvu = __builtin_amdgcn_readfirstlane(wv);
-        float stage[ROWS_PER_W], tail[TAILS];
-        {
-            const int ix = ox0 - a.pad + lane;
-            const bool okx = ix >= 0 && ix < a.W;
-            const unsigned cx = (unsigned)min(max(ix, 0), a.W - 1);
-    #pragma unroll
-            for (int k = 0; k < ROWS_PER_W; ++k) {
-                const int rr = wvu + 4 * k, c = rr / RH, r = rr - c * RH, iy = oy0 - a.pad + r;
-                const bool ok = rr < NROWS && iy >= 0 && iy < a.H;
-                const float* rowp = xb + (size_t)(rr < NROWS ? c : 0) * HW + (size_t)min(max(iy, 0), a.H - 1) * a.W;
-                const float v = rowp[cx];
-                stage[k] = (ok && okx) ? v : 0.f;
-            }
-    #pragma unroll
-            for (int k = 0; k < TAILS; ++k) {
-                const int e = tid + NT * k, rr = e >> 1, c = rr / RH, r = rr - c * RH;
-                const int iy = oy0 - a.pad + r, ix2 = ox0 - a.pad + 64 + (e & 1);
-                const bool ok = rr < NROWS && iy >= 0 && iy < a.H && ix2 >= 0 && ix2 < a.W;
-                const float v = xb[(size_t)(rr < NROWS ? c : 0) * HW + (size_t)min(max(iy, 0), a.H - 1) * a.W +
-                                   min(max(ix2, 0), a.W - 1)];
-                tail[k] = ok ? v : 0.f;
-            }
-    #pragma unroll
-            for (int k = 0; k < ROWS_PER_W; ++k) {
-                const int rr = wvu + 4 * k, c = rr / RH, r = rr - c * RH;
-                if (rr < NROWS) tile[c * CS + r * RW + lane] = stage[k];
-            }
-    #pragma unroll
-            for (int k = 0; k < TAILS; ++k) {
-                const int e = tid + NT * k, rr = e >> 1, c = rr / RH, r = rr - c * RH;
-                if (rr < NROWS) tile[c * CS + r * RW + 64 + (e & 1)] = tail[k];
-            }
+        const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.n_in * HW * 4));
+        const int ix = ox0 - a.pad + lane;
+        const unsigned col_off = (ix >= 0 && ix < a.W) ? (unsigned)ix * 4u : 0xFFFFFFFFu;
+        float stage[RPW], tail[TAILS];
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int c = NQ * wvu + k / RH, iy = oy0 - a.pad + (k % RH);          // uniform
+            const bool ok = c < a.n_in && iy >= 0 && iy < a.H;
+            const unsigned rowb = (unsigned)(((b * a.n_in + (ok ? c : 0)) * a.H + (ok ? iy : 0)) * a.W) * 4u;
+            stage[k] = (DMH_SMALL_ABLATE & 1) ? 1.f : ldb(xrs, ok ? col_off : 0xFFFFFFFFu, rowb);
+        }
+#pragma unroll
+        for (int k = 0; k < TAILS; ++k) {
+            const int e = tid + NT * k, rr = e >> 1, c = rr / RH, r = rr - c * RH;
+            const int iy = oy0 - a.pad + r, ix2 = ox0 - a.pad + 64 + (e & 1);
+            const bool ok = rr < C * RH && c < a.n_in && iy >= 0 && iy < a.H && ix2 >= 0 && ix2 < a.W;
+            tail[k] = ldb(xrs, ok ? (unsigned)(((b * a.n_in + c) * a.H + iy) * a.W + ix2) * 4u : 0xFFFFFFFFu, 0u);
+        }
+        float* const dst = tile + NQ * wvu * CS + lane;
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) dst[(k / RH) * CS + (k % RH) * RW] = stage[k];
+#pragma unroll
+        for (int k = 0; k < TAILS; ++k) {
+            const int e = tid + NT * k, rr = e >> 1, c = rr / RH, r = rr - c * RH;
+            if (rr < C * RH) tile[c * CS + r * RW + 64 + (e & 1)] = tail[k];
         }
     }
 
-    // ---- the filter of this lane: A operand of mfma 16x16x4 = W[kout = lane & 15][channel = 4q + (lane >> 4)]
+    // ---- the filter of this lane: A operand of mfma 16x16x4 = W[kout = lane & 15][channel = 4q + (lane >> 4)]; nine taps
+    //      at immediate offsets from one per-(block, quad) offset, out of range (= 0) for channels the layer does not have
+    const rsrc_t wrs = make_rsrc(a.w, (unsigned)((size_t)a.Kw * a.Cw * 9 * 4));
     float wreg[NKB][NQ][9];
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb) {
@@ -122,13 +104,12 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int ci = 4 * q + (lane >> 4);
+            const bool ok = ko < a.n_out && ci < a.n_in;
+            // forward: w[ko][ci][t]; backward-data: w[ci][ko][8 - t] (flipped, channel roles swapped)
+            // (out-of-range base 0x80000000: adding the tap's immediate offset cannot wrap back into the filter)
+            const unsigned wo = ok ? (unsigned)((a.backward ? ci * a.Cw + ko : ko * a.Cw + ci) * 9) * 4u : 0x80000000u;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                float v = 0.f;
-                if (ko < a.n_out && ci < a.n_in)
-                    v = a.backward ? a.w[((size_t)ci * a.Cw + ko) * 9 + (8 - t)] : a.w[((size_t)ko * a.Cw + ci) * 9 + t];
-                wreg[kb][q][t] = v;
-            }
+            for (int t = 0; t < 9; ++t) wreg[kb][q][t] = ldb(wrs, wo + 4u * (unsigned)(a.backward ? 8 - t : t), 0u);
         }
     }
     __syncthreads();
@@ -210,6 +191,7 @@ int dmh_conv3x3_small(const float* x, const float* w, const float* bias, int B, 
     DMH_REQUIRE(a.Ho >= 1 && a.Wo >= 1, "image smaller than the filter");
     DMH_REQUIRE((int64_t)a.n_in * H * W < ((int64_t)1 << 31) && (int64_t)a.n_out * a.Ho * a.Wo < ((int64_t)1 << 31),
                 "image too large");
+    DMH_REQUIRE((int64_t)B * a.n_in * H * W < ((int64_t)1 << 30), "input larger than 4 GB (32-bit byte offsets of the buffer loads)");
     hipStream_t st = (hipStream_t)stream;
     if (a.n_in <= 4 && a.n_out <= 16) return launch<1, 1, 8>(a, st);      // disparity-head backward: 1 -> 16
     if (a.n_in <= 4 && a.n_out <= 32) return launch<1, 2, 8>(a, st);

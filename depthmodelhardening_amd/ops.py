@@ -903,6 +903,8 @@ def _small_ok(n_in, n_out):
 
 def _small_conv(x, weight, bias, pad, backward):
     lib = N.lib()
+    if x.numel() >= (1 << 30):
+        raise RuntimeError("conv3x3_small: input larger than 4 GB")
     B, _, H, W = x.shape
     Kw, Cw = weight.shape[0], weight.shape[1]
     n_out = Cw if backward else Kw
