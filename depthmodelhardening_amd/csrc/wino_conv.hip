@@ -29,6 +29,8 @@
 //                   (conv + eval BatchNorm + identity + ReLU in one launch), 2-way channel split for small launches.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 using namespace dmh;
@@ -242,11 +244,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #define DMH_WINO_WRITE_RAW(BUFI)                                                                  \
     _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) raw[(BUFI) * RAW_BUF + tid + NT * k] = rreg[k];
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+    f32x16 acc[16];         // never cleared: the first chunk of an item multiplies onto a zero C operand (an inline constant)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // Software pipeline over the flattened (item, chunk) sequence, ONE barrier and ONE fenced block per chunk.
     // Iteration g = item * nch + ch runs
@@ -303,7 +302,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
         DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n)
-        for (int ch = 0; ch < nch; ++ch, ++g) {
+        // one chunk; FIRST: the item's first chunk, whose first MFMA per position starts the accumulation from zero
+        auto chunk = [&](const int ch, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const int cur = g & 1, nxt = cur ^ 1;
             const f32x4* Uc = U_lds + cur * BUF + aidx;
             const f32x4* Vc = V_lds + cur * BUF + bidx;
@@ -330,8 +331,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int sl = 0; sl < 32; ++sl) {
                 const int p0 = 2 * (sl >> 2), p1 = p0 + 1, ks = sl & 3;
-                acc[p0] = DMH_MFMA(ua[p0][ks], vb[p0][ks], acc[p0]);
-                acc[p1] = DMH_MFMA(ua[p1][ks], vb[p1][ks], acc[p1]);
+                if (FIRST && ks == 0) {
+                    acc[p0] = DMH_MFMA(ua[p0][ks], vb[p0][ks], zero16);
+                    acc[p1] = DMH_MFMA(ua[p1][ks], vb[p1][ks], zero16);
+                } else {
+                    acc[p0] = DMH_MFMA(ua[p0][ks], vb[p0][ks], acc[p0]);
+                    acc[p1] = DMH_MFMA(ua[p1][ks], vb[p1][ks], acc[p1]);
+                }
                 if (p0 + 2 < 16) {                          // operands of the next position pair, one read per slot
                     if (ks == 0) ua[p0 + 2] = Uc[(p0 + 2) * 128];
                     if (ks == 1) vb[p0 + 2] = Vc[(p0 + 2) * 128];
@@ -384,8 +390,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RAW_PER_T) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-        }
-        // ---- item done: output transform  Y = A^T M A, store, clear the accumulators; lane -> tile,
+            ++g;
+        };
+        chunk(0, std::true_type());
+        for (int ch = 1; ch < nch; ++ch) chunk(ch, std::false_type());
+        // ---- item done: output transform  Y = A^T M A, store; lane -> tile,
         //      register -> output channel
         {
             const Item it = decode_item<TRW>(a, item);
@@ -463,10 +472,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 }
                 __builtin_amdgcn_sched_barrier(0);   // one output channel at a time: hoisted accumulator reads spill
             }
-#pragma unroll
-            for (int pp = 0; pp < 16; ++pp)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[pp][v] = 0.f;
         }
 #pragma unroll
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
