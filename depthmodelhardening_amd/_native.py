@@ -92,6 +92,8 @@ _SIGNATURES = {
     "dmh_wino32_weight_size": (C.c_int64, [C.c_int, C.c_int]),
     "dmh_wino32_weight_transform": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "dmh_wino32_conv3x3": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp]),
+    "dmh_wino_wrw_workspace_size": (C.c_int64, [C.c_int] * 6),
+    "dmh_wino_wrw": (C.c_int, [_fp, _fp] + [C.c_int] * 6 + [_fp, _fp, _fp]),
     "dmh_conv3x3_small": (C.c_int, [_fp] * 3 + [C.c_int] * 7 + [_fp, _fp]),
     "dmh_conv3x3_head": (C.c_int, [_fp] * 3 + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_conv3x3_head_bwd_data": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [_fp, _fp]),

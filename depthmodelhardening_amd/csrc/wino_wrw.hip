@@ -1,0 +1,336 @@
+// K18 -- weight gradient of the 3x3 stride-1 convolutions with >= 64 channels on both sides, in the Winograd F(2x2, 3x3)
+// domain on v_mfma_f32_32x32x2_f32 (the train pass of MD2/networks/resnet_encoder.py:85-98 BasicBlocks and of the decoder's
+// Conv3x3, MD2/layers.py:127-141; autograd's aten.convolution_backward(..., [False, True, False])).
+//
+// Why: through round 2 these weight gradients were MIOpen's NHWC implicit GEMMs (12.2 ms per step at 75-114 TFLOP/s) wrapped
+// in layout transposes (2.9 ms), and their atomics made the training step irreproducible in the last bits.  With
+//     Y = A^T [ (G g G^T) .* (B^T d B) ] A        the gradient is       dg = G^T [ sum_tiles (A dY A^T) .* (B^T d B) ] G,
+// i.e. per transform position p one GEMM  dU_p[k][c] = sum_t dM_p[k][t] * V_p[c][t]  whose reduction axis is the TILE index:
+// 16/36 of the multiplications of the direct form, on the same fp32 MFMA and with the same LDS images as K10.
+//
+//   * workgroup   : one (64 output channels) x (64 input channels) block of dU, all 16 positions = 65,536 accumulators = 256
+//                   registers per lane (wave w: channel sub-block (w & 1, w >> 1)); it walks a contiguous slice of the
+//                   tile chunks and never leaves its accumulators: no per-item epilogue at all.
+//   * chunk       : 8 consecutive tiles of one tile row (2 x 16 output-gradient pixels, 4 x 18 input pixels) of the 64 + 64
+//                   channels.  Raw rows through registers into LDS (buffer loads: uniform row offsets in SGPRs, an
+//                   out-of-range offset = zero padding = masked ragged edge), both transforms LDS -> LDS into the images
+//                   dM[p][h][k][4], V[p][h][c][4] (h + 2s = tile: a 16-byte operand read feeds 4 k-steps, as in K10),
+//                   64 MFMAs per wave.  Images single-buffered, raw rows double-buffered: MFMA phase / transform phase with
+//                   two barriers per chunk (K17's scheme; the fp32 MFMA shares the vector pipe, so nothing is lost by
+//                   taking the transforms out from between the MFMAs).
+//   * split       : the 256 workgroups are dealt over the (k-block, c-block) pairs, each pair's chunks split into equal
+//                   contiguous slices; every workgroup stores its partial dU, and wino_wrw_reduce_kernel adds the slices in
+//                   a fixed order and applies G^T . G  -> dw[K][C][3][3].  No atomics: bitwise reproducible.
+#include <stdlib.h>
+
+#include "common.hpp"
+
+using namespace dmh;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 256;
+constexpr int TPC = 8;                       // tiles per chunk
+constexpr int XC = 2 * TPC + 2;              // 18 input columns, 4 rows
+constexpr int DC = 2 * TPC;                  // 16 gradient columns, 2 rows
+constexpr int XCS = 4 * XC + 2;              // raw channel strides in floats: == 2 (mod 8), odd multiples of 2 -> the 8-byte
+constexpr int DCS = 2 * DC + 2;              //   transform reads of 32 lanes (one channel each) hit 32 different bank pairs
+constexpr int XRAW = 64 * XCS, DRAW = 64 * DCS;
+constexpr int RAWBUF = XRAW + DRAW;          // floats per raw buffer (27 KB)
+constexpr int IMG = 16 * 2 * 64;             // f32x4 words of one image (32 KB)
+constexpr int NXL = 32, NDL = 4;             // raw loads per thread and chunk: x (8 channels x 32 column slots), dy (32 channels x 8 column pairs)
+
+struct RArgs {
+    const float* x;
+    const float* dy;
+    float* ws;                  // [pairs][S][16][64][64]
+    int B, C, K, H, W, Ho, Wo, pad;
+    int Ht, cpr;                // rows of tiles per image, chunks per tile row
+    int nchunks, nk, nc, S, cps;   // chunks in total; channel blocks; slices per pair; chunks per slice
+};
+
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wrw_kernel(RArgs a) {
+    extern __shared__ f32x4 smem[];
+    f32x4* M_lds = smem;                                         // dM image [16][2][64]
+    f32x4* V_lds = smem + IMG;                                   // V image  [16][2][64]
+    float* raw = reinterpret_cast<float*>(smem + 2 * IMG);       // [2][ x: 64 x XCS | dy: 64 x DCS ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int wv_s = __builtin_amdgcn_readfirstlane(wv);
+    const int HW = a.H * a.W, HoWo = a.Ho * a.Wo;
+    const int pair = (int)blockIdx.x / a.S, slice = (int)blockIdx.x - pair * a.S;
+    const int kb = pair / a.nc, cb = pair - kb * a.nc;
+    const int c_first = slice * a.cps, c_end = min(c_first + a.cps, a.nchunks);
+    const int n = c_end - c_first;                               // may be <= 0: the block then only stores zeros
+
+    const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.C * HW * 4));
+    const rsrc_t drs = make_rsrc(a.dy, (unsigned)((size_t)a.B * a.K * HoWo * 4));
+    // per-thread parts of the raw offsets: x load k covers channels 8 (k >> 2) + (tid >> 5), row k & 3, column slot
+    // tid & 31 (18 used); dy load k (8 bytes: columns 2 (tid & 7), + 1) covers channels 32 (k >> 1) + (tid >> 3), row k & 1
+    const int xcol = tid & 31, xchl = tid >> 5, dpr = tid & 7, dchl = tid >> 3;
+    const unsigned x_lane = (unsigned)(xchl * HW + xcol) * 4u, d_lane = (unsigned)(dchl * HoWo + 2 * dpr) * 4u;
+    float* const xdst = raw + xchl * XCS + xcol;                 // + (8 (k >> 2)) * XCS + (k & 3) * XC
+    float* const ddst = raw + XRAW + dchl * DCS + 2 * dpr;       // + (32 (k >> 1)) * DCS + (k & 1) * DC
+
+    float rx[NXL];
+    float2 rd[NDL];
+    // issue the raw loads of chunk `ch` (clamped to the slice: past its end the last chunk is re-read and never used)
+    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+        ch = min(max(ch, c_first), max(c_end - 1, c_first));
+        ch = min(ch, a.nchunks - 1);
+        const int b = ch / (a.Ht * a.cpr), rem = ch - b * (a.Ht * a.cpr), ty = rem / a.cpr, tx0 = (rem - ty * a.cpr) * TPC;
+        const int iy0 = 2 * ty - a.pad, ix0 = 2 * tx0 - a.pad;
+        const int ix = ix0 + xcol;
+        const unsigned xl = (xcol < XC && ix >= 0 && ix < a.W) ? x_lane + (unsigned)(ix0 * 4) : 0xFFFFFFFFu;
+        // the row validity is uniform: one select per ROW of the region, not per load
+        unsigned xlr[4], sbr[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int iy = iy0 + r;
+            const bool ok = iy >= 0 && iy < a.H;
+            xlr[r] = ok ? xl : 0xFFFFFFFFu;
+            sbr[r] = ok ? (unsigned)(iy * a.W) * 4u : 0u;
+        }
+        // gradient columns come in aligned pairs (Wo is even): a pair is inside or outside as a whole
+        const unsigned dl = (2 * tx0 + 2 * dpr < a.Wo) ? d_lane : 0xFFFFFFFFu;
+        const unsigned xbase = (unsigned)((b * a.C + cb * 64) * HW) * 4u;
+        const unsigned dbase = (unsigned)((b * a.K + kb * 64) * HoWo + 2 * ty * a.Wo + 2 * tx0) * 4u;
+#pragma unroll
+        for (int k = 0; k < NXL; ++k) rx[k] = ldb(xrs, xlr[k & 3], xbase + (unsigned)(8 * (k >> 2) * HW) * 4u + sbr[k & 3]);
+#pragma unroll
+        for (int k = 0; k < NDL; ++k) {
+            const unsigned so = dbase + (unsigned)((32 * (k >> 1)) * HoWo + (k & 1) * a.Wo) * 4u;
+            rd[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, dl, so, 0));
+        }
+    };
+    auto store_raw = [&](const int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NXL; ++k)
+            if (xcol < XC) xdst[buf * RAWBUF + (8 * (k >> 2)) * XCS + (k & 3) * XC] = rx[k];
+#pragma unroll
+        for (int k = 0; k < NDL; ++k)
+            *reinterpret_cast<float2*>(ddst + buf * RAWBUF + (32 * (k >> 1)) * DCS + (k & 1) * DC) = rd[k];
+    };
+    // transforms of one chunk: thread = (channel `lane`, tile pair h + 4j, h + 4j + 2) with h = wv & 1, j = wv >> 1; the two
+    // tiles are components 2j, 2j + 1 of the channel's 16-byte image word -> one 8-byte write per position
+    const int th = wv & 1, tj = wv >> 1;
+    auto transform = [&](const int buf) __attribute__((always_inline)) {
+        const float* xs = raw + buf * RAWBUF + lane * XCS + 2 * (th + 4 * tj);        // tile A; tile B: + 4 columns
+        const float* ds = raw + buf * RAWBUF + XRAW + lane * DCS + 2 * (th + 4 * tj);
+        float* const md = reinterpret_cast<float*>(M_lds + th * 64 + lane) + 2 * tj;
+        float* const vd = reinterpret_cast<float*>(V_lds + th * 64 + lane) + 2 * tj;
+        {   // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+            float m[2][4][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float2 r0 = *reinterpret_cast<const float2*>(ds + 4 * t), r1 = *reinterpret_cast<const float2*>(ds + DC + 4 * t);
+                const float u[4][2] = {{r0.x, r0.y}, {r0.x + r1.x, r0.y + r1.y}, {r0.x - r1.x, r0.y - r1.y}, {-r1.x, -r1.y}};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    m[t][i][0] = u[i][0];
+                    m[t][i][1] = u[i][0] + u[i][1];
+                    m[t][i][2] = u[i][0] - u[i][1];
+                    m[t][i][3] = -u[i][1];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float2*>(md + (i * 4 + j) * 512) = make_float2(m[0][i][j], m[1][i][j]);
+        }
+        {   // V = B^T d B
+            float v[2][4][4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float d[4][4], q[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float2 lo = *reinterpret_cast<const float2*>(xs + i * XC + 4 * t);
+                    const float2 hi = *reinterpret_cast<const float2*>(xs + i * XC + 4 * t + 2);
+                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q[0][j] = d[0][j] - d[2][j];
+                    q[1][j] = d[1][j] + d[2][j];
+                    q[2][j] = d[2][j] - d[1][j];
+                    q[3][j] = d[1][j] - d[3][j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[t][i][0] = q[i][0] - q[i][2];
+                    v[t][i][1] = q[i][1] + q[i][2];
+                    v[t][i][2] = q[i][2] - q[i][1];
+                    v[t][i][3] = q[i][1] - q[i][3];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    *reinterpret_cast<float2*>(vd + (i * 4 + j) * 512) = make_float2(v[0][i][j], v[1][i][j]);
+        }
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+    const int ki = wv & 1, ci = wv >> 1;
+    const f32x4* const Uc = M_lds + (lane >> 5) * 64 + ki * 32 + (lane & 31);
+    const f32x4* const Vc = V_lds + (lane >> 5) * 64 + ci * 32 + (lane & 31);
+
+    if (n > 0) {
+        // prologue: chunk 0 -> raw[0] -> images; chunk 1 -> raw[1]; chunk 2 in registers
+        load_chunk(c_first);
+        store_raw(0);
+        load_chunk(c_first + 1);
+        __syncthreads();
+        transform(0);
+        store_raw(1);
+        load_chunk(c_first + 2);
+        __syncthreads();
+        for (int g = 0; g < n; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            f32x4 ua[16], vb[16];
+            ua[0] = Uc[0]; vb[0] = Vc[0];
+            ua[1] = Uc[128]; vb[1] = Vc[128];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int sl = 0; sl < 32; ++sl) {
+                const int p0 = 2 * (sl >> 2), p1 = p0 + 1, ks = sl & 3;
+                acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], acc[p0], 0, 0, 0);
+                acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], acc[p1], 0, 0, 0);
+                if (p0 + 2 < 16) {                          // operands of the next position pair, one read per slot
+                    if (ks == 0) ua[p0 + 2] = Uc[(p0 + 2) * 128];
+                    if (ks == 1) vb[p0 + 2] = Vc[(p0 + 2) * 128];
+                    if (ks == 2) ua[p1 + 2] = Uc[(p1 + 2) * 128];
+                    if (ks == 3) vb[p1 + 2] = Vc[(p1 + 2) * 128];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // raw registers (chunk g+2) -> raw[cur] (read by transform(g) one iteration ago), then refill with chunk g+3
+            store_raw(cur);
+            load_chunk(c_first + g + 3);
+            // raw s_barrier + lgkmcnt only: __syncthreads() would also wait for the loads just issued (vmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                   // every wave has read the images of chunk g
+            asm volatile("" ::: "memory");
+            transform(nxt);                                 // chunk g+1 (written to raw[nxt] one iteration ago)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    }
+    // ---- partial dU of this slice: ws[pair][slice][p][k 64][c 64]; D row (k) = 8 (v >> 2) + 4 (lane >> 5) + (v & 3), col (c) = lane & 31
+    float* wsb = a.ws + ((size_t)pair * a.S + slice) * (16 * 4096) + (size_t)(ki * 32 + 4 * (lane >> 5)) * 64 + ci * 32 + (lane & 31);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) wsb[(size_t)p * 4096 + ((v & 3) + 8 * (v >> 2)) * 64] = acc[p][v];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// dw[k][c][3][3] = G^T (sum over the slices of dU[.][k][c]) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; slices in order.
+// A block = 16 consecutive input channels of one output channel x the 16 positions: every thread adds the S slices of its
+// (c, p) (64-byte segments per slice), the 4 x 4 sums meet in LDS and 144 threads form one filter tap each.
+__global__ __launch_bounds__(NT) void wino_wrw_reduce_kernel(const float* __restrict__ ws, int K, int C, int nc, int S,
+                                                             float* __restrict__ dw) {
+    __shared__ float su[16][17];                        // [position][channel], padded
+    const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
+    const int cblocks = C >> 4;
+    const int k = (int)blockIdx.x / cblocks, c = ((int)blockIdx.x - k * cblocks) * 16 + cl;
+    const int pair = (k >> 6) * nc + (c >> 6);
+    const float* src = ws + (size_t)pair * S * (16 * 4096) + (size_t)p * 4096 + (size_t)(k & 63) * 64 + (c & 63);
+    float s = 0.f;
+    for (int q = 0; q < S; ++q) s += src[(size_t)q * (16 * 4096)];
+    su[p][cl] = s;
+    __syncthreads();
+    if (threadIdx.x < 144) {
+        const int cc = threadIdx.x / 9, tap = threadIdx.x - cc * 9, r = tap / 3, col = tap - r * 3;
+        // G^T row r and G column `col`: coefficients over the 4 transform rows / columns
+        const float gr[3][4] = {{1.f, 0.5f, 0.5f, 0.f}, {0.f, 0.5f, -0.5f, 0.f}, {0.f, 0.5f, 0.5f, 1.f}};
+        float o = 0.f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            float t = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t += su[a * 4 + b][cc] * gr[col][b];
+            o += gr[r][a] * t;
+        }
+        dw[((size_t)k * C + ((int)blockIdx.x - k * cblocks) * 16 + cc) * 9 + tap] = o;
+    }
+}
+
+int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+    }
+    return n;
+}
+
+void plan(RArgs& a) {
+    a.Ht = a.Ho / 2;
+    a.cpr = (a.Wo / 2 + TPC - 1) / TPC;
+    a.nchunks = a.B * a.Ht * a.cpr;
+    a.nk = a.K / 64;
+    a.nc = a.C / 64;
+    const int pairs = a.nk * a.nc;
+    int S = num_cus() / pairs;
+    if (S < 1) S = 1;
+    if (S > a.nchunks) S = a.nchunks;
+    a.S = S;
+    a.cps = (a.nchunks + S - 1) / S;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t dmh_wino_wrw_workspace_size(int B, int C, int K, int H, int W, int pad) {
+    if (B <= 0 || C <= 0 || K <= 0 || C % 64 || K % 64 || pad < 0 || pad > 2) return -1;
+    RArgs a;
+    a.B = B; a.C = C; a.K = K; a.H = H; a.W = W; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
+    if (a.Ho < 2 || a.Wo < 2 || (a.Ho & 1) || (a.Wo & 1)) return -1;
+    plan(a);
+    return (int64_t)a.nk * a.nc * a.S * 16 * 4096;
+}
+
+int dmh_wino_wrw(const float* x, const float* dy, int B, int C, int K, int H, int W, int pad, float* workspace, float* dw,
+                 void* stream) {
+    DMH_REQUIRE(x && dy && workspace && dw, "null pointer");
+    DMH_REQUIRE(B > 0 && C >= 64 && K >= 64 && C % 64 == 0 && K % 64 == 0, "channel counts must be multiples of 64");
+    DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
+    RArgs a;
+    a.x = x; a.dy = dy; a.ws = workspace;
+    a.B = B; a.C = C; a.K = K; a.H = H; a.W = W; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
+    DMH_REQUIRE(a.Ho >= 2 && a.Wo >= 2 && (a.Ho & 1) == 0 && (a.Wo & 1) == 0, "output height and width must be even");
+    DMH_REQUIRE((int64_t)B * C * H * W < ((int64_t)1 << 30) && (int64_t)B * K * a.Ho * a.Wo < ((int64_t)1 << 30),
+                "tensor larger than 4 GB (32-bit byte offsets of the buffer loads)");
+    plan(a);
+    constexpr size_t smem = (size_t)2 * IMG * 16 + (size_t)2 * RAWBUF * 4;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wrw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_wrw");
+        configured = true;
+    }
+    hipLaunchKernelGGL(wino_wrw_kernel, dim3((unsigned)(a.nk * a.nc * a.S)), dim3(NT), smem, (hipStream_t)stream, a);
+    if (int rc = check_launch("dmh_wino_wrw")) return rc;
+    hipLaunchKernelGGL(wino_wrw_reduce_kernel, dim3((unsigned)(K * (C / 16))), dim3(NT), 0, (hipStream_t)stream,
+                       workspace, K, C, a.nc, a.S, dw);
+    return check_launch("dmh_wino_wrw (reduce)");
+}
+
+}  // extern "C"

@@ -772,6 +772,7 @@ def stem_bn_relu_pool(x, scale, shift):
 # channels (tools/wino_bench.py, profiles/); everything else is the ATen/MIOpen convolution.
 # ---------------------------------------------------------------------------------------------------------------
 WINO_ENABLED = os.environ.get("DMH_WINO", "1") != "0"
+WRW_ENABLED = os.environ.get("DMH_WRW", "1") != "0"     # K18 (weight gradients); 0: MIOpen (A/B switch)
 _wino_frozen = 0
 _wino_cache = {}
 
@@ -848,6 +849,17 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     nch = n_in // 8
     split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
     return regions * split >= 200
+
+
+def _wrw_ok(x, g, K, Cc):
+    """Shapes of K18 (Winograd-domain weight gradient): both channel counts multiples of 64, even output size, enough tile
+    chunks (8 tiles) to give every workgroup of a (k-block, c-block) pair a few, tensors below 4 GB."""
+    if not WINO_ENABLED or not WRW_ENABLED or K % 64 or Cc % 64 or g.shape[2] % 2 or g.shape[3] % 2:
+        return False
+    if x.numel() >= (1 << 30) or g.numel() >= (1 << 30):
+        return False
+    chunks = g.shape[0] * (g.shape[2] // 2) * -(-(g.shape[3] // 2) // 8)
+    return chunks * (K // 64) * (Cc // 64) >= 1024
 
 
 def _wino32_ok(B, n_in, n_out, Ho, Wo):
@@ -987,6 +999,17 @@ class _Conv3x3(torch.autograd.Function):
             N.check(_timed("conv3x3_small_wrw", lambda: lib.dmh_conv3x3_small_wrw(
                 N.ptr(x), N.ptr(g), B, Cc, H, W, pad, N.ptr(part), N.ptr(g_w), N.ptr(g_b), N.stream()),
                 4 * (x.numel() + g.numel()), 2 * 9 * 16 * Cc * g.numel() // 16))
+            need_w = need_b = False
+        if need_w and _wrw_ok(x, g, K, Cc):
+            # >= 64 channels on both sides: K18, the weight gradient in the Winograd domain on the fp32 MFMA (MIOpen: NHWC
+            # implicit GEMMs between layout transposes, with atomics); the bias gradient is a plain reduction of g
+            lib = N.lib()
+            ws = torch.empty(lib.dmh_wino_wrw_workspace_size(B, Cc, K, H, W, pad), device=g.device, dtype=torch.float32)
+            g_w = torch.empty_like(weight)
+            N.check(_timed("wino_wrw", lambda: lib.dmh_wino_wrw(N.ptr(x), N.ptr(g), B, Cc, K, H, W, pad, N.ptr(ws), N.ptr(g_w),
+                                                                N.stream()), 4 * (x.numel() + g.numel()), 18 * Cc * g.numel()))
+            if need_b:
+                g_b = g.sum((0, 2, 3))
             need_w = need_b = False
         if need_x or need_w or need_b:
             r = torch.ops.aten.convolution_backward(g, x, weight, [K] if ctx.has_bias else None, [1, 1], [pad, pad], [1, 1],

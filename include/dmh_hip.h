@@ -316,6 +316,17 @@ int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B,
                        float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K18 weight gradient of a 3x3 stride-1 convolution with C and K multiples of 64, in the Winograd F(2x2,3x3) domain on the
+ *     fp32 MFMA: dw[K][C][3][3] = d/dw sum(dy * corr3x3(zero_pad(x, pad), w)) -- what autograd asks
+ *     aten.convolution_backward(dy, x, w, ..., [False, True, False]) for in the train pass (MD2/trainer.py:305-309 backward
+ *     through torchvision BasicBlock / MD2/layers.py:127-141 Conv3x3).  x [B,C,H,W], dy [B,K,H+2pad-2,W+2pad-2] (even sizes);
+ *     workspace: dmh_wino_wrw_workspace_size(...) floats (per-workgroup partial sums, added in a fixed order: no atomics).
+ * ---------------------------------------------------------------------------------- */
+int64_t dmh_wino_wrw_workspace_size(int B, int C, int K, int H, int W, int pad);
+int dmh_wino_wrw(const float* x, const float* dy, int B, int C, int K, int H, int W, int pad, float* workspace, float* dw,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K11 3x3 stride-1 convolution with few channels (<=4 -> <=32, 16 -> <=32 or 32 -> <=16) at full resolution, direct implicit
  *     GEMM on v_mfma_f32_16x16x4_f32 with the filter held in registers: the last decoder stage and the disparity heads
  *     (MD2/networks/depth_decoder.py:38-44).  w is the FORWARD filter [Kw][Cw][3][3] in both directions:

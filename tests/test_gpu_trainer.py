@@ -376,6 +376,61 @@ def test_conv3x3_op_takes_k17_for_the_32_channel_decoder_layers():
     torch.testing.assert_close(gb, gbr, rtol=1e-4, atol=1e-5 * float(gbr.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [
+    # B, C, K, Ho, Wo, pad
+    (2, 64, 64, 16, 32, 1),      # encoder-like: zero padding at all four borders, two chunks per tile row
+    (3, 128, 64, 10, 34, 0),     # decoder-like (pre-padded input): 17 tile columns = 2 chunks + 1 ragged tile
+    (1, 64, 128, 6, 16, 1),      # two k-blocks, one chunk per tile row, few chunks (more slices than chunks per pair)
+    (2, 64, 64, 4, 6, 2),        # pad 2, 3 tile columns in an 8-tile chunk
+])
+def test_wino_wrw_kernel_vs_aten(shape):
+    """K18 (Winograd-domain weight gradient on the fp32 MFMA) through the C ABI == ATen's convolution_backward weight
+    gradient; launched twice: bitwise reproducible (fixed-order reduction, no atomics)."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    B, C, K, Ho, Wo, pad = shape
+    H, W = Ho + 2 - 2 * pad, Wo + 2 - 2 * pad
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + C + K)
+    x = torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5
+    w = ((torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.2).requires_grad_(True)
+    gy = torch.rand(B, K, Ho, Wo, device="cuda", generator=g) - 0.5
+    ref = torch.autograd.grad(F.conv2d(x, w, None, padding=pad), w, gy)[0]
+
+    def run():
+        ws = torch.empty(lib.dmh_wino_wrw_workspace_size(B, C, K, H, W, pad), device="cuda")
+        dw = torch.full((K, C, 3, 3), float("nan"), device="cuda")
+        N.check(lib.dmh_wino_wrw(N.ptr(x), N.ptr(gy), B, C, K, H, W, pad, N.ptr(ws), N.ptr(dw), N.stream()))
+        return dw
+    got = run()
+    assert torch.equal(got, run())
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()))
+
+
+def test_conv3x3_op_weight_gradient_takes_k18():
+    """ops.conv3x3 at an encoder shape of the train pass: the weight gradient comes from K18 (one launch recorded), all three
+    gradients == ATen, and two backward passes give bit-identical weight gradients."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(6)
+    B, C, K, H, W = 8, 64, 64, 80, 256
+    x = (torch.rand(B, C, H, W, device="cuda", generator=g) - 0.5).requires_grad_(True)
+    w = ((torch.rand(K, C, 3, 3, device="cuda", generator=g) - 0.5) * 0.1).requires_grad_(True)
+    gy = torch.rand(B, K, H, W, device="cuda", generator=g) - 0.5
+    ops.enable_profile(True)
+    y = ops.conv3x3(x, w, None, 1)
+    gx, gw = torch.autograd.grad(y, (x, w), gy, retain_graph=True)
+    launches = ops.profile_bytes()
+    ops.enable_profile(False)
+    assert launches["wino_wrw"][0] == 1
+    gw2 = torch.autograd.grad(y, w, gy)[0]
+    assert torch.equal(gw, gw2)
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    gxr, gwr = torch.autograd.grad(F.conv2d(xr, wr, None, padding=1), (xr, wr), gy)
+    torch.testing.assert_close(gx, gxr, rtol=1e-5, atol=2e-6 * float(gxr.abs().max()))
+    torch.testing.assert_close(gw, gwr, rtol=1e-4, atol=1e-5 * float(gwr.abs().max()))
+
+
 def test_network_kernels_vs_formulation_oracle():
     """K10 / K11 / K12 through the C ABI == oracle/conv_ref.py (fp64 numpy restatement of the same formulations:
     Winograd tiles, backward filter, parity gather), on seeded inputs small enough for the oracle's Python loops."""
