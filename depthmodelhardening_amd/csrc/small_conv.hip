@@ -74,7 +74,9 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
         for (int k = 0; k < RPW; ++k) {
             const int c = NQ * wvu + k / RH, iy = oy0 - a.pad + (k % RH);          // uniform
             const bool ok = c < a.n_in && iy >= 0 && iy < a.H;
-            const unsigned rowb = (unsigned)(((b * a.n_in + (ok ? c : 0)) * a.H + (ok ? iy : 0)) * a.W) * 4u;
+            // (clamped, not selected, and pinned to an SGPR: a scalar offset in a VGPR makes the load a waterfall loop)
+            unsigned rowb = (unsigned)(((b * a.n_in + min(c, a.n_in - 1)) * a.H + min(max(iy, 0), a.H - 1)) * a.W) * 4u;
+            asm volatile("" : "+s"(rowb));
             stage[k] = (DMH_SMALL_ABLATE & 1) ? 1.f : ldb(xrs, ok ? col_off : 0xFFFFFFFFu, rowb);
         }
 #pragma unroll

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const f32x4* Uc = U_lds + cur * UBUF + aidx;
             const f32x4* Vc = V_lds + bidx;
             const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
-            const unsigned xcb = (unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes;
+            unsigned xcb = (unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes;
+            asm volatile("" : "+s"(xcb));          // a scalar offset parked in a VGPR would make every load a waterfall loop
             const unsigned ucb = u_next ? uoff_n : uoff + (unsigned)(ch + 1) * uchunk_bytes;
             f32x4 ua[16], vb[16];
             ua[0] = Uc[0]; vb[0] = Vc[0];

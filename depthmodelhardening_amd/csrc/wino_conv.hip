@@ -313,7 +313,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // load-stage operands of this iteration: raw chunk ch+3 and filter chunk ch+1, possibly of the next item;
             // the raw registers written to LDS in this iteration hold chunk ch+2
             const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
-            const unsigned xcb = (unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes;   // raw chunk ch+3: byte offset in its item
+            unsigned xcb = (unsigned)__builtin_amdgcn_readfirstlane(   // raw chunk ch+3: byte offset in its item
+                (int)((unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes));
+            // pinned to an SGPR: a scalar offset the compiler parks in a VGPR turns every load that uses it into a waterfall
+            // loop (readfirstlane + compare + branch) -- the FLAT instantiations did, 17 loops per chunk
+            asm volatile("" : "+s"(xcb));
             const unsigned ucb = u_next ? uoff_n : uoff + (unsigned)(ch + 1) * uchunk_bytes;
             // The block is written in issue order and fenced (sched_barrier) per SLOT = 2 MFMAs on two alternating
             // accumulators (128 cycles of matrix pipe) + one operand read for the next position pair + a few

@@ -32,6 +32,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef DMH_WRW_ABLATE      // timing experiments (tools/wrw_ablate.sh): 1 no global loads, 2 no transforms, 4 no raw LDS stores,
+#define DMH_WRW_ABLATE 0    // 8 no MFMAs, 16 no barriers in the loop (results are garbage)
+#endif
 constexpr int NT = 256;
 constexpr int TPC = 8;                       // tiles per chunk
 constexpr int XC = 2 * TPC + 2;              // 18 input columns, 4 rows
@@ -92,18 +95,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const int iy = iy0 + r;
             const bool ok = iy >= 0 && iy < a.H;
             xlr[r] = ok ? xl : 0xFFFFFFFFu;
-            sbr[r] = ok ? (unsigned)(iy * a.W) * 4u : 0u;
+            // the scalar offset of an invalid row is never used (its per-lane offset is out of range): clamp instead of
+            // select -- a select is evaluated on the vector ALU, lands in a VGPR and puts every load that uses it as its
+            // scalar offset into a waterfall loop (v_readfirstlane + compare + branch per load)
+            sbr[r] = (unsigned)(min(max(iy, 0), a.H - 1) * a.W) * 4u;
         }
         // gradient columns come in aligned pairs (Wo is even): a pair is inside or outside as a whole
         const unsigned dl = (2 * tx0 + 2 * dpr < a.Wo) ? d_lane : 0xFFFFFFFFu;
-        const unsigned xbase = (unsigned)((b * a.C + cb * 64) * HW) * 4u;
-        const unsigned dbase = (unsigned)((b * a.K + kb * 64) * HoWo + 2 * ty * a.Wo + 2 * tx0) * 4u;
+        const unsigned xbase = (unsigned)__builtin_amdgcn_readfirstlane((b * a.C + cb * 64) * HW * 4);
+        const unsigned dbase = (unsigned)__builtin_amdgcn_readfirstlane(((b * a.K + kb * 64) * HoWo + 2 * ty * a.Wo + 2 * tx0) * 4);
+        // every scalar offset is pinned to an SGPR where it is used ("+s"): with 36 of them live at once the compiler parks
+        // some in VGPRs, and a load whose scalar offset sits in a VGPR becomes a waterfall loop (readfirstlane + compare +
+        // branch): 16 of the 36 loads of a chunk did, 128 of the kernel's 393 us at the layer3 shape (tools/wrw_ablate.py)
 #pragma unroll
-        for (int k = 0; k < NXL; ++k) rx[k] = ldb(xrs, xlr[k & 3], xbase + (unsigned)(8 * (k >> 2) * HW) * 4u + sbr[k & 3]);
+        for (int k = 0; k < NXL; ++k) {
+            unsigned so = xbase + (unsigned)(8 * (k >> 2) * HW) * 4u + sbr[k & 3];
+            asm volatile("" : "+s"(so));
+            rx[k] = (DMH_WRW_ABLATE & 1) ? 1.f : ldb(xrs, xlr[k & 3], so);
+        }
 #pragma unroll
         for (int k = 0; k < NDL; ++k) {
-            const unsigned so = dbase + (unsigned)((32 * (k >> 1)) * HoWo + (k & 1) * a.Wo) * 4u;
-            rd[k] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, dl, so, 0));
+            unsigned so = dbase + (unsigned)((32 * (k >> 1)) * HoWo + (k & 1) * a.Wo) * 4u;
+            asm volatile("" : "+s"(so));
+            rd[k] = (DMH_WRW_ABLATE & 1) ? make_float2(1.f, 1.f)
+                                         : __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, dl, so, 0));
         }
     };
     auto store_raw = [&](const int buf) __attribute__((always_inline)) {
@@ -204,8 +219,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int sl = 0; sl < 32; ++sl) {
                 const int p0 = 2 * (sl >> 2), p1 = p0 + 1, ks = sl & 3;
-                acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], acc[p0], 0, 0, 0);
-                acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], acc[p1], 0, 0, 0);
+                if (!(DMH_WRW_ABLATE & 8)) {
+                    acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], acc[p0], 0, 0, 0);
+                    acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], acc[p1], 0, 0, 0);
+                } else {
+                    acc[p0][ks] += ua[p0][ks] * vb[p0][ks];
+                    acc[p1][ks] += ua[p1][ks] * vb[p1][ks];
+                }
                 if (p0 + 2 < 16) {                          // operands of the next position pair, one read per slot
                     if (ks == 0) ua[p0 + 2] = Uc[(p0 + 2) * 128];
                     if (ks == 1) vb[p0 + 2] = Vc[(p0 + 2) * 128];
@@ -215,15 +235,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 __builtin_amdgcn_sched_barrier(0);
             }
             // raw registers (chunk g+2) -> raw[cur] (read by transform(g) one iteration ago), then refill with chunk g+3
-            store_raw(cur);
+            if (!(DMH_WRW_ABLATE & 4)) store_raw(cur);
             load_chunk(c_first + g + 3);
             // raw s_barrier + lgkmcnt only: __syncthreads() would also wait for the loads just issued (vmcnt(0))
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                   // every wave has read the images of chunk g
+            if (!(DMH_WRW_ABLATE & 16)) __builtin_amdgcn_s_barrier();   // every wave has read the images of chunk g
             asm volatile("" ::: "memory");
-            transform(nxt);                                 // chunk g+1 (written to raw[nxt] one iteration ago)
+            if (!(DMH_WRW_ABLATE & 2)) transform(nxt);      // chunk g+1 (written to raw[nxt] one iteration ago)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(DMH_WRW_ABLATE & 16)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
     }
