@@ -37,14 +37,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #endif
 constexpr int NT = 256;
 constexpr int TPC = 8;                       // tiles per chunk
-constexpr int XC = 2 * TPC + 2;              // 18 input columns, 4 rows
+constexpr int XC = 24;                       // input columns staged per row: the 18 of the chunk inside six aligned 16-byte words
 constexpr int DC = 2 * TPC;                  // 16 gradient columns, 2 rows
-constexpr int XCS = 4 * XC + 2;              // raw channel strides in floats: == 2 (mod 8), odd multiples of 2 -> the 8-byte
-constexpr int DCS = 2 * DC + 2;              //   transform reads of 32 lanes (one channel each) hit 32 different bank pairs
+constexpr int XCS = 4 * XC + 4;              // raw channel strides in floats (multiples of 4: 16-byte LDS writes)
+constexpr int DCS = 2 * DC + 4;
 constexpr int XRAW = 64 * XCS, DRAW = 64 * DCS;
-constexpr int RAWBUF = XRAW + DRAW;          // floats per raw buffer (27 KB)
+constexpr int RAWBUF = XRAW + DRAW;          // floats per raw buffer (34 KB)
 constexpr int IMG = 16 * 2 * 64;             // f32x4 words of one image (32 KB)
-constexpr int NXL = 32, NDL = 4;             // raw loads per thread and chunk: x (8 channels x 32 column slots), dy (32 channels x 8 column pairs)
+constexpr int NXL = 6, NDL = 2;              // 16-byte raw loads per thread and chunk (a vector-memory instruction costs the
+                                             // wave ~64 cycles among the MFMAs whatever its width: few, wide loads)
 
 struct RArgs {
     const float* x;
@@ -71,69 +72,71 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.C * HW * 4));
     const rsrc_t drs = make_rsrc(a.dy, (unsigned)((size_t)a.B * a.K * HoWo * 4));
-    // per-thread parts of the raw offsets: x load k covers channels 8 (k >> 2) + (tid >> 5), row k & 3, column slot
-    // tid & 31 (18 used); dy load k (8 bytes: columns 2 (tid & 7), + 1) covers channels 32 (k >> 1) + (tid >> 3), row k & 1
-    const int xcol = tid & 31, xchl = tid >> 5, dpr = tid & 7, dchl = tid >> 3;
-    const unsigned x_lane = (unsigned)(xchl * HW + xcol) * 4u, d_lane = (unsigned)(dchl * HoWo + 2 * dpr) * 4u;
-    float* const xdst = raw + xchl * XCS + xcol;                 // + (8 (k >> 2)) * XCS + (k & 3) * XC
-    float* const ddst = raw + XRAW + dchl * DCS + 2 * dpr;       // + (32 (k >> 1)) * DCS + (k & 1) * DC
+    // raw loads, 16 bytes each, lanes running ALONG the rows (six adjacent lanes read the 96 bytes of one x row, four the 64
+    // bytes of one dy row: every cache line is touched by one instruction; with one row per lane the lines were re-fetched
+    // for each word).  x: item = tid + 256 k -> (channel item / 24, row (item % 24) / 6, word item % 6), the words being the
+    // aligned 16-byte words of the row from the chunk's first column rounded down to a multiple of 4 (coff = columns in
+    // front of the chunk: 0 / 3 for pad 0 / 1; an image row holds whole words on either side of its zero padding: W is a
+    // multiple of 4 where pad = 1 matters, the encoder maps; the pre-padded decoder inputs, pad 0, have no padding).
+    // dy: item -> (channel item / 8, row (item % 8) / 4, word item % 4).  Everything about an item is a per-thread constant.
+    const int coff = (4 - (a.pad & 3)) & 3;
+    unsigned xg[NXL], xl[NXL], xm[NXL], dg[NDL], dl[NDL];
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) {
+        const int item = tid + NT * k, ch = item / 24, rem = item - ch * 24, r = rem / 6, f = rem - r * 6;
+        xg[k] = (unsigned)(ch * HW + r * a.W + 4 * f);
+        xl[k] = (unsigned)(ch * XCS + r * XC + 4 * f);
+        xm[k] = (r == 0 ? 1u : 0u) | (r == 3 ? 2u : 0u) | (f == 0 ? 4u : 0u) | (f == 5 ? 8u : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < NDL; ++k) {
+        const int item = tid + NT * k, ch = item >> 3, r = (item >> 2) & 1, f = item & 3;
+        dg[k] = (unsigned)(ch * HoWo + r * a.Wo + 4 * f);
+        dl[k] = (unsigned)(XRAW + ch * DCS + r * DC + 4 * f);
+    }
 
-    float rx[NXL];
-    float2 rd[NDL];
+    f32x4 rx[NXL], rd[NDL];
     // issue the raw loads of chunk `ch` (clamped to the slice: past its end the last chunk is re-read and never used)
     auto load_chunk = [&](int ch) __attribute__((always_inline)) {
         ch = min(max(ch, c_first), max(c_end - 1, c_first));
         ch = min(ch, a.nchunks - 1);
         const int b = ch / (a.Ht * a.cpr), rem = ch - b * (a.Ht * a.cpr), ty = rem / a.cpr, tx0 = (rem - ty * a.cpr) * TPC;
-        const int iy0 = 2 * ty - a.pad, ix0 = 2 * tx0 - a.pad;
-        const int ix = ix0 + xcol;
-        const unsigned xl = (xcol < XC && ix >= 0 && ix < a.W) ? x_lane + (unsigned)(ix0 * 4) : 0xFFFFFFFFu;
-        // the row validity is uniform: one select per ROW of the region, not per load
-        unsigned xlr[4], sbr[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int iy = iy0 + r;
-            const bool ok = iy >= 0 && iy < a.H;
-            xlr[r] = ok ? xl : 0xFFFFFFFFu;
-            // the scalar offset of an invalid row is never used (its per-lane offset is out of range): clamp instead of
-            // select -- a select is evaluated on the vector ALU, lands in a VGPR and puts every load that uses it as its
-            // scalar offset into a waterfall loop (v_readfirstlane + compare + branch per load)
-            sbr[r] = (unsigned)(min(max(iy, 0), a.H - 1) * a.W) * 4u;
-        }
-        // gradient columns come in aligned pairs (Wo is even): a pair is inside or outside as a whole
-        const unsigned dl = (2 * tx0 + 2 * dpr < a.Wo) ? d_lane : 0xFFFFFFFFu;
-        const unsigned xbase = (unsigned)__builtin_amdgcn_readfirstlane((b * a.C + cb * 64) * HW * 4);
-        const unsigned dbase = (unsigned)__builtin_amdgcn_readfirstlane(((b * a.K + kb * 64) * HoWo + 2 * ty * a.Wo + 2 * tx0) * 4);
-        // every scalar offset is pinned to an SGPR where it is used ("+s"): with 36 of them live at once the compiler parks
-        // some in VGPRs, and a load whose scalar offset sits in a VGPR becomes a waterfall loop (readfirstlane + compare +
-        // branch): 16 of the 36 loads of a chunk did, 128 of the kernel's 393 us at the layer3 shape (tools/wrw_ablate.py)
+        const int iy0 = 2 * ty - a.pad, ixa = 2 * tx0 - a.pad - coff;          // ixa: multiple of 4 (tx0 is a multiple of 8)
+        // which border rows / words of this chunk lie in the zero padding (uniform); an item in the padding reads at an
+        // out-of-range offset, i.e. 0
+        const unsigned bad = (iy0 < 0 ? 1u : 0u) | (iy0 + 3 >= a.H ? 2u : 0u) | (ixa < 0 ? 4u : 0u) | (ixa + 20 >= a.W ? 8u : 0u);
+        const unsigned xbase = (unsigned)(((b * a.C + cb * 64) * a.H + iy0) * a.W + ixa);      // may wrap below 0: sums are mod 2^32
 #pragma unroll
         for (int k = 0; k < NXL; ++k) {
-            unsigned so = xbase + (unsigned)(8 * (k >> 2) * HW) * 4u + sbr[k & 3];
-            asm volatile("" : "+s"(so));
-            rx[k] = (DMH_WRW_ABLATE & 1) ? 1.f : ldb(xrs, xlr[k & 3], so);
+            const unsigned vo = (xm[k] & bad) ? 0xFFFFFF00u : (xbase + xg[k]) * 4u;
+            rx[k] = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
+                                         : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
         }
+        const unsigned dbase = (unsigned)(((b * a.K + kb * 64) * a.Ho + 2 * ty) * a.Wo + 2 * tx0);
+        const int wrem = a.Wo - 2 * tx0;                        // gradient columns of the chunk inside the row
 #pragma unroll
         for (int k = 0; k < NDL; ++k) {
-            unsigned so = dbase + (unsigned)((32 * (k >> 1)) * HoWo + (k & 1) * a.Wo) * 4u;
-            asm volatile("" : "+s"(so));
-            rd[k] = (DMH_WRW_ABLATE & 1) ? make_float2(1.f, 1.f)
-                                         : __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(drs, dl, so, 0));
+            f32x4 v = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
+                                           : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, (dbase + dg[k]) * 4u, 0, 0));
+            if (wrem < DC) {                                    // ragged right edge (uniform): columns beyond the row are other rows'
+                const int c0 = 4 * ((tid + NT * k) & 3);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (c0 + j < wrem) ? v[j] : 0.f;
+            }
+            rd[k] = v;
         }
     };
     auto store_raw = [&](const int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NXL; ++k)
-            if (xcol < XC) xdst[buf * RAWBUF + (8 * (k >> 2)) * XCS + (k & 3) * XC] = rx[k];
+        for (int k = 0; k < NXL; ++k) *reinterpret_cast<f32x4*>(raw + buf * RAWBUF + xl[k]) = rx[k];
 #pragma unroll
-        for (int k = 0; k < NDL; ++k)
-            *reinterpret_cast<float2*>(ddst + buf * RAWBUF + (32 * (k >> 1)) * DCS + (k & 1) * DC) = rd[k];
+        for (int k = 0; k < NDL; ++k) *reinterpret_cast<f32x4*>(raw + buf * RAWBUF + dl[k]) = rd[k];
     };
     // transforms of one chunk: thread = (channel `lane`, tile pair h + 4j, h + 4j + 2) with h = wv & 1, j = wv >> 1; the two
     // tiles are components 2j, 2j + 1 of the channel's 16-byte image word -> one 8-byte write per position
     const int th = wv & 1, tj = wv >> 1;
     auto transform = [&](const int buf) __attribute__((always_inline)) {
-        const float* xs = raw + buf * RAWBUF + lane * XCS + 2 * (th + 4 * tj);        // tile A; tile B: + 4 columns
+        const float* xs = raw + buf * RAWBUF + lane * XCS + coff + 2 * (th + 4 * tj);  // tile A; tile B: + 4 columns
         const float* ds = raw + buf * RAWBUF + XRAW + lane * DCS + 2 * (th + 4 * tj);
         float* const md = reinterpret_cast<float*>(M_lds + th * 64 + lane) + 2 * tj;
         float* const vd = reinterpret_cast<float*>(V_lds + th * 64 + lane) + 2 * tj;
@@ -164,9 +167,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 float d[4][4], q[4][4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float2 lo = *reinterpret_cast<const float2*>(xs + i * XC + 4 * t);
-                    const float2 hi = *reinterpret_cast<const float2*>(xs + i * XC + 4 * t + 2);
-                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                    const float* row = xs + i * XC + 4 * t;      // 4-byte aligned only (coff is odd for pad 1): four dword reads,
+                    d[i][0] = row[0]; d[i][1] = row[1]; d[i][2] = row[2]; d[i][3] = row[3];   // paired by the compiler (ds_read2_b32)
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -318,7 +320,7 @@ void plan(RArgs& a) {
 extern "C" {
 
 int64_t dmh_wino_wrw_workspace_size(int B, int C, int K, int H, int W, int pad) {
-    if (B <= 0 || C <= 0 || K <= 0 || C % 64 || K % 64 || pad < 0 || pad > 2) return -1;
+    if (B <= 0 || C <= 0 || K <= 0 || C % 64 || K % 64 || pad < 0 || pad > 1 || (pad == 1 && W % 16)) return -1;
     RArgs a;
     a.B = B; a.C = C; a.K = K; a.H = H; a.W = W; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
     if (a.Ho < 2 || a.Wo < 2 || (a.Ho & 1) || (a.Wo & 1)) return -1;
@@ -330,7 +332,9 @@ int dmh_wino_wrw(const float* x, const float* dy, int B, int C, int K, int H, in
                  void* stream) {
     DMH_REQUIRE(x && dy && workspace && dw, "null pointer");
     DMH_REQUIRE(B > 0 && C >= 64 && K >= 64 && C % 64 == 0 && K % 64 == 0, "channel counts must be multiples of 64");
-    DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
+    DMH_REQUIRE(pad == 0 || pad == 1, "pad must be 0 or 1");
+    DMH_REQUIRE(pad == 0 || W % 16 == 0, "with pad 1 the width must be a multiple of 16 (whole 8-tile chunks: the zero\n"
+                "padding column then lies in the last 16-byte word of a chunk row)");
     RArgs a;
     a.x = x; a.dy = dy; a.ws = workspace;
     a.B = B; a.C = C; a.K = K; a.H = H; a.W = W; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;

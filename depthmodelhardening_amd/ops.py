@@ -856,6 +856,9 @@ def _wrw_ok(x, g, K, Cc):
     chunks (8 tiles) to give every workgroup of a (k-block, c-block) pair a few, tensors below 4 GB."""
     if not WINO_ENABLED or not WRW_ENABLED or K % 64 or Cc % 64 or g.shape[2] % 2 or g.shape[3] % 2:
         return False
+    pad = (g.shape[2] + 2 - x.shape[2]) // 2
+    if pad not in (0, 1) or (pad == 1 and x.shape[3] % 16):
+        return False
     if x.numel() >= (1 << 30) or g.numel() >= (1 << 30):
         return False
     chunks = g.shape[0] * (g.shape[2] // 2) * -(-(g.shape[3] // 2) // 8)

@@ -381,7 +381,7 @@ def test_conv3x3_op_takes_k17_for_the_32_channel_decoder_layers():
     (2, 64, 64, 16, 32, 1),      # encoder-like: zero padding at all four borders, two chunks per tile row
     (3, 128, 64, 10, 34, 0),     # decoder-like (pre-padded input): 17 tile columns = 2 chunks + 1 ragged tile
     (1, 64, 128, 6, 16, 1),      # two k-blocks, one chunk per tile row, few chunks (more slices than chunks per pair)
-    (2, 64, 64, 4, 6, 2),        # pad 2, 3 tile columns in an 8-tile chunk
+    (2, 64, 64, 4, 16, 1),       # one chunk per tile row, every chunk touches all four borders
 ])
 def test_wino_wrw_kernel_vs_aten(shape):
     """K18 (Winograd-domain weight gradient on the fp32 MFMA) through the C ABI == ATen's convolution_backward weight
