@@ -135,17 +135,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // ty), so a 5-row image wastes nothing; consecutive tile rows may then belong to different images, so each stages
     // its own 4 input rows, and to stay inside 160 KB of LDS the raw region is single-buffered with a second barrier
     // per chunk.  Measured: 10x32 images 178 -> 127 us, but 10-30 % slower where the plain regions waste < 15 %.
+    // The raw region is staged in aligned 16-BYTE WORDS (round 3): a vector-memory instruction costs the wave ~64 cycles
+    // among the MFMAs whatever its width (tools/wrw_ablate.py), so a row of the region -- 2 TRW + 2 columns from x0 = 2 tx0 -
+    // pad -- is fetched as the NWR aligned words that cover it (x0 rounded down to a multiple of 4: `coff` = 0 / 3 / 2
+    // columns in front for pad 0 / 1 / 2), lanes running along the rows: 4-5 loads per thread and chunk instead of 11-13.
+    // A word is inside or outside the image as a whole when W is a multiple of 4 (every layer of the network); otherwise
+    // the one word that straddles the right edge is masked when it is written to LDS (`partial`).
     constexpr int RW = 2 * TRW + 2;
+    constexpr int NWR = (RW + 6) / 4;                       // 16-byte words per staged row (18 / 10)
+    constexpr int RWA = 4 * NWR;                            // LDS row pitch in floats
     constexpr int RH = FLAT ? 4 * TRH : 2 * TRH + 2;        // raw input rows of a work item (per channel)
-    constexpr int TRS = (FLAT ? 4 : 2) * RW;                // raw floats from one tile row to the next
-    constexpr int RAW_N = CK * RH * RW;
+    constexpr int TRS = (FLAT ? 4 : 2) * RWA;               // raw floats from one tile row to the next
+    constexpr int RAW_N = CK * RH * NWR;                    // words of one raw buffer
     constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;
-    constexpr int RAW_BUF = FLAT ? 0 : RAW_PER_T * NT;      // floats from raw buffer 0 to buffer 1 (FLAT: one buffer)
+    constexpr int RAW_BUF = FLAT ? 0 : RAW_N;               // words from raw buffer 0 to buffer 1 (FLAT: one buffer)
     constexpr int BUF = 16 * 2 * 64;                        // f32x4 words of one U or V image (32 KB)
     extern __shared__ f32x4 smem[];
     f32x4* U_lds = smem;                                    // [2 buffers][16][2][64]
     f32x4* V_lds = smem + 2 * BUF;                          // [2 buffers][16][2][64]
-    float* raw = reinterpret_cast<float*>(smem + 4 * BUF);  // [1 or 2 buffers][CK][RH][RW]
+    f32x4* raw4 = smem + 4 * BUF;                           // [1 or 2 buffers][CK][RH][NWR] words
+    float* raw = reinterpret_cast<float*>(raw4);
     const int Ht = a.Ho >> 1, NR = a.B * Ht;                // FLAT: rows of tiles per image / in the batch
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -161,7 +170,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     // transform role: wave wv owns chunk channels {2wv, 2wv+1} = (h = wv>>1, s = 2(wv&1) + {0,1}); lane = tile
     const int tly = lane / TRW, tlx = lane - tly * TRW;
-    const float* rsrc = raw + (2 * wv) * (RH * RW) + tly * TRS + 2 * tlx;
+    const int coff = (4 - (a.pad & 3)) & 3;                 // columns of the first word in front of the region
+    const bool partial = a.pad > 0 && (a.W & 3) != 0;       // a word can straddle the right image edge
+    const float* rsrc = raw + (2 * wv) * (RH * RWA) + tly * TRS + 2 * tlx + coff;
     float* vdst = reinterpret_cast<float*>(V_lds + (wv >> 1) * 64 + lane) + 2 * (wv & 1);
     const int kb = wv & 1, tb = wv >> 1;
     const int aidx = (lane >> 5) * 64 + kb * 32 + (lane & 31);
@@ -178,10 +189,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const rsrc_t urs = make_rsrc(a.U, (unsigned)((size_t)(a.C / CK) * 32 * a.Kp * 16));
     unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
     unsigned uoff = 0, uoff_n = 0;           // byte offset of the item's first filter chunk (uniform)
-#define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, UOFF)                                                    \
+    int ixa = 0, ixa_n = 0;                  // first staged column of the item (uniform; `partial` only)
+#define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, UOFF, IXA)                                               \
     {                                                                                             \
         const Item it = decode_item<TRW>(a, ITEM);                                                \
-        const int ix0 = 2 * it.tx0 - a.pad;                                                       \
+        const int ix0 = 2 * it.tx0 - a.pad - coff;        /* multiple of 4: tx0 is a multiple of 16 */ \
+        IXA = ix0;                                                                                \
         /* thread index rebuilt from v_mbcnt + the scalar wave index: a copy of `tid` kept from kernel entry is  */ \
         /* spilled, and its reload's vmcnt(0) waits for the previous item's stores (also keeps the slot          */ \
         /* decomposition below from being hoisted and held in registers)                                         */ \
@@ -199,7 +212,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }                                                                                         \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
-            const int c = e / (RH * RW), rem = e - c * (RH * RW), rr = rem / RW, xx = rem - rr * RW; \
+            const int c = e / (RH * NWR), rem = e - c * (RH * NWR), rr = rem / NWR, xx = 4 * (rem - rr * NWR); \
             int iy, bofs = cbase;                                                                 \
             bool okr = e < RAW_N;                                                                 \
             if (FLAT) {                                                                           \
@@ -212,16 +225,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             } else {                                                                              \
                 iy = 2 * it.ty0 - a.pad + rr;                                                     \
             }                                                                                     \
-            const int ix = ix0 + xx;                                                              \
+            const int ix = ix0 + xx;                       /* first column of the word */         \
             const bool ok = okr && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;                    \
             ROFF[k] = ok ? (unsigned)(bofs + c * (int)HW + iy * a.W + ix) * 4u : 0xFFFFFFFFu;     \
         }                                                                                         \
     }
 
-    float rreg[RAW_PER_T];
+    f32x4 rreg[RAW_PER_T];
     // CHB: wave-uniform byte offset of the chunk inside the item (chunk index * 8 channels)
+#define DMH_WINO_LOAD1(K, CHB, OFF) rreg[K] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (OFF), (CHB), 0));
 #define DMH_WINO_LOAD_RAW(CHB, ROFF)                                                              \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = ldb(xrs, ROFF[k], (CHB));
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) DMH_WINO_LOAD1(k, CHB, ROFF[k])
+    // registers -> LDS (word e of the buffer: the region is enumerated in LDS order); IXW: first staged column of the item
+    // the data belongs to -- with `partial` the columns at and beyond W are zeroed (they hold the next row's first pixels)
+#define DMH_WINO_WRITE1(K, BUFI, IXW)                                                             \
+    {                                                                                             \
+        const int e_ = tid + NT * (K);                                                            \
+        f32x4 v_ = rreg[K];                                                                       \
+        if (partial) {                                                                            \
+            const int n_ = a.W - ((IXW) + 4 * (e_ % NWR));                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) v_[j] = (j < n_) ? v_[j] : 0.f;         \
+        }                                                                                         \
+        if (RAW_PER_T * NT == RAW_N || e_ < RAW_N) raw4[(BUFI) * RAW_BUF + e_] = v_;              \
+    }
     // filter chunk: 32 rows (p, h) of 64 x 16 B, lane-linear both in global memory and in the LDS image -> LDS-DMA
     // (buffer_load_dwordx4 ... lds: no registers, no ds_write; the row's byte offset is an SGPR, the per-lane part
     // lane * 16 a loop-invariant register); wave wv moves rows wv, wv+4, ...; K = row slot 0..7
@@ -241,8 +267,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 #define DMH_WINO_GLDS_U(UCB, BUFI)                                                                \
     _Pragma("unroll") for (int k = 0; k < 8; ++k) DMH_WINO_GLDS_U_ROW(UCB, BUFI, k)
-#define DMH_WINO_WRITE_RAW(BUFI)                                                                  \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) raw[(BUFI) * RAW_BUF + tid + NT * k] = rreg[k];
+#define DMH_WINO_WRITE_RAW(BUFI, IXW)                                                             \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) DMH_WINO_WRITE1(k, BUFI, IXW)
 
     f32x16 acc[16];         // never cleared: the first chunk of an item multiplies onto a zero C operand (an inline constant)
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -259,10 +285,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // first chunks into buffers nobody reads any more.
     const unsigned chunk_bytes = (unsigned)(CK * HW * 4);          // one chunk of 8 input channels
     const unsigned uchunk_bytes = (unsigned)(32 * a.Kp * 16);      // one filter chunk
-    DMH_WINO_ITEM_CONSTS(item0, roff, uoff)
+    DMH_WINO_ITEM_CONSTS(item0, roff, uoff, ixa)
     DMH_WINO_LOAD_RAW(0u, roff)
     DMH_WINO_GLDS_U(uoff, 0)
-    DMH_WINO_WRITE_RAW(0)
+    DMH_WINO_WRITE_RAW(0, ixa)
     DMH_WINO_LOAD_RAW(chunk_bytes, roff)
     __syncthreads();
     {   // T(0)
@@ -271,10 +297,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int ch = 0; ch < 2; ++ch) {
             float d[4][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float2 lo = *reinterpret_cast<const float2*>(rsrc + ch * (RH * RW) + i * RW);
-                const float2 hi = *reinterpret_cast<const float2*>(rsrc + ch * (RH * RW) + i * RW + 2);
-                d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+            for (int i = 0; i < 4; ++i) {       // 4-byte aligned only (coff is odd for pad 1): dword reads, paired by the compiler
+                const float* row = rsrc + ch * (RH * RWA) + i * RWA;
+                d[i][0] = row[0]; d[i][1] = row[1]; d[i][2] = row[2]; d[i][3] = row[3];
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -293,7 +318,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }
     }
     if (FLAT) __syncthreads();          // single raw buffer: every wave has transformed chunk 0 out of it
-    DMH_WINO_WRITE_RAW(1)
+    DMH_WINO_WRITE_RAW(1, ixa)
     DMH_WINO_LOAD_RAW(2u * chunk_bytes, roff)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_PER_T) : "memory");   // the LDS-DMA of U[0] has landed
     __syncthreads();
@@ -301,14 +326,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int g = 0;
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
-        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n)
+        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n, ixa_n)
         // one chunk; FIRST: the item's first chunk, whose first MFMA per position starts the accumulation from zero
         auto chunk = [&](const int ch, auto first_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const int cur = g & 1, nxt = cur ^ 1;
             const f32x4* Uc = U_lds + cur * BUF + aidx;
             const f32x4* Vc = V_lds + cur * BUF + bidx;
-            const float* rs = rsrc + nxt * RAW_BUF;
+            const float* rs = rsrc + nxt * RAW_BUF * 4;
+            const int ixw = (ch + 2 >= nch) ? ixa_n : ixa;  // the registers written to LDS below hold chunk ch+2
             float* vd = vdst + nxt * BUF * 4;
             // load-stage operands of this iteration: raw chunk ch+3 and filter chunk ch+1, possibly of the next item;
             // the raw registers written to LDS in this iteration hold chunk ch+2
@@ -353,9 +379,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 } else if (DMH_WINO_ABLATE & 2) {
                 } else if ((sl >= 8 && sl < 12) || (sl >= 14 && sl < 18)) {   // raw patch row of channel 0 / 1
                     const int c2 = sl >= 14, i = c2 ? sl - 14 : sl - 8;
-                    const float2 lo = *reinterpret_cast<const float2*>(rs + c2 * (RH * RW) + i * RW);
-                    const float2 hi = *reinterpret_cast<const float2*>(rs + c2 * (RH * RW) + i * RW + 2);
-                    d[i][0] = lo.x; d[i][1] = lo.y; d[i][2] = hi.x; d[i][3] = hi.y;
+                    const float* row = rs + c2 * (RH * RWA) + i * RWA;
+                    d[i][0] = row[0]; d[i][1] = row[1]; d[i][2] = row[2]; d[i][3] = row[3];
                 } else if (sl == 12 || sl == 13 || sl == 18 || sl == 19) {    // rows of B^T d, two columns per slot
                     const int c2 = sl >= 18, j0 = 2 * (sl & 1);
 #pragma unroll
@@ -382,8 +407,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (sl >= 28) {                             // raw registers -> LDS, then refill them (4 slots)
 #pragma unroll
                     for (int k = (sl - 28) * ((RAW_PER_T + 3) / 4); k < min((sl - 27) * ((RAW_PER_T + 3) / 4), RAW_PER_T); ++k) {
-                        if (!(DMH_WINO_ABLATE & 4)) raw[cur * RAW_BUF + tid + NT * k] = rreg[k];
-                        if (!(DMH_WINO_ABLATE & 1)) rreg[k] = ldb(xrs, r_next ? roff_n[k] : roff[k], xcb);
+                        if (!(DMH_WINO_ABLATE & 4)) DMH_WINO_WRITE1(k, cur, ixw)
+                        if (!(DMH_WINO_ABLATE & 1)) DMH_WINO_LOAD1(k, xcb, r_next ? roff_n[k] : roff[k])
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -480,6 +505,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
         uoff = uoff_n;
+        ixa = ixa_n;
     }
 }
 
@@ -498,8 +524,8 @@ template <int TRW, bool FLAT, bool EPI>
 int launch(WArgs& a, hipStream_t st) {
     constexpr int TRH = 64 / TRW;
     // U and V images (double-buffered, 128 KB) + the raw input region(s): see FLAT in the kernel
-    constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * (2 * TRW + 2);
-    constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * ((RAWN + NT - 1) / NT * NT) * 4;
+    constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);     // 16-byte words, see the kernel
+    constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<TRW, FLAT, EPI>),
