@@ -34,9 +34,11 @@ constexpr int CK = 8;                       // input channels per chunk
 constexpr int NT = 256;
 constexpr int TRW = 32, TRH = 4;            // tile region of an item
 constexpr int RW = 2 * TRW + 2, RH = 2 * TRH + 2;
-constexpr int RAW_N = CK * RH * RW;         // 5280 floats
-constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;   // 21
-constexpr int RAW_BUF = RAW_PER_T * NT;     // floats per raw buffer
+constexpr int NWR = (RW + 6) / 4;           // the raw rows are staged as aligned 16-byte words (see K10): 18 per row
+constexpr int RWA = 4 * NWR;                // LDS row pitch in floats (72)
+constexpr int RAW_N = CK * RH * NWR;        // 1440 words
+constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;   // 6 loads per thread and chunk (dword loads: 21)
+constexpr int RAW_BUF = RAW_N * 4;          // floats per raw buffer (23 KB)
 constexpr int UBUF = 16 * 2 * 32;           // f32x4 words of one U chunk image (16 KB)
 constexpr int VBUF = 16 * 2 * 128;          // f32x4 words of the V image (64 KB)
 
@@ -80,7 +82,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // transform role: wave wv owns chunk channels {2wv, 2wv+1} = (h = wv>>1, s = 2(wv&1) + {0,1}); a lane transforms
     // tiles `lane` and `lane + 64` of the region (tile t = row t/32, column t%32)
     const int tl0y = lane >> 5, tlx = lane & 31;
-    const float* rsrc0 = raw + (2 * wv) * (RH * RW) + (2 * tl0y) * RW + 2 * tlx;          // tile `lane`; +4*RW: tile lane+64
+    const int coff = (4 - (a.pad & 3)) & 3;                 // columns of the first word in front of the region
+    const bool partial = a.pad > 0 && (a.W & 3) != 0;       // a word can straddle the right image edge
+    f32x4* const raw4 = reinterpret_cast<f32x4*>(raw);
+    const float* rsrc0 = raw + (2 * wv) * (RH * RWA) + (2 * tl0y) * RWA + 2 * tlx + coff;  // tile `lane`; +4*RWA: tile lane+64
     float* vdst0 = reinterpret_cast<float*>(V_lds + (wv >> 1) * 128 + lane) + 2 * (wv & 1);   // +64 words: tile lane+64
     // MFMA role: wave wv multiplies the 32 channels by tiles [32 wv, 32 wv + 32)
     const int aidx = (lane >> 5) * 32 + (lane & 31);
@@ -92,11 +97,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const rsrc_t urs = make_rsrc(a.U, (unsigned)((size_t)nch * 32 * a.Kp * 16));
     unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
     unsigned uoff = 0, uoff_n = 0;
+    int ixa = 0, ixa_n = 0;
     // raw-load constants of an item.  The thread index is rebuilt from v_mbcnt so that nothing of this is hoisted and spilled.
-#define DMH_W32_ITEM_CONSTS(ITEM, ROFF, UOFF)                                                      \
+#define DMH_W32_ITEM_CONSTS(ITEM, ROFF, UOFF, IXA)                                                 \
     {                                                                                             \
         const Item it = decode_item(a, ITEM);                                                     \
-        const int ix0 = 2 * it.tx0 - a.pad, iy0 = 2 * it.ty0 - a.pad;                             \
+        const int ix0 = 2 * it.tx0 - a.pad - coff, iy0 = 2 * it.ty0 - a.pad;                      \
+        IXA = ix0;                                                                                \
         int tid_o;                                                                                \
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_o)); \
         tid_o += wv_s * 64;                                                                       \
@@ -104,17 +111,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const int cbase = it.b * a.C * (int)HW;                                                   \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
-            const int c = e / (RH * RW), rem = e - c * (RH * RW), rr = rem / RW, xx = rem - rr * RW; \
+            const int c = e / (RH * NWR), rem = e - c * (RH * NWR), rr = rem / NWR, xx = 4 * (rem - rr * NWR); \
             const int iy = iy0 + rr, ix = ix0 + xx;                                               \
             const bool ok = e < RAW_N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;              \
             ROFF[k] = ok ? (unsigned)(cbase + c * (int)HW + iy * a.W + ix) * 4u : 0xFFFFFFFFu;    \
         }                                                                                         \
     }
-    float rreg[RAW_PER_T];
+    f32x4 rreg[RAW_PER_T];
+#define DMH_W32_LOAD1(K, CHB, OFF) rreg[K] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (OFF), (CHB), 0));
 #define DMH_W32_LOAD_RAW(CHB, ROFF)                                                               \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) rreg[k] = ldb(xrs, ROFF[k], (CHB));
-#define DMH_W32_WRITE_RAW(BUFI)                                                                   \
-    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) raw[(BUFI) * RAW_BUF + tid + NT * k] = rreg[k];
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) DMH_W32_LOAD1(k, CHB, ROFF[k])
+#define DMH_W32_WRITE1(K, BUFI, IXW)                                                              \
+    {                                                                                             \
+        const int e_ = tid + NT * (K);                                                            \
+        f32x4 v_ = rreg[K];                                                                       \
+        if (partial) {        /* columns at and beyond W hold the next row's first pixels */      \
+            const int n_ = a.W - ((IXW) + 4 * (e_ % NWR));                                        \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) v_[j] = (j < n_) ? v_[j] : 0.f;         \
+        }                                                                                         \
+        if (RAW_PER_T * NT == RAW_N || e_ < RAW_N) raw4[(BUFI) * RAW_N + e_] = v_;                \
+    }
+#define DMH_W32_WRITE_RAW(BUFI, IXW)                                                              \
+    _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) DMH_W32_WRITE1(k, BUFI, IXW)
     // filter chunk: 16 positions x (2 halves x 32 channels x 16 B = 1 KB, contiguous in LDS): one LDS-DMA instruction per
     // position, four per wave; lanes 0-31 read half 0, lanes 32-63 half 1 of the position's rows (Kp * 16 B apart).
     // asm: see K10 (hipcc would drain vmcnt(0) at every later LDS read); completion is counted by hand before the barriers.
@@ -136,9 +154,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         _Pragma("unroll") for (int ch_ = 0; ch_ < 2; ++ch_) {                                     \
             float d_[4][4];                                                                       \
             _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-                const float2 lo = *reinterpret_cast<const float2*>((RS) + ch_ * (RH * RW) + i * RW);     \
-                const float2 hi = *reinterpret_cast<const float2*>((RS) + ch_ * (RH * RW) + i * RW + 2); \
-                d_[i][0] = lo.x; d_[i][1] = lo.y; d_[i][2] = hi.x; d_[i][3] = hi.y;               \
+                const float* row_ = (RS) + ch_ * (RH * RWA) + i * RWA;    /* 4-byte aligned only */ \
+                d_[i][0] = row_[0]; d_[i][1] = row_[1]; d_[i][2] = row_[2]; d_[i][3] = row_[3];   \
             }                                                                                     \
             _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                       \
                 t_[ch_][0][j] = d_[0][j] - d_[2][j];                                              \
@@ -157,7 +174,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #define DMH_W32_TRANSFORM(BUFI)                                                                   \
     {                                                                                             \
         DMH_W32_TRANSFORM_TILE(rsrc0 + (BUFI) * RAW_BUF, vdst0)                                   \
-        DMH_W32_TRANSFORM_TILE(rsrc0 + (BUFI) * RAW_BUF + 4 * RW, vdst0 + 64 * 4)                 \
+        DMH_W32_TRANSFORM_TILE(rsrc0 + (BUFI) * RAW_BUF + 4 * RWA, vdst0 + 64 * 4)                \
     }
 
     f32x16 acc[16];
@@ -172,15 +189,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     //   barrier, T(g+1): raw[(g+1)&1] -> V, barrier
     const unsigned chunk_bytes = (unsigned)(CK * HW * 4);
     const unsigned uchunk_bytes = (unsigned)(32 * a.Kp * 16);
-    DMH_W32_ITEM_CONSTS(item0, roff, uoff)
+    DMH_W32_ITEM_CONSTS(item0, roff, uoff, ixa)
     DMH_W32_LOAD_RAW(0u, roff)
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) DMH_W32_GLDS_U_ROW(uoff, 0, k4)
-    DMH_W32_WRITE_RAW(0)
+    DMH_W32_WRITE_RAW(0, ixa)
     DMH_W32_LOAD_RAW(chunk_bytes, roff)
     __syncthreads();
     DMH_W32_TRANSFORM(0)
-    DMH_W32_WRITE_RAW(1)
+    DMH_W32_WRITE_RAW(1, ixa)
     DMH_W32_LOAD_RAW(2u * chunk_bytes, roff)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RAW_PER_T) : "memory");   // the LDS-DMA of U[0] has landed
     __syncthreads();
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int g = 0;
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
-        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n)
+        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n, ixa_n)
         for (int ch = 0; ch < nch; ++ch, ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
             const f32x4* Uc = U_lds + cur * UBUF + aidx;
@@ -216,8 +233,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     DMH_W32_GLDS_U_ROW(ucb, nxt, sl)
                 } else if (sl >= 8 && sl < 8 + RAW_PER_T) {  // raw registers (chunk g+2) -> raw[cur], then refill (chunk g+3)
                     const int k = sl - 8;
-                    raw[cur * RAW_BUF + tid + NT * k] = rreg[k];
-                    rreg[k] = ldb(xrs, r_next ? roff_n[k] : roff[k], xcb);
+                    DMH_W32_WRITE1(k, cur, (ch + 2 >= nch) ? ixa_n : ixa)
+                    DMH_W32_LOAD1(k, xcb, r_next ? roff_n[k] : roff[k])
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -266,6 +283,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
         uoff = uoff_n;
+        ixa = ixa_n;
     }
 }
 
