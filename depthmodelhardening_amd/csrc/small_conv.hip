@@ -40,8 +40,10 @@ template <int NQ, int NKB, int TH>
 __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
     constexpr int C = 4 * NQ;
     constexpr int RH = TH + 2, RW = TW + 2;
-    constexpr int CS = ((RH * RW + 15) / 32) * 32 + 16;     // channel stride: == 16 (mod 32) floats, >= RH*RW
-    static_assert(CS >= RH * RW, "channel stride");
+    constexpr int NWR = (RW + 6) / 4;                        // aligned 16-byte words per staged row (18)
+    constexpr int RWA = 4 * NWR;                             // LDS row pitch in floats (72)
+    constexpr int CS = ((RH * RWA + 15) / 32) * 32 + 16;     // channel stride: == 16 (mod 32) floats, >= RH*RWA
+    static_assert(CS >= RH * RWA, "channel stride");
     extern __shared__ float tile[];                          // [C][CS]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -51,53 +53,47 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
     const int b = bid / a.gy;
     const int oy0 = gyi * TH, ox0 = gxi * TW;
     const size_t HW = (size_t)a.H * a.W;
-    const float* xb = a.x + (size_t)b * a.n_in * HW;      // n_in <= C: missing channels are staged as zeros
+    const int coff = (4 - (a.pad & 3)) & 3;                  // columns of a row's first word in front of the tile
 
     // ---- stage the input tile: rows oy0-pad .. +RH, cols ox0-pad .. +RW of every channel (zero outside the image).
-    //      Wave w stages channels [NQ w, NQ w + NQ): one 64-column wave-load per (channel, row) through a buffer resource
-    //      -- the row's byte offset is SALU arithmetic in an SGPR, the per-lane column offset a loop-invariant register
-    //      whose out-of-range value (0xFFFFFFFF: reads 0) IS the zero padding -- and an LDS write at an immediate
-    //      offset from one per-lane base.  One vector instruction per row (the select between the column offset and the
-    //      out-of-range offset for rows outside the image); round 2's flat element index cost ~35 per ELEMENT (index
-    //      decomposition, clamps, 64-bit addresses, masks): 1,900 vector instructions per thread ahead of 288 MFMAs that
-    //      share the same pipe.  The two halo columns 64, 65 of every row: a flat pass of <= 3 elements per thread.
-    //      All loads are issued before the first LDS write, so their latencies overlap.
+    //      Wave w stages channels [NQ w, NQ w + NQ) as aligned 16-BYTE WORDS, lanes along the rows (18 words cover the 66
+    //      columns of a row from its first column rounded down to a multiple of 4): 12 buffer loads per lane instead of one
+    //      dword per row and lane (40) -- a vector-memory instruction costs the wave ~64 cycles on the pipe the MFMAs of the
+    //      other workgroups of the CU want -- and an out-of-range offset (reads 0) IS the zero padding.  A word is inside or
+    //      outside the image as a whole when W is a multiple of 4 (every layer here); otherwise the word that straddles the
+    //      right edge is masked before it is written (`partial`).  All loads are issued before the first LDS write.
     {
-        constexpr int RPW = NQ * RH;                               // rows staged per wave
-        constexpr int TAILS = (2 * C * RH + NT - 1) / NT;
+        constexpr int NROW = NQ * RH;                              // rows staged per wave
+        constexpr int PER_L = (NROW * NWR + 63) / 64;
         const int wvu = __builtin_amdgcn_readfirstlane(wv);
         const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.n_in * HW * 4));
-        const int ix = ox0 - a.pad + lane;
-        const unsigned col_off = (ix >= 0 && ix < a.W) ? (unsigned)ix * 4u : 0xFFFFFFFFu;
-        float stage[RPW], tail[TAILS];
+        const bool partial = a.pad > 0 && (a.W & 3) != 0;
+        const int ixa = ox0 - a.pad - coff;                        // multiple of 4 (ox0 is a multiple of 64)
+        f32x4 stage[PER_L];
 #pragma unroll
-        for (int k = 0; k < RPW; ++k) {
-            const int c = NQ * wvu + k / RH, iy = oy0 - a.pad + (k % RH);          // uniform
-            const bool ok = c < a.n_in && iy >= 0 && iy < a.H;
-            // (clamped, not selected, and pinned to an SGPR: a scalar offset in a VGPR makes the load a waterfall loop)
-            unsigned rowb = (unsigned)(((b * a.n_in + min(c, a.n_in - 1)) * a.H + min(max(iy, 0), a.H - 1)) * a.W) * 4u;
-            asm volatile("" : "+s"(rowb));
-            stage[k] = (DMH_SMALL_ABLATE & 1) ? 1.f : ldb(xrs, ok ? col_off : 0xFFFFFFFFu, rowb);
+        for (int k = 0; k < PER_L; ++k) {
+            const int item = lane + 64 * k, rl = item / NWR, f = item - rl * NWR;
+            const int c = NQ * wvu + rl / RH, iy = oy0 - a.pad + (rl % RH), cx = ixa + 4 * f;
+            const bool ok = item < NROW * NWR && c < a.n_in && iy >= 0 && iy < a.H && cx >= 0 && cx < a.W;
+            const unsigned vo = ok ? (unsigned)(((b * a.n_in + c) * a.H + iy) * a.W + cx) * 4u : 0xFFFFFFFFu;
+            f32x4 v = (DMH_SMALL_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
+                                             : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
+            if (partial) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = (cx + j < a.W) ? v[j] : 0.f;
+            }
+            stage[k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < TAILS; ++k) {
-            const int e = tid + NT * k, rr = e >> 1, c = rr / RH, r = rr - c * RH;
-            const int iy = oy0 - a.pad + r, ix2 = ox0 - a.pad + 64 + (e & 1);
-            const bool ok = rr < C * RH && c < a.n_in && iy >= 0 && iy < a.H && ix2 >= 0 && ix2 < a.W;
-            tail[k] = ldb(xrs, ok ? (unsigned)(((b * a.n_in + c) * a.H + iy) * a.W + ix2) * 4u : 0xFFFFFFFFu, 0u);
-        }
-        float* const dst = tile + NQ * wvu * CS + lane;
-#pragma unroll
-        for (int k = 0; k < RPW; ++k) dst[(k / RH) * CS + (k % RH) * RW] = stage[k];
-#pragma unroll
-        for (int k = 0; k < TAILS; ++k) {
-            const int e = tid + NT * k, rr = e >> 1, c = rr / RH, r = rr - c * RH;
-            if (rr < C * RH) tile[c * CS + r * RW + 64 + (e & 1)] = tail[k];
+        for (int k = 0; k < PER_L; ++k) {
+            const int item = lane + 64 * k, rl = item / NWR, f = item - rl * NWR;
+            if (item < NROW * NWR)
+                *reinterpret_cast<f32x4*>(tile + (NQ * wvu + rl / RH) * CS + (rl % RH) * RWA + 4 * f) = stage[k];
         }
     }
 
-    // ---- the filter of this lane: A operand of mfma 16x16x4 = W[kout = lane & 15][channel = 4q + (lane >> 4)]; nine taps
-    //      at immediate offsets from one per-(block, quad) offset, out of range (= 0) for channels the layer does not have
+    // ---- the filter of this lane: A operand of mfma 16x16x4 = W[kout = lane & 15][channel = 4q + (lane >> 4)]; its nine
+    //      taps are contiguous in memory: two 16-byte loads + one dword (out of range = 0 for channels the layer lacks)
     const rsrc_t wrs = make_rsrc(a.w, (unsigned)((size_t)a.Kw * a.Cw * 9 * 4));
     float wreg[NKB][NQ][9];
 #pragma unroll
@@ -108,16 +104,20 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
             const int ci = 4 * q + (lane >> 4);
             const bool ok = ko < a.n_out && ci < a.n_in;
             // forward: w[ko][ci][t]; backward-data: w[ci][ko][8 - t] (flipped, channel roles swapped)
-            // (out-of-range base 0x80000000: adding the tap's immediate offset cannot wrap back into the filter)
+            // (out-of-range base 0x80000000: adding the immediate offsets cannot wrap back into the filter)
             const unsigned wo = ok ? (unsigned)((a.backward ? ci * a.Cw + ko : ko * a.Cw + ci) * 9) * 4u : 0x80000000u;
+            const f32x4 w0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wo, 0, 0));
+            const f32x4 w1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wo + 16u, 0, 0));
+            const float w8 = ldb(wrs, wo + 32u, 0u);
+            const float taps[9] = {w0[0], w0[1], w0[2], w0[3], w1[0], w1[1], w1[2], w1[3], w8};
 #pragma unroll
-            for (int t = 0; t < 9; ++t) wreg[kb][q][t] = ldb(wrs, wo + 4u * (unsigned)(a.backward ? 8 - t : t), 0u);
+            for (int t = 0; t < 9; ++t) wreg[kb][q][t] = a.backward ? taps[8 - t] : taps[t];
         }
     }
     __syncthreads();
 
     // ---- wave wv owns the 16-pixel column block wv of every row of the tile
-    const float* src = tile + (lane >> 4) * CS + 16 * wv + (lane & 15);
+    const float* src = tile + (lane >> 4) * CS + 16 * wv + (lane & 15) + coff;
     const int ox = ox0 + 16 * wv + (lane & 15);
     float bs[NKB][4];
 #pragma unroll
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
         for (int q = 0; q < ((DMH_SMALL_ABLATE & 2) ? 0 : NQ); ++q)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const float xv = src[4 * q * CS + (row + t / 3) * RW + (t % 3)];
+                const float xv = src[4 * q * CS + (row + t / 3) * RWA + (t % 3)];
 #pragma unroll
                 for (int kb = 0; kb < NKB; ++kb)
                     acc[kb] = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[kb][q][t], xv, acc[kb], 0, 0, 0);
@@ -157,8 +157,8 @@ __global__ __launch_bounds__(NT) void small_conv_kernel(SArgs a) {
 
 template <int NQ, int NKB, int TH>
 int launch(SArgs& a, hipStream_t st) {
-    constexpr int RH = TH + 2, RW = TW + 2;
-    constexpr int CS = ((RH * RW + 15) / 32) * 32 + 16;
+    constexpr int RH = TH + 2, RWA = 4 * ((TW + 2 + 6) / 4);
+    constexpr int CS = ((RH * RWA + 15) / 32) * 32 + 16;
     constexpr size_t smem = (size_t)4 * NQ * CS * sizeof(float);
     static bool configured = false;
     if (!configured) {
