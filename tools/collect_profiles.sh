@@ -5,6 +5,7 @@
 # fit one pass (TCC has 4 slots: 3 + 2).
 set -u
 TAG=${1:-r03}
+MODE=${2:-bench}   # the K10 loop below re-sets the positional parameters
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -39,7 +40,7 @@ for shp in "l1 64 64 80 256 1 12" "l3 256 256 20 64 1 12" "up21 128 64 80 256 0 
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/k10_${tagk}_write -- $K10 2 > $OUT/k10_${tagk}_write.log 2>&1
 done
 echo "k10 passes done"
-if [ "${2:-bench}" = "bench" ]; then
+if [ "$MODE" = "bench" ]; then
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline > $OUT/bench.json 2> $OUT/bench.err
   tail -1 $OUT/bench.json
 fi
