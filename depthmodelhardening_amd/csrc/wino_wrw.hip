@@ -41,26 +41,41 @@ constexpr int XC = 24;                       // input columns staged per row: th
 constexpr int DC = 2 * TPC;                  // 16 gradient columns, 2 rows
 constexpr int XCS = 4 * XC + 4;              // raw channel strides in floats (multiples of 4: 16-byte LDS writes)
 constexpr int DCS = 2 * DC + 4;
-constexpr int XRAW = 64 * XCS, DRAW = 64 * DCS;
-constexpr int RAWBUF = XRAW + DRAW;          // floats per raw buffer (34 KB)
-constexpr int IMG = 16 * 2 * 64;             // f32x4 words of one image (32 KB)
-constexpr int NXL = 6, NDL = 2;              // 16-byte raw loads per thread and chunk (a vector-memory instruction costs the
-                                             // wave ~64 cycles among the MFMAs whatever its width: few, wide loads)
+
+// Block shapes: KS x CS sub-blocks of 32 x 32 (output x input channels) per workgroup.  <2,2> = 64 x 64 (the >= 64-channel
+// layers), <1,3> = 32 x 96 (upconv(1,1)), <1,2> = 32 x 64 (upconv(1,0)): the 32-output-channel decoder layers.
+template <int KS, int CS>
+struct Cfg {
+    static constexpr int KCH = 32 * KS, CCH = 32 * CS;
+    static constexpr int XRAW = CCH * XCS, DRAW = KCH * DCS;
+    static constexpr int RAWBUF = XRAW + DRAW;                      // floats per raw buffer
+    static constexpr int IMGM = 16 * 2 * KCH, IMGV = 16 * 2 * CCH;  // f32x4 words of the two images
+    // 16-byte raw loads per thread and chunk (a vector-memory instruction costs the wave ~64 cycles among the MFMAs whatever
+    // its width: few, wide loads)
+    static constexpr int NXL = CCH * 24 / NT, NDL = KCH * 8 / NT;
+    static constexpr int NACC = 4 * KS * CS;                        // accumulator tiles per wave: 4 positions x the sub-blocks
+    static constexpr size_t SMEM = (size_t)(IMGM + IMGV) * 16 + (size_t)2 * RAWBUF * 4;
+    static_assert(CCH * 24 % NT == 0 && KCH * 8 % NT == 0, "whole load items per thread");
+    static_assert(NACC * 16 <= 256 && SMEM <= 160 * 1024, "accumulators / LDS");
+};
 
 struct RArgs {
     const float* x;
     const float* dy;
-    float* ws;                  // [pairs][S][16][64][64]
+    float* ws;                  // [pairs][S][16][KCH][CCH]
     int B, C, K, H, W, Ho, Wo, pad;
     int Ht, cpr;                // rows of tiles per image, chunks per tile row
     int nchunks, nk, nc, S, cps;   // chunks in total; channel blocks; slices per pair; chunks per slice
 };
 
+template <int KS, int CS>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wrw_kernel(RArgs a) {
+    using G = Cfg<KS, CS>;
+    constexpr int KCH = G::KCH, CCH = G::CCH, NXL = G::NXL, NDL = G::NDL, XRAW = G::XRAW, RAWBUF = G::RAWBUF;
     extern __shared__ f32x4 smem[];
-    f32x4* M_lds = smem;                                         // dM image [16][2][64]
-    f32x4* V_lds = smem + IMG;                                   // V image  [16][2][64]
-    float* raw = reinterpret_cast<float*>(smem + 2 * IMG);       // [2][ x: 64 x XCS | dy: 64 x DCS ]
+    f32x4* M_lds = smem;                                              // dM image [16][2][KCH]
+    f32x4* V_lds = smem + G::IMGM;                                    // V image  [16][2][CCH]
+    float* raw = reinterpret_cast<float*>(smem + G::IMGM + G::IMGV);  // [2][ x: CCH x XCS | dy: KCH x DCS ]
 
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int wv_s = __builtin_amdgcn_readfirstlane(wv);
@@ -105,14 +120,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // which border rows / words of this chunk lie in the zero padding (uniform); an item in the padding reads at an
         // out-of-range offset, i.e. 0
         const unsigned bad = (iy0 < 0 ? 1u : 0u) | (iy0 + 3 >= a.H ? 2u : 0u) | (ixa < 0 ? 4u : 0u) | (ixa + 20 >= a.W ? 8u : 0u);
-        const unsigned xbase = (unsigned)(((b * a.C + cb * 64) * a.H + iy0) * a.W + ixa);      // may wrap below 0: sums are mod 2^32
+        const unsigned xbase = (unsigned)(((b * a.C + cb * CCH) * a.H + iy0) * a.W + ixa);     // may wrap below 0: sums are mod 2^32
 #pragma unroll
         for (int k = 0; k < NXL; ++k) {
             const unsigned vo = (xm[k] & bad) ? 0xFFFFFF00u : (xbase + xg[k]) * 4u;
             rx[k] = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
                                          : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
         }
-        const unsigned dbase = (unsigned)(((b * a.K + kb * 64) * a.Ho + 2 * ty) * a.Wo + 2 * tx0);
+        const unsigned dbase = (unsigned)(((b * a.K + kb * KCH) * a.Ho + 2 * ty) * a.Wo + 2 * tx0);
         const int wrem = a.Wo - 2 * tx0;                        // gradient columns of the chunk inside the row
 #pragma unroll
         for (int k = 0; k < NDL; ++k) {
@@ -132,75 +147,90 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
         for (int k = 0; k < NDL; ++k) *reinterpret_cast<f32x4*>(raw + buf * RAWBUF + dl[k]) = rd[k];
     };
-    // transforms of one chunk: thread = (channel `lane`, tile pair h + 4j, h + 4j + 2) with h = wv & 1, j = wv >> 1; the two
-    // tiles are components 2j, 2j + 1 of the channel's 16-byte image word -> one 8-byte write per position
-    const int th = wv & 1, tj = wv >> 1;
-    auto transform = [&](const int buf) __attribute__((always_inline)) {
-        const float* xs = raw + buf * RAWBUF + lane * XCS + coff + 2 * (th + 4 * tj);  // tile A; tile B: + 4 columns
-        const float* ds = raw + buf * RAWBUF + XRAW + lane * DCS + 2 * (th + 4 * tj);
-        float* const md = reinterpret_cast<float*>(M_lds + th * 64 + lane) + 2 * tj;
-        float* const vd = reinterpret_cast<float*>(V_lds + th * 64 + lane) + 2 * tj;
-        {   // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
-            float m[2][4][4];
+    // transforms of one chunk: work item = (channel, tile pair tp): tiles h + 4j, h + 4j + 2 with h = tp & 1, j = tp >> 1; the
+    // two tiles are components 2j, 2j + 1 of the channel's 16-byte image word -> one 8-byte write per position.  Items are
+    // dealt channel-fastest over the threads (64 channels: lane = channel, wave = tile pair).
+    auto xform_d = [&](const int buf, const int ch, const int tp) __attribute__((always_inline)) {
+        // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+        const int th = tp & 1, tj = tp >> 1;
+        const float* ds = raw + buf * RAWBUF + XRAW + ch * DCS + 2 * (th + 4 * tj);
+        float* const md = reinterpret_cast<float*>(M_lds + th * KCH + ch) + 2 * tj;
+        float m[2][4][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float2 r0 = *reinterpret_cast<const float2*>(ds + 4 * t), r1 = *reinterpret_cast<const float2*>(ds + DC + 4 * t);
-                const float u[4][2] = {{r0.x, r0.y}, {r0.x + r1.x, r0.y + r1.y}, {r0.x - r1.x, r0.y - r1.y}, {-r1.x, -r1.y}};
+        for (int t = 0; t < 2; ++t) {
+            const float2 r0 = *reinterpret_cast<const float2*>(ds + 4 * t), r1 = *reinterpret_cast<const float2*>(ds + DC + 4 * t);
+            const float u[4][2] = {{r0.x, r0.y}, {r0.x + r1.x, r0.y + r1.y}, {r0.x - r1.x, r0.y - r1.y}, {-r1.x, -r1.y}};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    m[t][i][0] = u[i][0];
-                    m[t][i][1] = u[i][0] + u[i][1];
-                    m[t][i][2] = u[i][0] - u[i][1];
-                    m[t][i][3] = -u[i][1];
-                }
+            for (int i = 0; i < 4; ++i) {
+                m[t][i][0] = u[i][0];
+                m[t][i][1] = u[i][0] + u[i][1];
+                m[t][i][2] = u[i][0] - u[i][1];
+                m[t][i][3] = -u[i][1];
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<float2*>(md + (i * 4 + j) * 512) = make_float2(m[0][i][j], m[1][i][j]);
         }
-        {   // V = B^T d B
-            float v[2][4][4];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float d[4][4], q[4][4];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float* row = xs + i * XC + 4 * t;      // 4-byte aligned only (coff is odd for pad 1): four dword reads,
-                    d[i][0] = row[0]; d[i][1] = row[1]; d[i][2] = row[2]; d[i][3] = row[3];   // paired by the compiler (ds_read2_b32)
-                }
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float2*>(md + (i * 4 + j) * (8 * KCH)) = make_float2(m[0][i][j], m[1][i][j]);
+    };
+    auto xform_x = [&](const int buf, const int ch, const int tp) __attribute__((always_inline)) {
+        // V = B^T d B
+        const int th = tp & 1, tj = tp >> 1;
+        const float* xs = raw + buf * RAWBUF + ch * XCS + coff + 2 * (th + 4 * tj);  // tile A; tile B: + 4 columns
+        float* const vd = reinterpret_cast<float*>(V_lds + th * CCH + ch) + 2 * tj;
+        float v[2][4][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    q[0][j] = d[0][j] - d[2][j];
-                    q[1][j] = d[1][j] + d[2][j];
-                    q[2][j] = d[2][j] - d[1][j];
-                    q[3][j] = d[1][j] - d[3][j];
-                }
+        for (int t = 0; t < 2; ++t) {
+            float d[4][4], q[4][4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[t][i][0] = q[i][0] - q[i][2];
-                    v[t][i][1] = q[i][1] + q[i][2];
-                    v[t][i][2] = q[i][2] - q[i][1];
-                    v[t][i][3] = q[i][1] - q[i][3];
-                }
+            for (int i = 0; i < 4; ++i) {
+                const float* row = xs + i * XC + 4 * t;      // 4-byte aligned only (coff is odd for pad 1): four dword reads,
+                d[i][0] = row[0]; d[i][1] = row[1]; d[i][2] = row[2]; d[i][3] = row[3];   // paired by the compiler (ds_read2_b32)
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                q[0][j] = d[0][j] - d[2][j];
+                q[1][j] = d[1][j] + d[2][j];
+                q[2][j] = d[2][j] - d[1][j];
+                q[3][j] = d[1][j] - d[3][j];
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    *reinterpret_cast<float2*>(vd + (i * 4 + j) * 512) = make_float2(v[0][i][j], v[1][i][j]);
+            for (int i = 0; i < 4; ++i) {
+                v[t][i][0] = q[i][0] - q[i][2];
+                v[t][i][1] = q[i][1] + q[i][2];
+                v[t][i][2] = q[i][2] - q[i][1];
+                v[t][i][3] = q[i][1] - q[i][3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<float2*>(vd + (i * 4 + j) * (8 * CCH)) = make_float2(v[0][i][j], v[1][i][j]);
+    };
+    auto transform = [&](const int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < (KCH * 4 + NT - 1) / NT; ++r) {
+            const int it = tid + NT * r;
+            if ((KCH * 4) % NT == 0 || it < KCH * 4) xform_d(buf, it % KCH, it / KCH);
+        }
+#pragma unroll
+        for (int r = 0; r < (CCH * 4 + NT - 1) / NT; ++r) {
+            const int it = tid + NT * r;
+            if ((CCH * 4) % NT == 0 || it < CCH * 4) xform_x(buf, it % CCH, it / CCH);
         }
     };
 
-    f32x16 acc[16];
+    // MFMA phase: wave w owns positions 4w .. 4w+3 of every sub-block: per position KS + CS operand words (16 bytes = the 4
+    // k-steps of a chunk) feed 4 KS CS MFMAs, and consecutive MFMAs run on different accumulators.
+    f32x16 acc[G::NACC];
 #pragma unroll
-    for (int p = 0; p < 16; ++p)
+    for (int p = 0; p < G::NACC; ++p)
 #pragma unroll
         for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
-    const int ki = wv & 1, ci = wv >> 1;
-    const f32x4* const Uc = M_lds + (lane >> 5) * 64 + ki * 32 + (lane & 31);
-    const f32x4* const Vc = V_lds + (lane >> 5) * 64 + ci * 32 + (lane & 31);
+    const f32x4* const Mw = M_lds + (4 * wv_s) * (2 * KCH) + (lane >> 5) * KCH + (lane & 31);
+    const f32x4* const Vw = V_lds + (4 * wv_s) * (2 * CCH) + (lane >> 5) * CCH + (lane & 31);
 
     if (n > 0) {
         // prologue: chunk 0 -> raw[0] -> images; chunk 1 -> raw[1]; chunk 2 in registers
@@ -214,27 +244,33 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         __syncthreads();
         for (int g = 0; g < n; ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
-            f32x4 ua[16], vb[16];
-            ua[0] = Uc[0]; vb[0] = Vc[0];
-            ua[1] = Uc[128]; vb[1] = Vc[128];
+            f32x4 ua[2][KS], vb[2][CS];
+#pragma unroll
+            for (int i = 0; i < KS; ++i) ua[0][i] = Mw[i * 32];
+#pragma unroll
+            for (int i = 0; i < CS; ++i) vb[0][i] = Vw[i * 32];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int sl = 0; sl < 32; ++sl) {
-                const int p0 = 2 * (sl >> 2), p1 = p0 + 1, ks = sl & 3;
-                if (!(DMH_WRW_ABLATE & 8)) {
-                    acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], acc[p0], 0, 0, 0);
-                    acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], acc[p1], 0, 0, 0);
-                } else {
-                    acc[p0][ks] += ua[p0][ks] * vb[p0][ks];
-                    acc[p1][ks] += ua[p1][ks] * vb[p1][ks];
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int ci = 0; ci < CS; ++ci)
+#pragma unroll
+                        for (int ki = 0; ki < KS; ++ki) {
+                            f32x16& c = acc[(q * CS + ci) * KS + ki];
+                            if (!(DMH_WRW_ABLATE & 8)) c = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[q & 1][ki][ks], vb[q & 1][ci][ks], c, 0, 0, 0);
+                            else c[ks] += ua[q & 1][ki][ks] * vb[q & 1][ci][ks];
+                        }
+                    if (q + 1 < 4) {                          // operands of the next position, spread over the four k-steps
+#pragma unroll
+                        for (int r = ks; r < KS + CS; r += 4) {
+                            if (r < KS) ua[(q + 1) & 1][r] = Mw[(q + 1) * (2 * KCH) + r * 32];
+                            else vb[(q + 1) & 1][r - KS] = Vw[(q + 1) * (2 * CCH) + (r - KS) * 32];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (p0 + 2 < 16) {                          // operands of the next position pair, one read per slot
-                    if (ks == 0) ua[p0 + 2] = Uc[(p0 + 2) * 128];
-                    if (ks == 1) vb[p0 + 2] = Vc[(p0 + 2) * 128];
-                    if (ks == 2) ua[p1 + 2] = Uc[(p1 + 2) * 128];
-                    if (ks == 3) vb[p1 + 2] = Vc[(p1 + 2) * 128];
-                }
-                __builtin_amdgcn_sched_barrier(0);
             }
             // raw registers (chunk g+2) -> raw[cur] (read by transform(g) one iteration ago), then refill with chunk g+3
             if (!(DMH_WRW_ABLATE & 4)) store_raw(cur);
@@ -249,29 +285,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             asm volatile("" ::: "memory");
         }
     }
-    // ---- partial dU of this slice: ws[pair][slice][p][k 64][c 64]; D row (k) = 8 (v >> 2) + 4 (lane >> 5) + (v & 3), col (c) = lane & 31
-    float* wsb = a.ws + ((size_t)pair * a.S + slice) * (16 * 4096) + (size_t)(ki * 32 + 4 * (lane >> 5)) * 64 + ci * 32 + (lane & 31);
+    // ---- partial dU of this slice: ws[pair][slice][p][k KCH][c CCH]; D row (k) = 8 (v >> 2) + 4 (lane >> 5) + (v & 3), col (c) = lane & 31
+    float* wsb = a.ws + (((size_t)pair * a.S + slice) * 16 + 4 * wv) * (KCH * CCH) + (size_t)(4 * (lane >> 5)) * CCH + (lane & 31);
 #pragma unroll
-    for (int p = 0; p < 16; ++p) {
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int v = 0; v < 16; ++v) wsb[(size_t)p * 4096 + ((v & 3) + 8 * (v >> 2)) * 64] = acc[p][v];
-        __builtin_amdgcn_sched_barrier(0);
-    }
+        for (int ci = 0; ci < CS; ++ci)
+#pragma unroll
+            for (int ki = 0; ki < KS; ++ki) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v)
+                    wsb[(size_t)q * (KCH * CCH) + (ki * 32 + (v & 3) + 8 * (v >> 2)) * CCH + ci * 32] = acc[(q * CS + ci) * KS + ki][v];
+                __builtin_amdgcn_sched_barrier(0);
+            }
 }
 
 // dw[k][c][3][3] = G^T (sum over the slices of dU[.][k][c]) G,  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]; slices in order.
 // A block = 16 consecutive input channels of one output channel x the 16 positions: every thread adds the S slices of its
 // (c, p) (64-byte segments per slice), the 4 x 4 sums meet in LDS and 144 threads form one filter tap each.
-__global__ __launch_bounds__(NT) void wino_wrw_reduce_kernel(const float* __restrict__ ws, int K, int C, int nc, int S,
-                                                             float* __restrict__ dw) {
+__global__ __launch_bounds__(NT) void wino_wrw_reduce_kernel(const float* __restrict__ ws, int K, int C, int kch, int cch, int nc,
+                                                             int S, float* __restrict__ dw) {
     __shared__ float su[16][17];                        // [position][channel], padded
     const int cl = threadIdx.x & 15, p = threadIdx.x >> 4;
     const int cblocks = C >> 4;
     const int k = (int)blockIdx.x / cblocks, c = ((int)blockIdx.x - k * cblocks) * 16 + cl;
-    const int pair = (k >> 6) * nc + (c >> 6);
-    const float* src = ws + (size_t)pair * S * (16 * 4096) + (size_t)p * 4096 + (size_t)(k & 63) * 64 + (c & 63);
+    const int pair = (k / kch) * nc + c / cch;
+    const size_t blk = (size_t)kch * cch;
+    const float* src = ws + (size_t)pair * S * (16 * blk) + (size_t)p * blk + (size_t)(k % kch) * cch + (c % cch);
     float s = 0.f;
-    for (int q = 0; q < S; ++q) s += src[(size_t)q * (16 * 4096)];
+    for (int q = 0; q < S; ++q) s += src[(size_t)q * (16 * blk)];
     su[p][cl] = s;
     __syncthreads();
     if (threadIdx.x < 144) {
@@ -301,12 +343,20 @@ int num_cus() {
     return n;
 }
 
-void plan(RArgs& a) {
+// block shape for (K, C): 0 = none
+int pick_shape(int K, int C, int& kch, int& cch) {
+    if (K % 64 == 0 && C % 64 == 0) { kch = 64; cch = 64; return 1; }
+    if (K % 32 == 0 && C % 96 == 0) { kch = 32; cch = 96; return 2; }
+    if (K % 32 == 0 && C % 64 == 0) { kch = 32; cch = 64; return 3; }
+    return 0;
+}
+
+void plan(RArgs& a, int kch, int cch) {
     a.Ht = a.Ho / 2;
     a.cpr = (a.Wo / 2 + TPC - 1) / TPC;
     a.nchunks = a.B * a.Ht * a.cpr;
-    a.nk = a.K / 64;
-    a.nc = a.C / 64;
+    a.nk = a.K / kch;
+    a.nc = a.C / cch;
     const int pairs = a.nk * a.nc;
     int S = num_cus() / pairs;
     if (S < 1) S = 1;
@@ -315,23 +365,40 @@ void plan(RArgs& a) {
     a.cps = (a.nchunks + S - 1) / S;
 }
 
+template <int KS, int CS>
+int launch(const RArgs& a, hipStream_t st) {
+    constexpr size_t smem = Cfg<KS, CS>::SMEM;
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wrw_kernel<KS, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)smem) != hipSuccess)
+            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_wrw");
+        configured = true;
+    }
+    hipLaunchKernelGGL((wino_wrw_kernel<KS, CS>), dim3((unsigned)(a.nk * a.nc * a.S)), dim3(NT), smem, st, a);
+    return check_launch("dmh_wino_wrw");
+}
+
 }  // namespace
 
 extern "C" {
 
 int64_t dmh_wino_wrw_workspace_size(int B, int C, int K, int H, int W, int pad) {
-    if (B <= 0 || C <= 0 || K <= 0 || C % 64 || K % 64 || pad < 0 || pad > 1 || (pad == 1 && W % 16)) return -1;
+    int kch, cch;
+    if (B <= 0 || C <= 0 || K <= 0 || !pick_shape(K, C, kch, cch) || pad < 0 || pad > 1 || (pad == 1 && W % 16)) return -1;
     RArgs a;
     a.B = B; a.C = C; a.K = K; a.H = H; a.W = W; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
     if (a.Ho < 2 || a.Wo < 2 || (a.Ho & 1) || (a.Wo & 1)) return -1;
-    plan(a);
-    return (int64_t)a.nk * a.nc * a.S * 16 * 4096;
+    plan(a, kch, cch);
+    return (int64_t)a.nk * a.nc * a.S * 16 * kch * cch;
 }
 
 int dmh_wino_wrw(const float* x, const float* dy, int B, int C, int K, int H, int W, int pad, float* workspace, float* dw,
                  void* stream) {
     DMH_REQUIRE(x && dy && workspace && dw, "null pointer");
-    DMH_REQUIRE(B > 0 && C >= 64 && K >= 64 && C % 64 == 0 && K % 64 == 0, "channel counts must be multiples of 64");
+    int kch = 0, cch = 0;
+    const int shape = (B > 0 && C > 0 && K > 0) ? pick_shape(K, C, kch, cch) : 0;
+    DMH_REQUIRE(shape != 0, "channel counts: K and C multiples of 64, or K a multiple of 32 with C a multiple of 96 or 64");
     DMH_REQUIRE(pad == 0 || pad == 1, "pad must be 0 or 1");
     DMH_REQUIRE(pad == 0 || W % 16 == 0, "with pad 1 the width must be a multiple of 16 (whole 8-tile chunks: the zero\n"
                 "padding column then lies in the last 16-byte word of a chunk row)");
@@ -341,19 +408,14 @@ int dmh_wino_wrw(const float* x, const float* dy, int B, int C, int K, int H, in
     DMH_REQUIRE(a.Ho >= 2 && a.Wo >= 2 && (a.Ho & 1) == 0 && (a.Wo & 1) == 0, "output height and width must be even");
     DMH_REQUIRE((int64_t)B * C * H * W < ((int64_t)1 << 30) && (int64_t)B * K * a.Ho * a.Wo < ((int64_t)1 << 30),
                 "tensor larger than 4 GB (32-bit byte offsets of the buffer loads)");
-    plan(a);
-    constexpr size_t smem = (size_t)2 * IMG * 16 + (size_t)2 * RAWBUF * 4;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wrw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_wrw");
-        configured = true;
-    }
-    hipLaunchKernelGGL(wino_wrw_kernel, dim3((unsigned)(a.nk * a.nc * a.S)), dim3(NT), smem, (hipStream_t)stream, a);
-    if (int rc = check_launch("dmh_wino_wrw")) return rc;
+    plan(a, kch, cch);
+    int rc;
+    if (shape == 1) rc = launch<2, 2>(a, (hipStream_t)stream);
+    else if (shape == 2) rc = launch<1, 3>(a, (hipStream_t)stream);
+    else rc = launch<1, 2>(a, (hipStream_t)stream);
+    if (rc) return rc;
     hipLaunchKernelGGL(wino_wrw_reduce_kernel, dim3((unsigned)(K * (C / 16))), dim3(NT), 0, (hipStream_t)stream,
-                       workspace, K, C, a.nc, a.S, dw);
+                       workspace, K, C, kch, cch, a.nc, a.S, dw);
     return check_launch("dmh_wino_wrw (reduce)");
 }
 

@@ -852,9 +852,18 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
 
 
 def _wrw_ok(x, g, K, Cc):
-    """Shapes of K18 (Winograd-domain weight gradient): both channel counts multiples of 64, even output size, enough tile
-    chunks (8 tiles) to give every workgroup of a (k-block, c-block) pair a few, tensors below 4 GB."""
-    if not WINO_ENABLED or not WRW_ENABLED or K % 64 or Cc % 64 or g.shape[2] % 2 or g.shape[3] % 2:
+    """Shapes of K18 (Winograd-domain weight gradient): both channel counts multiples of 64 (64 x 64 blocks), or 32 k output
+    channels with 96 k' / 64 k' input channels (32 x 96 / 32 x 64 blocks: upconv(1,1), upconv(1,0)); even output size, enough
+    tile chunks (8 tiles) to give every workgroup of a (k-block, c-block) pair a few, tensors below 4 GB."""
+    if not WINO_ENABLED or not WRW_ENABLED or g.shape[2] % 2 or g.shape[3] % 2:
+        return False
+    if K % 64 == 0 and Cc % 64 == 0:
+        kch, cch = 64, 64
+    elif K % 32 == 0 and Cc % 96 == 0:
+        kch, cch = 32, 96
+    elif K % 32 == 0 and Cc % 64 == 0:
+        kch, cch = 32, 64
+    else:
         return False
     pad = (g.shape[2] + 2 - x.shape[2]) // 2
     if pad not in (0, 1) or (pad == 1 and x.shape[3] % 16):
@@ -862,7 +871,7 @@ def _wrw_ok(x, g, K, Cc):
     if x.numel() >= (1 << 30) or g.numel() >= (1 << 30):
         return False
     chunks = g.shape[0] * (g.shape[2] // 2) * -(-(g.shape[3] // 2) // 8)
-    return chunks * (K // 64) * (Cc // 64) >= 1024
+    return chunks * (K // kch) * (Cc // cch) >= 1024
 
 
 def _wino32_ok(B, n_in, n_out, Ho, Wo):

@@ -62,8 +62,8 @@ def test_convolution_entry_points_reject_bad_shapes_without_gpu():
     assert lib.dmh_wino32_weight_size(32, 96) == (96 // 8) * 16 * 2 * 32 * 4
     assert lib.dmh_wino32_weight_size(96, 32) == (32 // 8) * 16 * 2 * 96 * 4       # output channels padded to 32s
     assert lib.dmh_wino32_conv3x3(one, one, None, 1, 16, 32, 8, 8, 1, one, None) != 0        # < 24 input channels
-    assert lib.dmh_wino_wrw_workspace_size(2, 64, 64, 16, 32, 1) > 0 and lib.dmh_wino_wrw_workspace_size(2, 96, 64, 16, 32, 1) == -1 and lib.dmh_wino_wrw_workspace_size(2, 64, 64, 16, 24, 1) == -1
-    assert lib.dmh_wino_wrw(one, one, 1, 64, 96, 8, 8, 1, one, one, None) != 0                # K not a multiple of 64
+    assert lib.dmh_wino_wrw_workspace_size(2, 64, 64, 16, 32, 1) > 0 and lib.dmh_wino_wrw_workspace_size(2, 96, 32, 16, 32, 1) > 0 and lib.dmh_wino_wrw_workspace_size(2, 48, 64, 16, 32, 1) == -1 and lib.dmh_wino_wrw_workspace_size(2, 64, 64, 16, 24, 1) == -1
+    assert lib.dmh_wino_wrw(one, one, 1, 64, 48, 8, 8, 1, one, one, None) != 0                # K not a multiple of 32
     assert lib.dmh_wino_conv3x3(one, one, None, 1, 16, 64, 8, 8, 1, one, None) != 0          # < 24 input channels
     assert b"multiple of 8" in lib.dmh_last_error()
     assert lib.dmh_wino_conv3x3(one, one, None, 1, 32, 64, 9, 8, 1, one, None) != 0          # odd output height

@@ -382,6 +382,10 @@ def test_conv3x3_op_takes_k17_for_the_32_channel_decoder_layers():
     (3, 128, 64, 10, 34, 0),     # decoder-like (pre-padded input): 17 tile columns = 2 chunks + 1 ragged tile
     (1, 64, 128, 6, 16, 1),      # two k-blocks, one chunk per tile row, few chunks (more slices than chunks per pair)
     (2, 64, 64, 4, 16, 1),       # one chunk per tile row, every chunk touches all four borders
+    (2, 96, 32, 12, 36, 0),      # 32 x 96 blocks (upconv(1,1)): 18 tile columns = 2 chunks + 2 ragged tiles
+    (2, 64, 32, 8, 32, 0),       # 32 x 64 blocks (upconv(1,0))
+    (1, 192, 64, 6, 18, 0),      # 64 x 64 blocks preferred over 32 x 96 when both fit; three c-blocks
+    (2, 96, 96, 8, 16, 1),       # three k-blocks x one c-block of the 32 x 96 shape, zero padding
 ])
 def test_wino_wrw_kernel_vs_aten(shape):
     """K18 (Winograd-domain weight gradient on the fp32 MFMA) through the C ABI == ATen's convolution_backward weight

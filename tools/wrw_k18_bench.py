@@ -14,7 +14,7 @@ torch.backends.cudnn.benchmark = False
 SHAPES = [(64, 64, 80, 256, 1, "layer1"), (128, 128, 40, 128, 1, "layer2"), (256, 256, 20, 64, 1, "layer3"),
           (512, 512, 10, 32, 1, "layer4"), (512, 256, 10, 32, 0, "upconv4_0"), (512, 256, 20, 64, 0, "upconv4_1"),
           (256, 128, 20, 64, 0, "upconv3_0"), (256, 128, 40, 128, 0, "upconv3_1"), (128, 64, 40, 128, 0, "upconv2_0"),
-          (128, 64, 80, 256, 0, "upconv2_1")]
+          (128, 64, 80, 256, 0, "upconv2_1"), (64, 32, 80, 256, 0, "upconv1_0"), (96, 32, 160, 512, 0, "upconv1_1")]
 
 
 def timeit(fn, it=10):
