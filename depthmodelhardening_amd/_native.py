@@ -82,6 +82,8 @@ _SIGNATURES = {
     "dmh_bn_act_bwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp, _fp, _fp]),
     "dmh_bn_stats_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dmh_bn_train_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float] + [_fp] * 8),
+    "dmh_bn_train_bwd_workspace_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dmh_bn_train_bwd": (C.c_int, [_fp] * 6 + [C.c_int, C.c_int, C.c_int] + [_fp] * 5 + [C.c_void_p]),
     "dmh_stem_bn_relu_pool_fwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp] * 4),
     "dmh_stem_bn_relu_pool_bwd": (C.c_int, [_fp] * 5 + [C.c_int] * 4 + [_fp, _fp]),
     "dmh_wino_weight_size": (C.c_int64, [C.c_int, C.c_int]),

@@ -313,6 +313,144 @@ __global__ __launch_bounds__(NT) void bn_stats_finalize_kernel(const float* __re
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + NT - 1) / NT); }
 
+// ---- train-mode BatchNorm backward with the ReLU mask folded in (round 3; MD2/trainer.py:335-375 train pass through
+// torchvision's BasicBlocks).  With g' = g * [out > 0] (or g), xc = x - mean, N = B * HW:
+//     db = sum g',   dw = invstd * sum g' xc,   dx = w invstd ( g' - db / N - xc * invstd^2 * (sum g' xc) / N )
+// in three launches: per-(slab, channel) partial sums (x, g, out read once), one thread per channel combining them in a fixed
+// order (double) into db, dw and the three coefficients of dx, and one element-wise pass (x, g, out read again, dx and --
+// for a residual branch -- g' written).  Before: one K9 mask pass + MIOpen's two-pass kernel (8 tensor passes, now 7 / 8
+// without / with a residual branch, and no atomics).
+template <bool RELU, bool VEC>
+__global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ out, const float* __restrict__ mean,
+                                                            int B, int C, int HW, int S, float* __restrict__ part) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    const float m = mean[c];
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};     // 4 independent chains
+    for (int b = 0; b < B; ++b) {
+        const size_t base = ((size_t)b * C + c) * HW;
+        if (VEC) {      // HW % 4 == 0: slabs of 4 * NT elements as one float4 per thread
+            for (int r = s * 4 * NT + 4 * (int)threadIdx.x; r < HW; r += S * 4 * NT) {
+                const float4 xv = *reinterpret_cast<const float4*>(x + base + r);
+                float4 gv = *reinterpret_cast<const float4*>(g + base + r);
+                if (RELU) {
+                    const float4 o = *reinterpret_cast<const float4*>(out + base + r);
+                    gv = make_float4(o.x > 0.f ? gv.x : 0.f, o.y > 0.f ? gv.y : 0.f, o.z > 0.f ? gv.z : 0.f, o.w > 0.f ? gv.w : 0.f);
+                }
+                a1[0] += gv.x; a1[1] += gv.y; a1[2] += gv.z; a1[3] += gv.w;
+                a2[0] = fmaf(gv.x, xv.x - m, a2[0]); a2[1] = fmaf(gv.y, xv.y - m, a2[1]);
+                a2[2] = fmaf(gv.z, xv.z - m, a2[2]); a2[3] = fmaf(gv.w, xv.w - m, a2[3]);
+            }
+        } else {
+            for (int r0 = s * 4 * NT; r0 < HW; r0 += S * 4 * NT) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = r0 + q * NT + (int)threadIdx.x;
+                    if (r < HW) {
+                        float gv = g[base + r];
+                        if (RELU) gv = out[base + r] > 0.f ? gv : 0.f;
+                        a1[q] += gv;
+                        a2[q] = fmaf(gv, x[base + r] - m, a2[q]);
+                    }
+                }
+            }
+        }
+    }
+    float s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]), s2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);
+    // wave, then block reduction (fixed order: reproducible)
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) {
+        s1 += __shfl_down(s1, o, WAVE);
+        s2 += __shfl_down(s2, o, WAVE);
+    }
+    __shared__ float red[NT / WAVE][2];
+    if ((threadIdx.x & (WAVE - 1)) == 0) {
+        red[threadIdx.x / WAVE][0] = s1;
+        red[threadIdx.x / WAVE][1] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t1 = red[0][0], t2 = red[0][1];
+#pragma unroll
+        for (int i = 1; i < NT / WAVE; ++i) {
+            t1 += red[i][0];
+            t2 += red[i][1];
+        }
+        part[((size_t)c * S + s) * 2 + 0] = t1;
+        part[((size_t)c * S + s) * 2 + 1] = t2;
+    }
+}
+
+// coef[c] = { w invstd, db / N, invstd^2 sum(g' xc) / N, mean }
+__global__ __launch_bounds__(NT) void bn_bwd_finalize_kernel(const float* __restrict__ part, int C, int S, double inv_n,
+                                                             const float* __restrict__ weight, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ coef,
+                                                             float* __restrict__ g_weight, float* __restrict__ g_bias) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        s1 += (double)part[((size_t)c * S + s) * 2 + 0];
+        s2 += (double)part[((size_t)c * S + s) * 2 + 1];
+    }
+    const double is = (double)invstd[c], w = weight ? (double)weight[c] : 1.0;
+    if (g_bias) g_bias[c] = (float)s1;
+    if (g_weight) g_weight[c] = (float)(s2 * is);
+    float4 k;
+    k.x = (float)(w * is);
+    k.y = (float)(s1 * inv_n);
+    k.z = (float)(s2 * is * is * inv_n);
+    k.w = mean[c];
+    reinterpret_cast<float4*>(coef)[c] = k;
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_vec(const float4* __restrict__ x, const float4* __restrict__ g,
+                                                       const float4* __restrict__ out, const float4* __restrict__ coef,
+                                                       unsigned C, unsigned hw4, unsigned total4, float4* __restrict__ g_x,
+                                                       float4* __restrict__ g_res) {
+    const unsigned i = blockIdx.x * NT + threadIdx.x;
+    if (i >= total4) return;
+    const float4 k = coef[(i / hw4) % C];
+    const float4 xv = x[i];
+    float4 gv = g[i];
+    if (RELU) {
+        const float4 o = out[i];
+        gv = make_float4(o.x > 0.f ? gv.x : 0.f, o.y > 0.f ? gv.y : 0.f, o.z > 0.f ? gv.z : 0.f, o.w > 0.f ? gv.w : 0.f);
+    }
+    if (RES) g_res[i] = gv;
+    g_x[i] = make_float4(k.x * ((gv.x - k.y) - (xv.x - k.w) * k.z), k.x * ((gv.y - k.y) - (xv.y - k.w) * k.z),
+                         k.x * ((gv.z - k.y) - (xv.z - k.w) * k.z), k.x * ((gv.w - k.y) - (xv.w - k.w) * k.z));
+}
+
+template <bool RELU, bool RES>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_scalar(const float* __restrict__ x, const float* __restrict__ g,
+                                                          const float* __restrict__ out, const float4* __restrict__ coef,
+                                                          unsigned C, unsigned hw, unsigned total, float* __restrict__ g_x,
+                                                          float* __restrict__ g_res) {
+    const unsigned i = blockIdx.x * NT + threadIdx.x;
+    if (i >= total) return;
+    const float4 k = coef[(i / hw) % C];
+    float gv = g[i];
+    if (RELU) gv = out[i] > 0.f ? gv : 0.f;
+    if (RES) g_res[i] = gv;
+    g_x[i] = k.x * ((gv - k.y) - (x[i] - k.w) * k.z);
+}
+
+template <bool RELU, bool RES>
+void launch_bn_bwd_apply(const float* x, const float* g, const float* out, const float* coef, int C, int HW, int64_t total,
+                         float* g_x, float* g_res, hipStream_t st) {
+    if ((HW & 3) == 0)
+        hipLaunchKernelGGL((bn_bwd_apply_vec<RELU, RES>), dim3(blocks_for(total / 4)), dim3(NT), 0, st,
+                           reinterpret_cast<const float4*>(x), reinterpret_cast<const float4*>(g),
+                           reinterpret_cast<const float4*>(out), reinterpret_cast<const float4*>(coef), (unsigned)C,
+                           (unsigned)(HW / 4), (unsigned)(total / 4), reinterpret_cast<float4*>(g_x),
+                           reinterpret_cast<float4*>(g_res));
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_scalar<RELU, RES>), dim3(blocks_for(total)), dim3(NT), 0, st, x, g, out,
+                           reinterpret_cast<const float4*>(coef), (unsigned)C, (unsigned)HW, (unsigned)total, g_x, g_res);
+}
+
 template <bool RELU, bool RES>
 void launch_fwd(const float* x, const float* scale, const float* shift, const float* res, int C, int HW, int64_t total,
                 float* out, hipStream_t st) {
@@ -395,6 +533,46 @@ int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(blocks_for(C)), dim3(NT), 0, st, partials, C, (int)S, weight, bias,
                        momentum, eps, running_mean, running_var, scale, shift, save_mean, save_invstd);
     return check_launch("dmh_bn_train_stats");
+}
+
+int64_t dmh_bn_train_bwd_workspace_size(int B, int C, int HW) {
+    const int64_t S = dmh_bn_stats_partials_size(B, C, HW);
+    if (S < 0) return -1;
+    return S / 3 * 2 + (int64_t)C * 4;      // [C][S][2] partial sums + [C] float4 coefficients
+}
+
+int dmh_bn_train_bwd(const float* x, const float* g_out, const float* out, const float* weight, const float* save_mean,
+                     const float* save_invstd, int B, int C, int HW, float* workspace, float* g_x, float* g_weight,
+                     float* g_bias, float* g_pre, void* stream) {
+    DMH_REQUIRE(x && g_out && save_mean && save_invstd && workspace && g_x, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && HW > 0 && C <= 65535, "bad sizes");
+    const int64_t total = (int64_t)B * C * HW;
+    DMH_REQUIRE(total < ((int64_t)1 << 31), "tensor too large");
+    DMH_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0, "workspace must be 16-byte aligned");
+    int64_t S = ((int64_t)HW + 4 * NT - 1) / (4 * NT);     // slabs per plane, as for the forward statistics
+    if (S > 64) S = 64;
+    hipStream_t st = (hipStream_t)stream;
+    float* coef = workspace;                                // [C] float4 first: keeps its alignment
+    float* part = workspace + (size_t)C * 4;
+    const dim3 pg((unsigned)S, C);
+    const bool vec = (HW & 3) == 0;
+    if (out) {
+        if (vec) hipLaunchKernelGGL((bn_bwd_partial_kernel<true, true>), pg, dim3(NT), 0, st, x, g_out, out, save_mean, B, C, HW, (int)S, part);
+        else hipLaunchKernelGGL((bn_bwd_partial_kernel<true, false>), pg, dim3(NT), 0, st, x, g_out, out, save_mean, B, C, HW, (int)S, part);
+    } else {
+        if (vec) hipLaunchKernelGGL((bn_bwd_partial_kernel<false, true>), pg, dim3(NT), 0, st, x, g_out, out, save_mean, B, C, HW, (int)S, part);
+        else hipLaunchKernelGGL((bn_bwd_partial_kernel<false, false>), pg, dim3(NT), 0, st, x, g_out, out, save_mean, B, C, HW, (int)S, part);
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(blocks_for(C)), dim3(NT), 0, st, part, C, (int)S,
+                       1.0 / ((double)B * (double)HW), weight, save_mean, save_invstd, coef, g_weight, g_bias);
+    if (out) {
+        if (g_pre) launch_bn_bwd_apply<true, true>(x, g_out, out, coef, C, HW, total, g_x, g_pre, st);
+        else launch_bn_bwd_apply<true, false>(x, g_out, out, coef, C, HW, total, g_x, nullptr, st);
+    } else {
+        if (g_pre) launch_bn_bwd_apply<false, true>(x, g_out, out, coef, C, HW, total, g_x, g_pre, st);
+        else launch_bn_bwd_apply<false, false>(x, g_out, out, coef, C, HW, total, g_x, nullptr, st);
+    }
+    return check_launch("dmh_bn_train_bwd");
 }
 
 int dmh_stem_bn_relu_pool_fwd(const float* x, const float* scale, const float* shift, int B, int C, int H, int W,

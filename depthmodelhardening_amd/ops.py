@@ -630,6 +630,27 @@ def _bn_backward(g_pre, x, weight, bn, mean, invstd, eps, mask):
                                                      eps, mask)
 
 
+BN_BWD_ENABLED = os.environ.get("DMH_BN_BWD", "1") != "0"      # A/B switch: 0 = K9 mask pass + MIOpen's backward
+
+
+def _bn_backward_fused(g, x, out, weight, mean, invstd, want_pre):
+    """K9 train-mode BatchNorm backward (dmh_bn_train_bwd): ReLU mask (``out`` = the saved ReLU output, or None) + the
+    three gradients in three launches.  Returns (g_x, g_weight, g_bias, g_pre or None)."""
+    lib = N.lib()
+    B, Cc = g.shape[0], g.shape[1]
+    HW = g.numel() // (B * Cc)
+    ws = torch.empty(lib.dmh_bn_train_bwd_workspace_size(B, Cc, HW), device=g.device, dtype=torch.float32)
+    gx = torch.empty_like(g)
+    gw = torch.empty(Cc, device=g.device, dtype=torch.float32)
+    gb = torch.empty(Cc, device=g.device, dtype=torch.float32)
+    g_pre = torch.empty_like(g) if want_pre else None
+    nb = 4 * g.numel() * ((6 if out is not None else 4) + 1 + (1 if want_pre else 0))
+    N.check(_timed("bn_train_bwd", lambda: lib.dmh_bn_train_bwd(
+        N.ptr(x), N.ptr(g), N.ptr(out), N.ptr(weight), N.ptr(mean), N.ptr(invstd), B, Cc, HW, N.ptr(ws), N.ptr(gx), N.ptr(gw),
+        N.ptr(gb), N.ptr(g_pre), N.stream()), nb))
+    return gx, gw, gb, g_pre
+
+
 class _BnActTrain(torch.autograd.Function):
     """Train-mode BatchNorm2d -> (+ residual) -> ReLU: K9 statistics + one bn_act pass forward; backward = ReLU mask
     (one K9 pass) + aten::native_batch_norm_backward (MIOpen) with the saved batch statistics."""
@@ -655,6 +676,12 @@ class _BnActTrain(torch.autograd.Function):
         lib = N.lib()
         g = _c(g)
         B, Cc = g.shape[0], g.shape[1]
+        if BN_BWD_ENABLED and weight is not None and g.numel() < (1 << 31):
+            gx, gw, gb, g_pre = _bn_backward_fused(g, x, out if ctx.relu else None, weight, mean, invstd,
+                                                   ctx.res_grad and ctx.relu)
+            if ctx.res_grad and not ctx.relu:
+                g_pre = g
+            return gx, gw, gb, (g_pre if ctx.res_grad else None), None, None
         if ctx.relu:
             ones = frozen_memo(("ones", Cc, g.device), lambda: torch.ones(Cc, device=g.device, dtype=torch.float32))
             g_pre = torch.empty_like(g)
@@ -746,6 +773,9 @@ class _StemTrain(torch.autograd.Function):
         N.check(_timed("stem_bwd", lambda: lib.dmh_stem_bn_relu_pool_bwd(N.ptr(feat), N.ptr(arg), N.ptr(g_feat),
                                                                         N.ptr(g_pooled), N.ptr(ones), B, Cc, H, W,
                                                                         N.ptr(g_pre), N.stream()), 12 * feat.numel()))
+        if BN_BWD_ENABLED and weight is not None and g_pre.numel() < (1 << 31):
+            gx, gw, gb, _ = _bn_backward_fused(g_pre, x, None, weight, mean, invstd, False)
+            return gx, gw, gb, None
         gx, gw, gb = _bn_backward(g_pre, x, weight, ctx.bn, mean, invstd, ctx.eps,
                                   [ctx.needs_input_grad[0], weight is not None and ctx.needs_input_grad[1],
                                    weight is not None and ctx.needs_input_grad[2]])

@@ -272,6 +272,18 @@ int64_t dmh_bn_stats_partials_size(int B, int C, int HW);
 int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
                        float eps, float* running_mean, float* running_var, float* partials, float* scale, float* shift,
                        float* save_mean, float* save_invstd, void* stream);
+/* train-mode BatchNorm backward with the ReLU mask folded in (replaces one dmh_bn_act_bwd pass +
+ * aten::miopen_batch_norm_backward in the train pass; torch.nn.BatchNorm2d semantics, torch/nn/functional.py batch_norm
+ * as called by torchvision's BasicBlock, MD2/networks/resnet_encoder.py:85-98):
+ *   g' = out ? g_out * [out > 0] : g_out;   g_bias = sum g';   g_weight = invstd * sum g' (x - mean);
+ *   g_x = weight invstd ( g' - g_bias / N - (x - mean) invstd^2 sum g' (x - mean) / N ),  N = B * HW.
+ * out (the saved ReLU output), weight (NULL = 1), g_weight, g_bias, g_pre (receives g', the gradient of a residual branch)
+ * may be NULL.  workspace: dmh_bn_train_bwd_workspace_size(B, C, HW) floats, 16-byte aligned.  Three launches, fixed-order
+ * sums: bitwise reproducible. */
+int64_t dmh_bn_train_bwd_workspace_size(int B, int C, int HW);
+int dmh_bn_train_bwd(const float* x, const float* g_out, const float* out, const float* weight, const float* save_mean,
+                     const float* save_invstd, int B, int C, int HW, float* workspace, float* g_x, float* g_weight,
+                     float* g_bias, float* g_pre, void* stream);
 int dmh_stem_bn_relu_pool_fwd(const float* x, const float* scale, const float* shift, int B, int C, int H, int W,
                               float* feat, float* pooled, unsigned char* argmax, void* stream);
 int dmh_stem_bn_relu_pool_bwd(const float* feat, const unsigned char* argmax, const float* g_feat, const float* g_pooled,

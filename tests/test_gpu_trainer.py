@@ -639,6 +639,52 @@ def test_train_mode_fused_batchnorm_matches_modules():
         torch.testing.assert_close(a.float(), b.float(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(3, 8, 10, 18), (2, 5, 7, 9), (4, 64, 20, 64)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_bn_train_bwd_kernel_vs_autograd(shape, relu, res):
+    """dmh_bn_train_bwd (K9: ReLU mask + train-mode BatchNorm backward in three launches) through the C ABI == autograd of
+    relu(F.batch_norm(x, training=True) [+ residual]) in float64: all three gradients and the masked gradient handed to the
+    residual branch; launched twice: bitwise reproducible."""
+    import torch.nn.functional as F
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    B, C, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + C * 10 + int(relu) + 2 * int(res))
+    x = torch.randn(B, C, H, W, device="cuda", generator=g) * 1.5 + 0.3
+    wt = torch.rand(C, device="cuda", generator=g) + 0.5
+    bs = torch.rand(C, device="cuda", generator=g) - 0.5
+    r = torch.randn(B, C, H, W, device="cuda", generator=g) if res else None
+    go = torch.randn(B, C, H, W, device="cuda", generator=g)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, wt, bs))
+    rd = r.double().requires_grad_(True) if res else None
+    y = F.batch_norm(xd, None, None, wd, bd, True, 0.1, 1e-5)
+    if res:
+        y = y + rd
+    out64 = torch.relu(y) if relu else y
+    refs = torch.autograd.grad(out64, [xd, wd, bd] + ([rd] if res else []), go.double())
+    mean = x.double().mean((0, 2, 3)).float()       # (kept alive: N.ptr() of a temporary would dangle)
+    invstd = (x.double().var((0, 2, 3), unbiased=False) + 1e-5).rsqrt().float()
+    out = out64.detach().float().contiguous() if relu else None
+    HW = H * W
+
+    def run():
+        ws = torch.empty(lib.dmh_bn_train_bwd_workspace_size(B, C, HW), device="cuda")
+        gx, gp = torch.full_like(x, float("nan")), (torch.full_like(x, float("nan")) if res else None)
+        gw, gb = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        N.check(lib.dmh_bn_train_bwd(N.ptr(x), N.ptr(go), N.ptr(out), N.ptr(wt), N.ptr(mean), N.ptr(invstd), B, C,
+                                     HW, N.ptr(ws), N.ptr(gx), N.ptr(gw), N.ptr(gb), N.ptr(gp), N.stream()))
+        return gx, gw, gb, gp
+    got = run()
+    again = run()
+    for a, b in zip(got, again):
+        assert (a is None and b is None) or torch.equal(a, b)
+    names = ["g_x", "g_weight", "g_bias", "g_pre"]
+    for a, b, nm in zip(got, list(refs[:3]) + [refs[3] if res else None], names):
+        if b is None:
+            continue
+        torch.testing.assert_close(a.double(), b, rtol=2e-4, atol=2e-5 * float(b.abs().max()), msg=lambda m: nm + ": " + m)
+
+
 def test_conv3x3_op_autograd_matches_aten():
     """ops.conv3x3 (Winograd-MFMA forward + backward-data, MIOpen weight gradient) == F.conv2d under autograd, on a
     shape the dispatcher sends to K10 and on one it leaves to MIOpen; frozen_weights() caches the transformed filter."""
