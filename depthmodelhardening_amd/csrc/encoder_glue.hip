@@ -250,6 +250,20 @@ __global__ __launch_bounds__(NT) void bn_stats_partial_kernel(const float* __res
     float nq[4] = {0.f, 0.f, 0.f, 0.f}, s1q[4] = {0.f, 0.f, 0.f, 0.f}, s2q[4] = {0.f, 0.f, 0.f, 0.f};   // 4 independent chains
     for (int b = 0; b < B; ++b) {
         const float* xp = x + ((size_t)b * C + c) * HW;
+        if ((HW & 3) == 0) {    // whole 16-byte words: one float4 per thread and slab (uniform branch)
+            for (int r = s * 4 * NT + 4 * (int)threadIdx.x; r < HW; r += S * 4 * NT) {
+                const float4 v4 = *reinterpret_cast<const float4*>(xp + r);
+                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = v[q] - k;
+                    nq[q] += 1.f;
+                    s1q[q] += d;
+                    s2q[q] = fmaf(d, d, s2q[q]);
+                }
+            }
+            continue;
+        }
         for (int r0 = s * 4 * NT; r0 < HW; r0 += S * 4 * NT) {
             float v[4];
 #pragma unroll
