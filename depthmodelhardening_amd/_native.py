@@ -82,6 +82,8 @@ _SIGNATURES = {
     "dmh_bn_act_bwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp, _fp, _fp]),
     "dmh_bn_stats_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dmh_bn_train_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float] + [_fp] * 8),
+    "dmh_channel_sum_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dmh_channel_sum": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_void_p]),
     "dmh_bn_train_bwd_workspace_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dmh_bn_train_bwd": (C.c_int, [_fp] * 6 + [C.c_int, C.c_int, C.c_int] + [_fp] * 5 + [C.c_void_p]),
     "dmh_stem_bn_relu_pool_fwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp] * 4),
@@ -108,6 +110,7 @@ _SIGNATURES = {
     "dmh_down_conv_fwd": (C.c_int, [_fp] * 3 + [C.c_int] * 5 + [_fp] * 3),
     "dmh_down_conv_fwd_act": (C.c_int, [_fp] * 5 + [C.c_int] * 6 + [_fp] * 3),
     "dmh_down_conv_bwd_data": (C.c_int, [_fp] * 4 + [C.c_int] * 5 + [_fp, _fp]),
+    "dmh_down_conv_bwd_data_acc": (C.c_int, [_fp] * 5 + [C.c_int] * 5 + [_fp, _fp]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

@@ -208,6 +208,7 @@ constexpr int G_NP = CK * TR * TC / NT;                                       //
 
 struct BArgs {
     const float *g3, *gd, *w3t, *wdt;
+    const float* gadd;           // optional: a gradient of the same tensor from another consumer, added in the epilogue
     float* gx;
     int B, Cin, Cout, H, W, Ho, Wo, tx, ty, gc;
 };
@@ -348,8 +349,14 @@ __global__ __launch_bounds__(NT, 2) void down_conv_bwd_kernel(const BArgs a) {
             for (int v = 0; v < 16; ++v) {
                 const int i = 8 * (v >> 2) + 4 * h + (v & 3) + 32 * half;
                 float* g = a.gx + o + (size_t)i * HW;
-                *reinterpret_cast<float2*>(g) = make_float2(acc[0][half][v], acc[1][half][v]);
-                *reinterpret_cast<float2*>(g + a.W) = make_float2(acc[2][half][v], acc[3][half][v]);
+                float2 r0 = make_float2(acc[0][half][v], acc[1][half][v]), r1 = make_float2(acc[2][half][v], acc[3][half][v]);
+                if (a.gadd) {
+                    const float* q = a.gadd + o + (size_t)i * HW;
+                    const float2 q0 = *reinterpret_cast<const float2*>(q), q1 = *reinterpret_cast<const float2*>(q + a.W);
+                    r0.x += q0.x; r0.y += q0.y; r1.x += q1.x; r1.y += q1.y;
+                }
+                *reinterpret_cast<float2*>(g) = r0;
+                *reinterpret_cast<float2*>(g + a.W) = r1;
             }
     }
 }
@@ -411,6 +418,11 @@ int dmh_down_conv_fwd_act(const float* x, const float* w3, const float* wd, cons
 
 int dmh_down_conv_bwd_data(const float* g3, const float* gd, const float* w3t, const float* wdt, int B, int Cin, int Cout,
                            int H, int W, float* g_x, void* stream) {
+    return dmh_down_conv_bwd_data_acc(g3, gd, w3t, wdt, nullptr, B, Cin, Cout, H, W, g_x, stream);
+}
+
+int dmh_down_conv_bwd_data_acc(const float* g3, const float* gd, const float* w3t, const float* wdt, const float* g_add, int B,
+                               int Cin, int Cout, int H, int W, float* g_x, void* stream) {
     DMH_REQUIRE(g3 && w3t && g_x && ((gd == nullptr) == (wdt == nullptr)), "null pointer");
     if (int rc = check_sizes(B, Cin, Cout, H, W)) return rc;
     DMH_REQUIRE(Cout % CK == 0 && Cin % 64 == 0, "C_out must be a multiple of 8 and C_in of 64");
@@ -421,6 +433,7 @@ int dmh_down_conv_bwd_data(const float* g3, const float* gd, const float* w3t, c
     a.gd = gd;
     a.w3t = w3t;
     a.wdt = wdt;
+    a.gadd = g_add;
     a.gx = g_x;
     a.B = B;
     a.Cin = Cin;

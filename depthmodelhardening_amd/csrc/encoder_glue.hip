@@ -231,6 +231,12 @@ __global__ __launch_bounds__(NT) void stem_bwd4_kernel(const float* __restrict__
 //   finalize: one thread per channel combines the S partials, writes the affine of the normalisation
 //             scale = weight * invstd, shift = bias - mean * scale, the saved mean / invstd for the backward, and
 //             updates the running statistics in place (unbiased variance, torch.nn.BatchNorm2d semantics).
+// slabs (4 * NT elements) of one HW-element plane that fall to block s of S: s, s + S, s + 2 S, ...
+__device__ __forceinline__ int slabs_of(int HW, int s, int S) {
+    const int nslab = (HW + 4 * NT - 1) / (4 * NT);
+    return s < nslab ? (nslab - 1 - s) / S + 1 : 0;
+}
+
 struct Wf {
     float n, mean, m2;
 };
@@ -250,20 +256,7 @@ __global__ __launch_bounds__(NT) void bn_stats_partial_kernel(const float* __res
     float nq[4] = {0.f, 0.f, 0.f, 0.f}, s1q[4] = {0.f, 0.f, 0.f, 0.f}, s2q[4] = {0.f, 0.f, 0.f, 0.f};   // 4 independent chains
     for (int b = 0; b < B; ++b) {
         const float* xp = x + ((size_t)b * C + c) * HW;
-        if ((HW & 3) == 0) {    // whole 16-byte words: one float4 per thread and slab (uniform branch)
-            for (int r = s * 4 * NT + 4 * (int)threadIdx.x; r < HW; r += S * 4 * NT) {
-                const float4 v4 = *reinterpret_cast<const float4*>(xp + r);
-                const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float d = v[q] - k;
-                    nq[q] += 1.f;
-                    s1q[q] += d;
-                    s2q[q] = fmaf(d, d, s2q[q]);
-                }
-            }
-            continue;
-        }
+        if ((HW & 3) == 0) continue;    // whole 16-byte words: the flattened loop below
         for (int r0 = s * 4 * NT; r0 < HW; r0 += S * 4 * NT) {
             float v[4];
 #pragma unroll
@@ -277,6 +270,32 @@ __global__ __launch_bounds__(NT) void bn_stats_partial_kernel(const float* __res
                 const float d = v[q] - k;           // padding lanes contribute d = 0
                 s1q[q] += d;
                 s2q[q] = fmaf(d, d, s2q[q]);
+            }
+        }
+    }
+    if ((HW & 3) == 0) {
+        // one float4 per thread and slab; the (image, slab) pairs of the block as ONE loop, four loads in flight per thread
+        // (an image holds only one or two slabs per block: image after image, every load waited for the one before)
+        const int nk = slabs_of(HW, s, S), total = B * nk;
+        for (int i0 = 0; i0 < total; i0 += 4) {
+            float4 v4[4];
+            bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u, total - 1), b = i / nk, r = (s + (i - b * nk) * S) * 4 * NT + 4 * (int)threadIdx.x;
+                ok[u] = i0 + u < total && r < HW;
+                v4[u] = ok[u] ? *reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * HW + r) : make_float4(k, k, k, k);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float d = v[q] - k;           // skipped loads contribute d = 0
+                    nq[q] += ok[u] ? 1.f : 0.f;
+                    s1q[q] += d;
+                    s2q[q] = fmaf(d, d, s2q[q]);
+                }
             }
         }
     }
@@ -343,18 +362,8 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(const float* __restr
     float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2[4] = {0.f, 0.f, 0.f, 0.f};     // 4 independent chains
     for (int b = 0; b < B; ++b) {
         const size_t base = ((size_t)b * C + c) * HW;
-        if (VEC) {      // HW % 4 == 0: slabs of 4 * NT elements as one float4 per thread
-            for (int r = s * 4 * NT + 4 * (int)threadIdx.x; r < HW; r += S * 4 * NT) {
-                const float4 xv = *reinterpret_cast<const float4*>(x + base + r);
-                float4 gv = *reinterpret_cast<const float4*>(g + base + r);
-                if (RELU) {
-                    const float4 o = *reinterpret_cast<const float4*>(out + base + r);
-                    gv = make_float4(o.x > 0.f ? gv.x : 0.f, o.y > 0.f ? gv.y : 0.f, o.z > 0.f ? gv.z : 0.f, o.w > 0.f ? gv.w : 0.f);
-                }
-                a1[0] += gv.x; a1[1] += gv.y; a1[2] += gv.z; a1[3] += gv.w;
-                a2[0] = fmaf(gv.x, xv.x - m, a2[0]); a2[1] = fmaf(gv.y, xv.y - m, a2[1]);
-                a2[2] = fmaf(gv.z, xv.z - m, a2[2]); a2[3] = fmaf(gv.w, xv.w - m, a2[3]);
-            }
+        if (VEC) {      // HW % 4 == 0: the flattened loop below
+            break;
         } else {
             for (int r0 = s * 4 * NT; r0 < HW; r0 += S * 4 * NT) {
 #pragma unroll
@@ -367,6 +376,32 @@ __global__ __launch_bounds__(NT) void bn_bwd_partial_kernel(const float* __restr
                         a2[q] = fmaf(gv, x[base + r] - m, a2[q]);
                     }
                 }
+            }
+        }
+    }
+    if (VEC) {
+        // one float4 per tensor, thread and slab; (image, slab) pairs as one loop, two pairs (4-6 loads) in flight per thread
+        const int nk = slabs_of(HW, s, S), total = B * nk;
+        for (int i0 = 0; i0 < total; i0 += 2) {
+            float4 xv[2], gv[2], ov[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int i = min(i0 + u, total - 1), b = i / nk, r = (s + (i - b * nk) * S) * 4 * NT + 4 * (int)threadIdx.x;
+                const bool ok = i0 + u < total && r < HW;
+                const size_t o = ((size_t)b * C + c) * HW + r;
+                xv[u] = ok ? *reinterpret_cast<const float4*>(x + o) : make_float4(m, m, m, m);
+                gv[u] = ok ? *reinterpret_cast<const float4*>(g + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (RELU) ov[u] = ok ? *reinterpret_cast<const float4*>(out + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                float4 gq = gv[u];
+                if (RELU)
+                    gq = make_float4(ov[u].x > 0.f ? gq.x : 0.f, ov[u].y > 0.f ? gq.y : 0.f, ov[u].z > 0.f ? gq.z : 0.f,
+                                     ov[u].w > 0.f ? gq.w : 0.f);
+                a1[0] += gq.x; a1[1] += gq.y; a1[2] += gq.z; a1[3] += gq.w;
+                a2[0] = fmaf(gq.x, xv[u].x - m, a2[0]); a2[1] = fmaf(gq.y, xv[u].y - m, a2[1]);
+                a2[2] = fmaf(gq.z, xv[u].z - m, a2[2]); a2[3] = fmaf(gq.w, xv[u].w - m, a2[3]);
             }
         }
     }
@@ -465,6 +500,54 @@ void launch_bn_bwd_apply(const float* x, const float* g, const float* out, const
                            reinterpret_cast<const float4*>(coef), (unsigned)C, (unsigned)HW, (unsigned)total, g_x, g_res);
 }
 
+// ---- per-channel sum of a [B, C, HW] tensor: the bias gradient of a convolution (aten::sum over (0, 2, 3) takes 86 us on
+// the decoder's maps; this is one read at streaming rate).  Partial sums per (slab, channel), fixed-order finish in double.
+__global__ __launch_bounds__(NT) void channel_sum_partial_kernel(const float* __restrict__ g, int B, int C, int HW, int S,
+                                                                 float* __restrict__ part) {
+    const int c = blockIdx.y, s = blockIdx.x;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((HW & 3) == 0) {    // (image, slab) pairs as one loop, four 16-byte loads in flight per thread
+        const int nk = slabs_of(HW, s, S), total = B * nk;
+        for (int i0 = 0; i0 < total; i0 += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = min(i0 + u, total - 1), b = i / nk, r = (s + (i - b * nk) * S) * 4 * NT + 4 * (int)threadIdx.x;
+                v[u] = (i0 + u < total && r < HW) ? *reinterpret_cast<const float4*>(g + ((size_t)b * C + c) * HW + r)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[0] += v[u].x; a[1] += v[u].y; a[2] += v[u].z; a[3] += v[u].w; }
+        }
+    } else {
+        for (int b = 0; b < B; ++b) {
+            const float* gp = g + ((size_t)b * C + c) * HW;
+            for (int r = s * NT + (int)threadIdx.x; r < HW; r += S * NT) a[0] += gp[r];
+        }
+    }
+    float t = (a[0] + a[1]) + (a[2] + a[3]);
+#pragma unroll
+    for (int o = WAVE / 2; o > 0; o >>= 1) t += __shfl_down(t, o, WAVE);
+    __shared__ float red[NT / WAVE];
+    if ((threadIdx.x & (WAVE - 1)) == 0) red[threadIdx.x / WAVE] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float u = red[0];
+#pragma unroll
+        for (int i = 1; i < NT / WAVE; ++i) u += red[i];
+        part[(size_t)c * S + s] = u;
+    }
+}
+
+__global__ __launch_bounds__(NT) void channel_sum_finalize_kernel(const float* __restrict__ part, int C, int S,
+                                                                  float* __restrict__ out) {
+    const int c = blockIdx.x * NT + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (int s = 0; s < S; ++s) t += (double)part[(size_t)c * S + s];
+    out[c] = (float)t;
+}
+
 template <bool RELU, bool RES>
 void launch_fwd(const float* x, const float* scale, const float* shift, const float* res, int C, int HW, int64_t total,
                 float* out, hipStream_t st) {
@@ -547,6 +630,22 @@ int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(blocks_for(C)), dim3(NT), 0, st, partials, C, (int)S, weight, bias,
                        momentum, eps, running_mean, running_var, scale, shift, save_mean, save_invstd);
     return check_launch("dmh_bn_train_stats");
+}
+
+int64_t dmh_channel_sum_partials_size(int B, int C, int HW) {
+    const int64_t S = dmh_bn_stats_partials_size(B, C, HW);
+    return S < 0 ? -1 : S / 3;
+}
+
+int dmh_channel_sum(const float* g, int B, int C, int HW, float* partials, float* out, void* stream) {
+    DMH_REQUIRE(g && partials && out, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && HW > 0 && C <= 65535, "bad sizes");
+    int64_t S = ((int64_t)HW + 4 * NT - 1) / (4 * NT);
+    if (S > 64) S = 64;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3((unsigned)S, C), dim3(NT), 0, st, g, B, C, HW, (int)S, partials);
+    hipLaunchKernelGGL(channel_sum_finalize_kernel, dim3(blocks_for(C)), dim3(NT), 0, st, partials, C, (int)S, out);
+    return check_launch("dmh_channel_sum");
 }
 
 int64_t dmh_bn_train_bwd_workspace_size(int B, int C, int HW) {

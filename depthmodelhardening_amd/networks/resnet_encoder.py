@@ -90,7 +90,16 @@ class BasicBlock(nn.Module):
         out = self.bn2(_conv(self.conv2, out))
         return self.relu(out + idt)
 
-    def forward_fused(self, x, aff):
+    def forward_fused(self, x, aff, want_skip=False):
+        """``want_skip``: x is also a pyramid feature (the previous layer's output).  Returns (y, x') then, where x' is the
+        tensor the decoder should take in place of x: an alias whose gradient enters the down-sampling node (added in
+        K15's epilogue instead of by autograd's accumulation pass), or x itself on the other paths."""
+        if want_skip:
+            if (self._is_down_pair() and _plain3x3(self.conv2) and x.requires_grad
+                    and ops.down_block_eval_ok(x, self.conv1.weight, self.downsample[0].weight, self.conv2.weight)):
+                return ops.down_block_eval(x, self.conv1.weight, *aff[self.bn1], self.downsample[0].weight,
+                                           *aff[self.downsample[1]], self.conv2.weight, *aff[self.bn2], return_skip=True)
+            return self.forward_fused(x, aff), x
         if (self.downsample is None and all(_plain3x3(c) for c in (self.conv1, self.conv2))
                 and ops.basic_block_eval_ok(x, self.conv1.weight, self.conv2.weight)):
             # inside an attack: the whole block as one autograd node (masks and the identity add in K10's epilogues)
@@ -271,8 +280,12 @@ class ResnetEncoder(nn.Module):
             f0 = ops.bn_act(z, *aff[e.bn1])
             y = e.maxpool(f0)
         feats = [f0]
-        for layer in (e.layer1, e.layer2, e.layer3, e.layer4):
-            for blk in layer:
-                y = blk.forward_fused(y, aff)
+        for li, layer in enumerate((e.layer1, e.layer2, e.layer3, e.layer4)):
+            for bi, blk in enumerate(layer):
+                if li > 0 and bi == 0 and hasattr(blk, "_is_down_pair"):
+                    # y is the previous layer's output = a pyramid feature with two consumers (this block and the decoder)
+                    y, feats[-1] = blk.forward_fused(y, aff, want_skip=True)
+                else:
+                    y = blk.forward_fused(y, aff)
             feats.append(y)
         return feats

@@ -630,6 +630,18 @@ def _bn_backward(g_pre, x, weight, bn, mean, invstd, eps, mask):
                                                      eps, mask)
 
 
+def channel_sum(g):
+    """sum of a contiguous fp32 CUDA [B, C, H, W] tensor over (0, 2, 3): a convolution's bias gradient, one streaming read."""
+    lib = N.lib()
+    B, Cc = g.shape[0], g.shape[1]
+    HW = g.numel() // (B * Cc)
+    part = torch.empty(lib.dmh_channel_sum_partials_size(B, Cc, HW), device=g.device, dtype=torch.float32)
+    out = torch.empty(Cc, device=g.device, dtype=torch.float32)
+    N.check(_timed("channel_sum", lambda: lib.dmh_channel_sum(N.ptr(g), B, Cc, HW, N.ptr(part), N.ptr(out), N.stream()),
+                   4 * g.numel()))
+    return out
+
+
 BN_BWD_ENABLED = os.environ.get("DMH_BN_BWD", "1") != "0"      # A/B switch: 0 = K9 mask pass + MIOpen's backward
 
 
@@ -1051,7 +1063,7 @@ class _Conv3x3(torch.autograd.Function):
             N.check(_timed("wino_wrw", lambda: lib.dmh_wino_wrw(N.ptr(x), N.ptr(g), B, Cc, K, H, W, pad, N.ptr(ws), N.ptr(g_w),
                                                                 N.stream()), 4 * (x.numel() + g.numel()), 18 * Cc * g.numel()))
             if need_b:
-                g_b = g.sum((0, 2, 3))
+                g_b = channel_sum(g)
             need_w = need_b = False
         if need_x or need_w or need_b:
             r = torch.ops.aten.convolution_backward(g, x, weight, [K] if ctx.has_bias else None, [1, 1], [pad, pad], [1, 1],
@@ -1377,7 +1389,7 @@ class _DownBlockEval(torch.autograd.Function):
     epilogue) and one K15 launch on the transposed, scaled filters -- no separate BatchNorm / ReLU passes."""
 
     @staticmethod
-    def forward(ctx, x, w3, s1, b1, wd, sd, bd, w2, s2, b2):
+    def forward(ctx, x, w3, s1, b1, wd, sd, bd, w2, s2, b2, want_skip):
         lib = N.lib()
         B, Cin, H, W = x.shape
         Co = w3.shape[0]
@@ -1393,15 +1405,22 @@ class _DownBlockEval(torch.autograd.Function):
             N.stream()), 4 * 3 * out1.numel(), 18 * Co * out1.numel()))
         ctx.save_for_backward(out1, y, w3, s1, wd, sd, w2, s2)
         ctx.in_shape = (B, Cin, H, W)
-        return y
+        ctx.set_materialize_grads(False)
+        # want_skip: x is handed back as a second output (an alias).  A caller that feeds THAT tensor to x's other consumer
+        # (the decoder's skip connection) makes its gradient an input of this node's backward, where K15's epilogue adds it:
+        # autograd's separate accumulation pass over the feature map disappears.
+        return (y, x) if want_skip else (y, None)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_skip=None):
         out1, y, w3, s1, wd, sd, w2, s2 = ctx.saved_tensors
         lib = N.lib()
         B, Cin, H, W = ctx.in_shape
         Co = w3.shape[0]
+        if g is None:           # only the alias was used
+            return (g_skip,) + (None,) * 10
         g = _c(g)
+        g_skip = None if g_skip is None else _c(g_skip)
         ones = frozen_memo(("ones", Co, g.device), lambda: torch.ones(Co, device=g.device, dtype=torch.float32))
         g2 = torch.empty_like(g)            # g * [y > 0]: gradient of bn2's output and of the shortcut's BatchNorm output
         N.check(_timed("bn_act_bwd", lambda: lib.dmh_bn_act_bwd(N.ptr(y), N.ptr(g), N.ptr(ones), B, Co, (H // 2) * (W // 2), 1,
@@ -1415,10 +1434,10 @@ class _DownBlockEval(torch.autograd.Function):
         wdts = frozen_memo(("down_wdts", wd.data_ptr(), wd._version, sd.data_ptr()),
                            lambda: _c((wd * sd.view(-1, 1, 1, 1)).reshape(Co, Cin).t()))
         g_x = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32)
-        N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data(
-            N.ptr(g1), N.ptr(g2), N.ptr(w3ts), N.ptr(wdts), B, Cin, Co, H, W, N.ptr(g_x), N.stream()),
-            4 * (g_x.numel() + 2 * g.numel()), 20 * Cin * g.numel()))
-        return (g_x,) + (None,) * 9
+        N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data_acc(
+            N.ptr(g1), N.ptr(g2), N.ptr(w3ts), N.ptr(wdts), N.ptr(g_skip), B, Cin, Co, H, W, N.ptr(g_x), N.stream()),
+            4 * (g_x.numel() * (1 if g_skip is None else 2) + 2 * g.numel()), 20 * Cin * g.numel()))
+        return (g_x,) + (None,) * 10
 
 
 DOWN_NODE_ENABLED = os.environ.get("DMH_DOWN_NODE", "1") != "0"     # timing comparisons
@@ -1432,20 +1451,24 @@ def down_block_eval_ok(x, w3, wd, w2):
     return tuple(w2.shape) == (Co, Co, 3, 3) and _wino_ok(x.shape[0], Co, Co, x.shape[2] // 2, x.shape[3] // 2, allow_split=False)
 
 
-def down_block_eval(x, w3, scale1, shift1, wd, scale_d, shift_d, w2, scale2, shift2):
+def down_block_eval(x, w3, scale1, shift1, wd, scale_d, shift_d, w2, scale2, shift2, return_skip=False):
     """relu(bn2(conv2(relu(bn1(conv1_s2(x))))) + bn_d(conv1x1_s2(x))) with the BatchNorms given as (scale, shift): a
-    down-sampling BasicBlock of the encoder during an attack, as one autograd node (see _DownBlockEval)."""
+    down-sampling BasicBlock of the encoder during an attack, as one autograd node (see _DownBlockEval).
+    ``return_skip``: returns (y, x') with x' an alias of x to be used by x's OTHER consumer (the decoder's skip connection,
+    MD2/networks/depth_decoder.py:53-57): its gradient then enters this node and is added in K15's epilogue."""
     if not down_block_eval_ok(x, w3, wd, w2):
         raise RuntimeError("down_block_eval: needs ops.frozen_weights() and shapes K15 / K10 take (ops.down_block_eval_ok)")
     for sc, sh in ((scale1, shift1), (scale_d, shift_d), (scale2, shift2)):
         _reject_affine_grad("down_block_eval", sc, sh)
     d = lambda t: _c(t.detach())        # noqa: E731
+    x = _c(x)
+    args = (x, w3.detach(), d(scale1), d(shift1), wd.detach(), d(scale_d), d(shift_d), w2.detach(), d(scale2), d(shift2))
     if not x.requires_grad:
         with torch.no_grad():
-            return _DownBlockEval.apply(_c(x), w3.detach(), d(scale1), d(shift1), wd.detach(), d(scale_d), d(shift_d),
-                                        w2.detach(), d(scale2), d(shift2))
-    return _DownBlockEval.apply(_c(x), w3.detach(), d(scale1), d(shift1), wd.detach(), d(scale_d), d(shift_d), w2.detach(),
-                                d(scale2), d(shift2))
+            y, _ = _DownBlockEval.apply(*args, False)
+        return (y, x) if return_skip else y
+    y, skip = _DownBlockEval.apply(*args, bool(return_skip))
+    return (y, skip) if return_skip else y
 
 
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,

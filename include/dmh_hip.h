@@ -272,6 +272,10 @@ int64_t dmh_bn_stats_partials_size(int B, int C, int HW);
 int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
                        float eps, float* running_mean, float* running_var, float* partials, float* scale, float* shift,
                        float* save_mean, float* save_invstd, void* stream);
+/* out[c] = sum over (b, hw) of g[b][c][hw]: the bias gradient of a convolution (aten::convolution_backward's third
+ * output, aten::sum(g, (0, 2, 3))).  Two launches, fixed order.  partials: dmh_channel_sum_partials_size(B, C, HW) floats. */
+int64_t dmh_channel_sum_partials_size(int B, int C, int HW);
+int dmh_channel_sum(const float* g, int B, int C, int HW, float* partials, float* out, void* stream);
 /* train-mode BatchNorm backward with the ReLU mask folded in (replaces one dmh_bn_act_bwd pass +
  * aten::miopen_batch_norm_backward in the train pass; torch.nn.BatchNorm2d semantics, torch/nn/functional.py batch_norm
  * as called by torchvision's BasicBlock, MD2/networks/resnet_encoder.py:85-98):
@@ -412,6 +416,10 @@ int dmh_down_conv_fwd_act(const float* x, const float* w3, const float* wd, cons
                           int relu3, int B, int Cin, int Cout, int H, int W, float* y3, float* yd, void* stream);
 int dmh_down_conv_bwd_data(const float* g3, const float* gd, const float* w3t, const float* wdt, int B, int Cin, int Cout,
                            int H, int W, float* g_x, void* stream);
+/* the same with g_add[B, Cin, H, W] (may be NULL) added in the epilogue: the gradient the same tensor receives from its other
+ * consumer (the decoder's skip connection), instead of autograd's separate accumulation pass. */
+int dmh_down_conv_bwd_data_acc(const float* g3, const float* gd, const float* w3t, const float* wdt, const float* g_add, int B,
+                               int Cin, int Cout, int H, int W, float* g_x, void* stream);
 
 #ifdef __cplusplus
 }

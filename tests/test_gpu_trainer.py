@@ -435,6 +435,17 @@ def test_conv3x3_op_weight_gradient_takes_k18():
     torch.testing.assert_close(gw, gwr, rtol=1e-4, atol=1e-5 * float(gwr.abs().max()))
 
 
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9), (2, 64, 20, 64), (4, 16, 162, 514)])
+def test_channel_sum_kernel(shape):
+    """ops.channel_sum (the bias gradient beside K18) == the float64 sum over (0, 2, 3); bitwise reproducible."""
+    from depthmodelhardening_amd import ops
+    g = torch.randn(*shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(sum(shape)))
+    got = ops.channel_sum(g)
+    assert torch.equal(got, ops.channel_sum(g))
+    ref = g.double().sum((0, 2, 3))
+    torch.testing.assert_close(got.double(), ref, rtol=1e-5, atol=1e-5 * float(g.double().abs().sum((0, 2, 3)).max()))
+
+
 def test_network_kernels_vs_formulation_oracle():
     """K10 / K11 / K12 through the C ABI == oracle/conv_ref.py (fp64 numpy restatement of the same formulations:
     Winograd tiles, backward filter, parity gather), on seeded inputs small enough for the oracle's Python loops."""
@@ -1088,6 +1099,14 @@ def test_down_block_eval_node_vs_module_path():
             ggot = torch.autograd.grad(got, x, gy)[0]
             with torch.no_grad():
                 got_ng = blk.forward_fused(x, aff)
-        assert torch.equal(got_ng, got)
+            # the input as a pyramid feature with a second consumer (the decoder's skip connection): the alias handed back
+            # carries that consumer's gradient into the node, K15's epilogue adds it
+            y2, xs = blk.forward_fused(x, aff, want_skip=True)
+            assert xs.data_ptr() == x.data_ptr() and type(xs.grad_fn).__name__.startswith("_DownBlockEval")
+            gs = torch.randn_like(x)
+            gboth = torch.autograd.grad([y2, xs], x, [gy, gs])[0]
+            gonly = torch.autograd.grad(blk.forward_fused(x, aff, want_skip=True)[1], x, gs)[0]
+        assert torch.equal(got_ng, got) and torch.equal(y2, got) and torch.equal(gonly, gs)
+        torch.testing.assert_close(gboth, ggot + gs, rtol=0, atol=2e-6 * float(gs.abs().max()))
         assert_close_frac(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()), name="down block out")
         assert_close_frac(ggot, gref, rtol=1e-3, atol=1e-4 * float(gref.abs().max()), max_bad_frac=2e-4, name="down block grad")
