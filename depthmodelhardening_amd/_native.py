@@ -52,6 +52,8 @@ _SIGNATURES = {
     "dmh_photo_stage_size": (C.c_int64, [C.POINTER(PhotoArgs)]),
     "dmh_photo_loss_fwd": (C.c_int, [C.POINTER(PhotoArgs), _fp, _PtrArr, _fp, _fp]),
     "dmh_photo_loss_bwd": (C.c_int, [C.POINTER(PhotoArgs), _fp, _fp, _fp, _fp, _PtrArr, _fp]),
+    "dmh_photo_pose_partials_size": (C.c_int64, [C.POINTER(PhotoArgs)]),
+    "dmh_photo_loss_bwd_pose": (C.c_int, [C.POINTER(PhotoArgs), _fp, _fp, _fp, _fp, _PtrArr, _fp, _fp]),
     "dmh_unpack_selection": (C.c_int, [_fp, C.c_int64, C.c_int, _fp, _fp]),
     "dmh_upsample_bilinear_adjoint": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _fp]),
     "dmh_warp_view_fwd": (C.c_int, [_fp] * 5 + [C.c_int] * 5 + [C.c_float, C.c_float] + [_fp] * 4),

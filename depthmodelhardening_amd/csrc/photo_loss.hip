@@ -302,6 +302,7 @@ struct KArgs {
     const float* fin;
     float* g_disp[DMH_MAX_SCALES];
     float* stage[DMH_MAX_SCALES];              // per-strip partial low-resolution gradients of the coarse scales
+    float* pose_part;                          // POSE: [NS][strip][NF][12] partial sums of d loss / d (K T)[:3,:]
     int sy_slots[DMH_MAX_SCALES], sx_slots[DMH_MAX_SCALES];
     int tiles_x, tiles_y, ntiles, R;
     float min_disp, dmul;                      // scaled_disp = min_disp + dmul * disp   MD2/layers.py:21-23
@@ -655,10 +656,17 @@ struct BRow {   // record of one processed row: its row sums, the coefficient ro
     float tx, ty, jx, jy;    // bilinear fractions; d ix / d disp, d iy / d disp (0 where the coordinate is clamped)
     float ptv[3];
     unsigned psel;           // selection byte of the row above (the coefficient row)
+    float pqa, pqb, ppx, ppy;   // POSE, requested a row ahead: 1/den gated by "x / y not clamped", the sample coordinate
+    // POSE, kept for two rows: d warped_c / d ix, / d iy; d ix / d disp, d iy / d disp; the four factors above
+    float dvx[3], dvy[3], sjx, sjy, qa, qb, qx, qy;
 };
 
 // SAME: the wave's scale has the image resolution (gradient written directly); otherwise the up-sampling adjoint runs.
-template <int NF, bool SAME>
+// POSE: also d loss / d P_f with P_f = (K T_f)[:3,:] (MD2/layers.py:188-191: cam = P [X;1], pix = cam[:2] / (cam[2] + eps)).
+// With G = d loss / d pix of a pixel, den = a_z + sd m (so cam[2] + eps = depth den), p = (x, y, 1), X = depth inv_K p:
+//     a = G_x / den, b = G_y / den, c = -(a pix_x + b pix_y):   d loss / d P[i][j<3] = sum_k invK[j][k] sum_pix (a,b,c)_i p_k,
+//     d loss / d P[i][3] = sum_pix (a,b,c)_i sd   -> twelve sums per (strip, frame), finished on the host side of the C ABI's caller.
+template <int NF, bool SAME, bool POSE>
 __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, const int tile, float* sA, float* sB) {
     const dmh_photo_args& a = k.a;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -712,6 +720,9 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
         BRow recA, recB, recC;
         float accA = 0.f, accB = 0.f;     // vertical up-sampling adjoint: low rows ja and ja + 1
         int ja = jlo;
+        float pacc[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) pacc[i] = 0.f;
 
         auto flush = [&](const int j, const float v) __attribute__((always_inline)) {
             const int slot = j - jlo;
@@ -750,6 +761,12 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
             rec.jy = t.gy_ok ? fmaf(rp.ny, rp.az, -rp.ey * cam.m) * rd2 : 0.f;   // d iy / d disp
             rec.tx = t.tx;
             rec.ty = t.ty;
+            if constexpr (POSE) {
+                rec.pqa = t.gx_ok ? rden : 0.f;
+                rec.pqb = t.gy_ok ? rden : 0.f;
+                rec.ppx = (float)xr + dx;
+                rec.ppy = (float)yr + dy;
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const unsigned po = plane * (unsigned)c;
@@ -764,6 +781,10 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
             const int r = Y0 - 2 + kk;
             // (1) this row: warped values and chain factors J_c = d warped_c / d disp from the operands requested a row ago
             const float sd_rq = older.sdv;  // of the row two above (read before `older` becomes the next row's record)
+            if constexpr (POSE) {           // this row's request fields -> fields that live for two more rows
+                cur.sjx = cur.jx; cur.sjy = cur.jy;
+                cur.qa = cur.pqa; cur.qb = cur.pqb; cur.qx = cur.ppx; cur.qy = cur.ppy;
+            }
             issue(kk + 1, older);           // only the request fields of `older` are written; its sums are still read below
             const float gx = 1.f - cur.tx, gy = 1.f - cur.ty;
             const float w00 = gx * gy, w01 = cur.tx * gy, w10 = gx * cur.ty, w11 = cur.tx * cur.ty;
@@ -774,6 +795,10 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
                 cur.yv[c] = cur.ptv[c] - SHIFT;
                 const float dvx = (v01 - v00) * gy + (v11 - v10) * cur.ty, dvy = (v10 - v00) * gx + (v11 - v01) * cur.tx;
                 cur.J[c] = dvx * cur.jx + dvy * cur.jy;
+                if constexpr (POSE) {
+                    cur.dvx[c] = dvx;
+                    cur.dvy[c] = dvy;
+                }
                 // (2) row sums
                 cur.hx[c] = hsum3(cur.xv[c]);
                 cur.hxx[c] = hsum3(cur.xv[c] * cur.xv[c]);
@@ -814,7 +839,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
                 const int rq = r - 2;
                 const float myt = (rq == 1) ? 2.f : 1.f, myb = (rq == H - 2) ? 2.f : 1.f;
                 const float l1g = (newer.sel == fsel || (hints && newer.sel == 3u)) ? l1w : 0.f;
-                float g = 0.f;
+                float g = 0.f, Gx = 0.f, Gy = 0.f;
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const float S0 = fmaf(myt, older.ch[c][0], newer.ch[c][0]) + myb * cur.ch[c][0];
@@ -824,6 +849,19 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
                     float gw = fmaf(older.xv[c], Sxc, fmaf(older.yv[c], Syc, S0));
                     gw = fmaf(l1g, df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f), gw);
                     g = fmaf(gw, older.J[c], g);
+                    if constexpr (POSE) {
+                        Gx = fmaf(gw, older.dvx[c], Gx);
+                        Gy = fmaf(gw, older.dvy[c], Gy);
+                    }
+                }
+                if constexpr (POSE) {
+                    if (out_lane) {
+                        const float pa = Gx * older.qa, pb = Gy * older.qb, pc = -(pa * older.qx + pb * older.qy);
+                        const float fx = (float)col, fy = (float)rq;
+                        pacc[0] = fmaf(pa, fx, pacc[0]); pacc[1] = fmaf(pa, fy, pacc[1]); pacc[2] += pa; pacc[3] = fmaf(pa, sd_rq, pacc[3]);
+                        pacc[4] = fmaf(pb, fx, pacc[4]); pacc[5] = fmaf(pb, fy, pacc[5]); pacc[6] += pb; pacc[7] = fmaf(pb, sd_rq, pacc[7]);
+                        pacc[8] = fmaf(pc, fx, pacc[8]); pacc[9] = fmaf(pc, fy, pacc[9]); pacc[10] += pc; pacc[11] = fmaf(pc, sd_rq, pacc[11]);
+                    }
                 }
                 if (hints && newer.sel == 3u && out_lane) {
                     const unsigned ho = (unsigned)(rq * W + col) * 4u;
@@ -893,11 +931,19 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
             flush(ja, accA);
             if (ja + 1 < Hs) flush(ja + 1, accB);
         }
+        if constexpr (POSE) {       // fixed-order wave sums -> one record per (scale, strip, frame)
+            float* pp = k.pose_part + (((size_t)s * k.ntiles + tile) * NF + f) * 12;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                const float t = wave_sum(pacc[i]);
+                if (lane == 0) pp[i] = t;
+            }
+        }
     }
 }
 
-template <int NF>
-__global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArgs k) {
+template <int NF, bool POSE = false>
+__global__ __launch_bounds__(NT, POSE ? 1 : DMH_BWD_WAVES) void photo_bwd_kernel(const KArgs k) {
     __shared__ float s_row[WPB][2][WAVE];     // horizontal up-sampling adjoint: g*(1-lx), g*lx of one row
     const int wv = threadIdx.x >> 6;
     const int item = wave_item();
@@ -905,8 +951,8 @@ __global__ __launch_bounds__(NT, DMH_BWD_WAVES) void photo_bwd_kernel(const KArg
     // scale fastest: the waves of one workgroup take the scales of ONE strip and share its target / source / selection
     // lines in L1 and L2 (the opposite order re-fetched them per scale: 1.8x the algorithmic traffic, profiles/README.md)
     const int tile = item / k.a.num_scales, s = item - tile * k.a.num_scales;
-    if (k.a.Hs[s] == k.a.H) photo_bwd_strip<NF, true>(k, s, tile, s_row[wv][0], s_row[wv][1]);
-    else photo_bwd_strip<NF, false>(k, s, tile, s_row[wv][0], s_row[wv][1]);
+    if (k.a.Hs[s] == k.a.H) photo_bwd_strip<NF, true, POSE>(k, s, tile, s_row[wv][0], s_row[wv][1]);
+    else photo_bwd_strip<NF, false, POSE>(k, s, tile, s_row[wv][0], s_row[wv][1]);
 }
 
 // Coarse scales: add the (<= 4) overlapping strip blocks of every low-resolution texel in a fixed order.
@@ -1067,8 +1113,20 @@ int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_op
     return check_launch("dmh_photo_loss_fwd");
 }
 
+int64_t dmh_photo_pose_partials_size(const dmh_photo_args* a) {
+    if (!a || check_photo(a) != DMH_OK) return 0;
+    KArgs k;
+    fill_kargs(k, a, BW_OUT);
+    return (int64_t)a->num_scales * k.ntiles * a->num_frames * 12;
+}
+
 int dmh_photo_loss_bwd(const dmh_photo_args* a, const uint8_t* sel, const float* gvec, const float* fin, float* stage,
                        float* const g_disp[DMH_MAX_SCALES], void* stream) {
+    return dmh_photo_loss_bwd_pose(a, sel, gvec, fin, stage, g_disp, nullptr, stream);
+}
+
+int dmh_photo_loss_bwd_pose(const dmh_photo_args* a, const uint8_t* sel, const float* gvec, const float* fin, float* stage,
+                            float* const g_disp[DMH_MAX_SCALES], float* pose_partials, void* stream) {
     if (int rc = check_photo(a)) return rc;
     DMH_REQUIRE(sel && gvec && fin && stage && g_disp, "null argument");
     DMH_REQUIRE(a->num_frames <= 3, "at most 3 source frames");
@@ -1102,10 +1160,19 @@ int dmh_photo_loss_bwd(const dmh_photo_args* a, const uint8_t* sel, const float*
     }
     const int items = k.ntiles * a->num_scales;
     const dim3 grid((items + WPB - 1) / WPB), block(NT);
-    switch (a->num_frames) {
-        case 1: hipLaunchKernelGGL(photo_bwd_kernel<1>, grid, block, 0, (hipStream_t)stream, k); break;
-        case 2: hipLaunchKernelGGL(photo_bwd_kernel<2>, grid, block, 0, (hipStream_t)stream, k); break;
-        default: hipLaunchKernelGGL(photo_bwd_kernel<3>, grid, block, 0, (hipStream_t)stream, k); break;
+    k.pose_part = pose_partials;
+    if (pose_partials) {
+        switch (a->num_frames) {
+            case 1: hipLaunchKernelGGL((photo_bwd_kernel<1, true>), grid, block, 0, (hipStream_t)stream, k); break;
+            case 2: hipLaunchKernelGGL((photo_bwd_kernel<2, true>), grid, block, 0, (hipStream_t)stream, k); break;
+            default: hipLaunchKernelGGL((photo_bwd_kernel<3, true>), grid, block, 0, (hipStream_t)stream, k); break;
+        }
+    } else {
+        switch (a->num_frames) {
+            case 1: hipLaunchKernelGGL((photo_bwd_kernel<1>), grid, block, 0, (hipStream_t)stream, k); break;
+            case 2: hipLaunchKernelGGL((photo_bwd_kernel<2>), grid, block, 0, (hipStream_t)stream, k); break;
+            default: hipLaunchKernelGGL((photo_bwd_kernel<3>), grid, block, 0, (hipStream_t)stream, k); break;
+        }
     }
     if (int rc = check_launch("dmh_photo_loss_bwd")) return rc;
     if (coarse) {

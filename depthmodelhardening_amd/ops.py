@@ -140,9 +140,6 @@ class _PhotoSmoothLoss(torch.autograd.Function):
             pos += NS
         disps = rest[pos:pos + NS]
         hint = tuple(rest[pos + NS:pos + NS + 2]) if cfg["hints"] else None
-        if any(t.requires_grad for t in Ts):
-            raise NotImplementedError("gradient w.r.t. camera poses (cam_T_cam) is not implemented in the fused "
-                                      "photometric kernel yet; stereo training (frame_ids [0,'s']) does not need it")
         lib = N.lib()
         B, _, H, W = target.shape
         dev = target.device
@@ -187,11 +184,29 @@ class _PhotoSmoothLoss(torch.autograd.Function):
         g_disp = [torch.empty_like(d) for d in disps]
         stage = torch.empty(lib.dmh_photo_stage_size(C.byref(a)), device=dev, dtype=torch.float32)
         gp = N.ptr_array(g_disp)
-        N.check(_timed("photo_bwd", lambda: lib.dmh_photo_loss_bwd(C.byref(a), N.ptr(sel), N.ptr(gvec), N.ptr(fin),
-                                                                  N.ptr(stage), gp, st)))
+        want_pose = [bool(ctx.needs_input_grad[4 + F + f]) for f in range(F)]      # cam_T_cam of source frame f
+        g_T = [None] * F
+        if any(want_pose):
+            # monocular frames: K1's backward also leaves twelve sums per (scale, strip, frame), from which
+            # d loss / d P_f (P_f = (K T_f)[:3,:]) and d loss / d T_f = K[:3,:]^T dP_f follow (include/dmh_hip.h)
+            B = target.shape[0]
+            part = torch.empty(lib.dmh_photo_pose_partials_size(C.byref(a)), device=dev, dtype=torch.float32)
+            N.check(_timed("photo_bwd", lambda: lib.dmh_photo_loss_bwd_pose(C.byref(a), N.ptr(sel), N.ptr(gvec), N.ptr(fin),
+                                                                           N.ptr(stage), gp, N.ptr(part), st)))
+            sums = part.view(NS, B, -1, F, 3, 4).double().sum((0, 2))               # [B, F, 3, (S_i0, S_i1, S_i2, s_i)]
+            Kd, iKd = K.double(), inv_K.double()
+            for f in range(F):
+                if not want_pose[f]:
+                    continue
+                dP = torch.cat([torch.matmul(sums[:, f, :, :3], iKd[:, :3, :3].transpose(1, 2)), sums[:, f, :, 3:4]], 2)
+                g_T[f] = torch.matmul(Kd[:, :3, :].transpose(1, 2), dP).to(Ts[f].dtype)     # [B, 4, 4]
+        else:
+            N.check(_timed("photo_bwd", lambda: lib.dmh_photo_loss_bwd(C.byref(a), N.ptr(sel), N.ptr(gvec), N.ptr(fin),
+                                                                      N.ptr(stage), gp, st)))
         N.check(lib.dmh_smooth_loss_bwd(C.byref(sm), N.ptr(gvec), N.ptr(sstats), cfg["smooth_wt"], gp, 1, st))
-        n_mid = 2 * F + NS + (NS if cfg["noise_mode"] == N.NOISE_TENSOR else 0)
-        return (None, None, None, None) + (None,) * n_mid + tuple(g_disp) + ((None, None) if cfg["hints"] else ())
+        n_tail = NS + (NS if cfg["noise_mode"] == N.NOISE_TENSOR else 0)
+        return ((None, None, None, None) + (None,) * F + tuple(g_T) + (None,) * n_tail + tuple(g_disp)
+                + ((None, None) if cfg["hints"] else ()))
 
 
 class SelectionMaps(object):

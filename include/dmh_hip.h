@@ -106,6 +106,14 @@ int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_op
  * (overwritten; the adjoint of the bilinear up-sampling, MD2/trainer.py:481-482, is applied in the kernel).   */
 int dmh_photo_loss_bwd(const dmh_photo_args* a, const uint8_t* sel, const float* gvec, const float* fin, float* stage,
                        float* const g_disp[DMH_MAX_SCALES], void* stream);
+/* The same + the gradient w.r.t. the camera poses (outputs[("cam_T_cam", 0, f)] of monocular source frames,
+ * MD2/trainer.py:276-330,487-519): pose_partials[num_scales][strips][num_frames][12] receives per-strip sums
+ *   [ S_i0, S_i1, S_i2, s_i ]  (i = 0, 1, 2)   with   d loss / d P_f[i][j<3] = sum_k inv_K[j][k] S_ik,   d loss / d P_f[i][3] = s_i,
+ * P_f = (K T_f)[:3,:] (MD2/layers.py:188); the caller sums over scales and an image's strips (strip index = image-major:
+ * strips / B per image) and forms d loss / d T_f = K[:3,:]^T dP_f.  dmh_photo_pose_partials_size(a) floats. */
+int64_t dmh_photo_pose_partials_size(const dmh_photo_args* a);
+int dmh_photo_loss_bwd_pose(const dmh_photo_args* a, const uint8_t* sel, const float* gvec, const float* fin, float* stage,
+                            float* const g_disp[DMH_MAX_SCALES], float* pose_partials, void* stream);
 
 /* out[i] = field `scale` of the packed selection map as float (0 identity, 1+f frame f), n = B*H*W.          */
 int dmh_unpack_selection(const uint8_t* sel, int64_t n, int scale, float* out, void* stream);

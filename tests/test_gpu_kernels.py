@@ -242,6 +242,63 @@ def test_photo_loss_two_frames_and_options():
         assert (out2.sel[s] == 1).all()
 
 
+@pytest.mark.parametrize("variant", ["md2", "dh"])
+def test_pose_gradient_vs_fp64_oracle(variant):
+    """d loss / d cam_T_cam (the pose of a monocular source frame, MD2/trainer.py:487-519 -> layers.py:182-198) and
+    d loss / d stereo_T from K1's backward == autograd of the oracle: pooled over seeds, the HIP result is as close to the
+    float64 oracle as the float32 oracle is (x1.5 + 1e-4 of the gradient's norm); disparity gradients unchanged by the
+    pose path; bitwise reproducible."""
+    N, ops, loss_ref, _, synth, _ = _mods()
+    B, H, W = 2, 40, 136
+    fids = (0, -1, "s")
+    e_h = e_o = n64 = 0.0
+    for seed in (31, 131, 231, 331, 431, 531):
+        inputs, disps = synth.make_loss_case(B, H, W, seed)
+        g = torch.Generator().manual_seed(seed + 1)
+        inputs[("color", -1, 0)] = (0.8 * torch.roll(inputs[("color", 0, 0)], -2, 3) +
+                                    0.2 * synth.kitti_like(B, 3, H, W, g))
+        T2 = _general_pose(B, seed + 2).float()
+        d_in = to_dev(inputs)
+
+        def oracle(dtype):
+            ins = {k: v.to(dtype) for k, v in inputs.items()}
+            Ta = T2.detach().clone().to(dtype).requires_grad_(True)      # (.to() alone returns T2 itself for float32)
+            Ts = ins["stereo_T"].detach().clone().requires_grad_(True)
+            ins["stereo_T"] = Ts
+            outs = {("cam_T_cam", 0, -1): Ta}
+            for s, d in enumerate(disps):
+                outs[("disp", s)] = d.detach().clone().to(dtype)
+            loss_ref.generate_images_pred(ins, outs, frame_ids=fids)
+            ls, _ = loss_ref.compute_losses(ins, outs, frame_ids=fids, noise=None, variant=variant)
+            ls["loss"].backward()
+            return Ta.grad, Ts.grad
+        g32, g64 = oracle(torch.float32), oracle(torch.float64)
+
+        def hip(pose):
+            Ta = T2.detach().cuda().requires_grad_(pose)
+            Ts = d_in["stereo_T"].detach().clone().requires_grad_(pose)
+            dd = [d.cuda().requires_grad_(True) for d in disps]
+            out = ops.photometric_smooth_loss(d_in[("color", 0, 0)], [d_in[("color", -1, 0)], d_in[("color", "s", 0)]],
+                                              [Ta, Ts], d_in[("K", 0)], d_in[("inv_K", 0)], dd,
+                                              [d_in[("color", 0, s)] for s in range(4)], noise=None, variant=variant)
+            out.fin[N.FIN_LOSS].backward()
+            return Ta.grad, Ts.grad, [d.grad for d in dd]
+        ga, gs, gd = hip(True)
+        ga2, gs2, _ = hip(True)
+        assert torch.equal(ga, ga2) and torch.equal(gs, gs2)
+        na, ns, gd0 = hip(False)
+        assert na is None and ns is None
+        for a_, b_ in zip(gd, gd0):        # the pose variant of the kernel computes the same disparity gradients
+            torch.testing.assert_close(a_, b_, rtol=1e-4, atol=1e-6 * float(b_.abs().max()))    # (another instruction order)
+        for got, r32, r64 in ((ga, g32[0], g64[0]), (gs, g32[1], g64[1])):
+            assert float(got[:, 3].abs().max()) == 0.0            # (K T)[:3,:] does not depend on T's last row
+            e_h += float((got.cpu().double() - r64).pow(2).sum())
+            e_o += float((r32.double() - r64).pow(2).sum())
+            n64 += float(r64.pow(2).sum())
+    e_h, e_o, n64 = e_h ** 0.5, e_o ** 0.5, n64 ** 0.5
+    assert n64 > 0 and e_h <= 1.5 * e_o + 1e-4 * n64, (e_h / n64, e_o / n64)
+
+
 def test_philox_noise_is_tiny_and_seeded():
     N, ops, loss_ref, _, synth, _ = _mods()
     B, H, W = 2, 32, 96
