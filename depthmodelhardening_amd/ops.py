@@ -703,7 +703,7 @@ class _BnActTrain(torch.autograd.Function):
         lib = N.lib()
         g = _c(g)
         B, Cc = g.shape[0], g.shape[1]
-        if BN_BWD_ENABLED and weight is not None and g.numel() < (1 << 31):
+        if BN_BWD_ENABLED and weight is not None and g.numel() < (1 << 31) and Cc <= 65535:
             gx, gw, gb, g_pre = _bn_backward_fused(g, x, out if ctx.relu else None, weight, mean, invstd,
                                                    ctx.res_grad and ctx.relu)
             if ctx.res_grad and not ctx.relu:
@@ -800,7 +800,7 @@ class _StemTrain(torch.autograd.Function):
         N.check(_timed("stem_bwd", lambda: lib.dmh_stem_bn_relu_pool_bwd(N.ptr(feat), N.ptr(arg), N.ptr(g_feat),
                                                                         N.ptr(g_pooled), N.ptr(ones), B, Cc, H, W,
                                                                         N.ptr(g_pre), N.stream()), 12 * feat.numel()))
-        if BN_BWD_ENABLED and weight is not None and g_pre.numel() < (1 << 31):
+        if BN_BWD_ENABLED and weight is not None and g_pre.numel() < (1 << 31) and Cc <= 65535:
             gx, gw, gb, _ = _bn_backward_fused(g_pre, x, None, weight, mean, invstd, False)
             return gx, gw, gb, None
         gx, gw, gb = _bn_backward(g_pre, x, weight, ctx.bn, mean, invstd, ctx.eps,
@@ -1078,7 +1078,7 @@ class _Conv3x3(torch.autograd.Function):
             N.check(_timed("wino_wrw", lambda: lib.dmh_wino_wrw(N.ptr(x), N.ptr(g), B, Cc, K, H, W, pad, N.ptr(ws), N.ptr(g_w),
                                                                 N.stream()), 4 * (x.numel() + g.numel()), 18 * Cc * g.numel()))
             if need_b:
-                g_b = channel_sum(g)
+                g_b = channel_sum(g) if K <= 65535 else g.sum((0, 2, 3))
             need_w = need_b = False
         if need_x or need_w or need_b:
             r = torch.ops.aten.convolution_backward(g, x, weight, [K] if ctx.has_bias else None, [1, 1], [pad, pad], [1, 1],
