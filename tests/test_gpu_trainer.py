@@ -901,9 +901,51 @@ def test_config5_physical_hardening_full_size():
     assert torch.equal(adv, adv2) and torch.equal(ben, ben2) and torch.equal(masks, masks2), "attack not reproducible"
     assert torch.equal(patch, patch2), "patch not reproducible"
     assert torch.equal(loss, loss2), "hardening loss not reproducible"
-    # the weight gradients of the >= 64-channel layers still come from MIOpen, whose kernels accumulate with atomics:
-    # after one Adam step (|update| <= lr) the weights agree to the update size, not bit for bit
+    # the weight gradients of the strided / 1x1 / stem convolutions still come from MIOpen, whose kernels accumulate with
+    # atomics: after one Adam step (|update| <= lr) the weights agree to the update size, not bit for bit
     assert float((w1 - w2).abs().max()) <= 2.0e-4, float((w1 - w2).abs().max())
+
+
+@pytest.mark.parametrize("cfg", [3, 4])
+def test_configs_3_and_4_step_full_size(tmp_path, cfg):
+    """BASELINE configs 3 and 4 at their workloads (what `bench.py --config N` times), one train_step each on the ResNet-18
+    U-Net at 320x1024: config 3 = L0/Adam attack (10 steps, 12 scenes) + supervised_adv, batch 32; config 4 = DepthHints loss
+    variant + 20-step PGD + SimSiam contrastive term, batch 64.  All loss terms present and finite, the attack moved the
+    object inside its constraint, every trained parameter moved, and the losses of the iteration are bitwise reproducible."""
+    from depthmodelhardening_amd.options import MonodepthOptions
+    from depthmodelhardening_amd.trainer import Trainer
+    extra = {3: ["--batch_size", "32", "--atk_steps", "10", "--norm_type", "l_0", "--supervised_adv"],
+             4: ["--batch_size", "64", "--atk_steps", "20", "--norm_type", "l_inf", "--loss_variant", "dh",
+                 "--contrastive_learning"]}[cfg]
+    argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "320", "--width", "1024",
+            "--learning_rate", "1e-5", "--adv_train", "--weights_init", "scratch", "--model_name", "c%d" % cfg,
+            "--log_dir", str(tmp_path), "--synthetic_len", "1000"] + extra
+
+    def run():
+        import random
+        random.seed(11)             # the EOT pose draws use the random module (physicalTrans.py:150-155)
+        np.random.seed(11)
+        torch.manual_seed(11)
+        tr = Trainer(MonodepthOptions().parse(argv), device=torch.device("cuda"))
+        tr.set_train()
+        obj0 = tr.dataset.obj_img_adv.detach().clone()
+        w0 = {n: p.detach().clone() for n, p in tr.models["encoder"].named_parameters() if p.requires_grad}
+        losses = tr.train_step()
+        torch.cuda.synchronize()
+        return tr, obj0, w0, {k: v.detach().clone() for k, v in losses.items() if torch.is_tensor(v) and v.dim() == 0}
+    tr, obj0, w0, losses = run()
+    want = {"loss", "loss/0", "loss/1", "loss/2", "loss/3"}
+    want |= {"sup_loss"} if cfg == 3 else {"contras_loss", "reproj_loss/0"}
+    assert want <= set(losses), sorted(losses)
+    assert all(torch.isfinite(v) for v in losses.values()) and float(losses["loss"]) > 0
+    assert tr.opt.batch_size == (32 if cfg == 3 else 64) and tr.adv_args["step"] == (10 if cfg == 3 else 20)
+    moved = [n for n, p in tr.models["encoder"].named_parameters() if n in w0 and not torch.equal(p.detach(), w0[n])]
+    assert len(moved) >= len([n for n in w0 if not n.startswith("encoder.fc")]) - 2, len(moved)
+    assert not torch.equal(tr.dataset.obj_img_adv, obj0)                     # the iteration's attack produced a new object
+    del tr
+    _, _, _, losses2 = run()
+    for k in losses:
+        assert torch.equal(losses[k], losses2[k]), "%s not reproducible" % k
 
 
 def test_trainer_depth_hints_step(tmp_path):
