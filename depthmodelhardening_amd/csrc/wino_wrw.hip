@@ -111,41 +111,61 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 
     f32x4 rx[NXL], rd[NDL];
-    // issue the raw loads of chunk `ch` (clamped to the slice: past its end the last chunk is re-read and never used)
-    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+    // raw loads of chunk `ch` (clamped to the slice: past its end the last chunk is re-read and never used): chunk_at() forms the
+    // wave-uniform part, load_x(k) / load_d(k) issue one 16-byte load each, store_x(k) / store_d(k) put a register into the raw
+    // buffer -- one at a time, so that the steady-state loop can place each of them in the shadow of a group of MFMAs (a
+    // vector-memory instruction issued in a block of its own costs the wave ~64 cycles of nothing else)
+    struct Chunk { unsigned xbase, dbase, bad; int wrem; };
+    auto chunk_at = [&](int ch) __attribute__((always_inline)) {
         ch = min(max(ch, c_first), max(c_end - 1, c_first));
         ch = min(ch, a.nchunks - 1);
         const int b = ch / (a.Ht * a.cpr), rem = ch - b * (a.Ht * a.cpr), ty = rem / a.cpr, tx0 = (rem - ty * a.cpr) * TPC;
         const int iy0 = 2 * ty - a.pad, ixa = 2 * tx0 - a.pad - coff;          // ixa: multiple of 4 (tx0 is a multiple of 8)
+        Chunk c;
         // which border rows / words of this chunk lie in the zero padding (uniform); an item in the padding reads at an
         // out-of-range offset, i.e. 0
-        const unsigned bad = (iy0 < 0 ? 1u : 0u) | (iy0 + 3 >= a.H ? 2u : 0u) | (ixa < 0 ? 4u : 0u) | (ixa + 20 >= a.W ? 8u : 0u);
-        const unsigned xbase = (unsigned)(((b * a.C + cb * CCH) * a.H + iy0) * a.W + ixa);     // may wrap below 0: sums are mod 2^32
+        c.bad = (iy0 < 0 ? 1u : 0u) | (iy0 + 3 >= a.H ? 2u : 0u) | (ixa < 0 ? 4u : 0u) | (ixa + 20 >= a.W ? 8u : 0u);
+        c.xbase = (unsigned)(((b * a.C + cb * CCH) * a.H + iy0) * a.W + ixa);     // may wrap below 0: sums are mod 2^32
+        c.dbase = (unsigned)(((b * a.K + kb * KCH) * a.Ho + 2 * ty) * a.Wo + 2 * tx0);
+        c.wrem = a.Wo - 2 * tx0;                                // gradient columns of the chunk inside the row
+        return c;
+    };
+    auto load_x = [&](const Chunk& c, const int k) __attribute__((always_inline)) {
+        const unsigned vo = (xm[k] & c.bad) ? 0xFFFFFF00u : (c.xbase + xg[k]) * 4u;
+        rx[k] = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
+                                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
+    };
+    // (the ragged right edge of dy -- columns beyond the row are other rows' -- is masked when the register is stored)
+    auto load_d = [&](const Chunk& c, const int k) __attribute__((always_inline)) {
+        rd[k] = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
+                                     : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, (c.dbase + dg[k]) * 4u, 0, 0));
+    };
+    auto store_x = [&](const int buf, const int k) __attribute__((always_inline)) {
+        *reinterpret_cast<f32x4*>(raw + buf * RAWBUF + xl[k]) = rx[k];
+    };
+    auto store_d = [&](const int buf, const int k, const int wrem) __attribute__((always_inline)) {
+        f32x4 v = rd[k];
+        if (wrem < DC) {                                        // uniform
+            const int c0 = 4 * ((tid + NT * k) & 3);
 #pragma unroll
-        for (int k = 0; k < NXL; ++k) {
-            const unsigned vo = (xm[k] & bad) ? 0xFFFFFF00u : (xbase + xg[k]) * 4u;
-            rx[k] = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
-                                         : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
+            for (int j = 0; j < 4; ++j) v[j] = (c0 + j < wrem) ? v[j] : 0.f;
         }
-        const unsigned dbase = (unsigned)(((b * a.K + kb * KCH) * a.Ho + 2 * ty) * a.Wo + 2 * tx0);
-        const int wrem = a.Wo - 2 * tx0;                        // gradient columns of the chunk inside the row
+        *reinterpret_cast<f32x4*>(raw + buf * RAWBUF + dl[k]) = v;
+    };
+    int wrem_held = DC;          // of the chunk whose dy words sit in rd[]
+    auto load_chunk = [&](int ch) __attribute__((always_inline)) {
+        const Chunk c = chunk_at(ch);
 #pragma unroll
-        for (int k = 0; k < NDL; ++k) {
-            f32x4 v = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
-                                           : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(drs, (dbase + dg[k]) * 4u, 0, 0));
-            if (wrem < DC) {                                    // ragged right edge (uniform): columns beyond the row are other rows'
-                const int c0 = 4 * ((tid + NT * k) & 3);
+        for (int k = 0; k < NXL; ++k) load_x(c, k);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = (c0 + j < wrem) ? v[j] : 0.f;
-            }
-            rd[k] = v;
-        }
+        for (int k = 0; k < NDL; ++k) load_d(c, k);
+        wrem_held = c.wrem;
     };
     auto store_raw = [&](const int buf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int k = 0; k < NXL; ++k) *reinterpret_cast<f32x4*>(raw + buf * RAWBUF + xl[k]) = rx[k];
+        for (int k = 0; k < NXL; ++k) store_x(buf, k);
 #pragma unroll
-        for (int k = 0; k < NDL; ++k) *reinterpret_cast<f32x4*>(raw + buf * RAWBUF + dl[k]) = rd[k];
+        for (int k = 0; k < NDL; ++k) store_d(buf, k, wrem_held);
     };
     // transforms of one chunk: work item = (channel, tile pair tp): tiles h + 4j, h + 4j + 2 with h = tp & 1, j = tp >> 1; the
     // two tiles are components 2j, 2j + 1 of the channel's 16-byte image word -> one 8-byte write per position.  Items are
@@ -249,6 +269,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             for (int i = 0; i < KS; ++i) ua[0][i] = Mw[i * 32];
 #pragma unroll
             for (int i = 0; i < CS; ++i) vb[0][i] = Vw[i * 32];
+            // staging work of this iteration, dealt over the 16 MFMA groups below: groups 0-7 the raw registers (chunk g+2)
+            // -> raw[cur] (read by transform(g) one iteration ago), groups 8-15 the refill of those registers with chunk g+3
+            constexpr int NST = NXL + NDL;
+            const int wrem_st = wrem_held;
+            Chunk cn;
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -269,12 +294,27 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             else vb[(q + 1) & 1][r - KS] = Vw[(q + 1) * (2 * CCH) + (r - KS) * 32];
                         }
                     }
+                    const int sl = q * 4 + ks;
+                    if (sl < 8) {
+                        if (!(DMH_WRW_ABLATE & 4)) {
+#pragma unroll
+                            for (int k = sl * NST / 8; k < (sl + 1) * NST / 8; ++k) {
+                                if (k < NXL) store_x(cur, k);
+                                else store_d(cur, k - NXL, wrem_st);
+                            }
+                        }
+                    } else {
+                        if (sl == 8) cn = chunk_at(c_first + g + 3);
+#pragma unroll
+                        for (int k = (sl - 8) * NST / 8; k < (sl - 7) * NST / 8; ++k) {
+                            if (k < NXL) load_x(cn, k);
+                            else load_d(cn, k - NXL);
+                        }
+                        if (sl == 15) wrem_held = cn.wrem;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            // raw registers (chunk g+2) -> raw[cur] (read by transform(g) one iteration ago), then refill with chunk g+3
-            if (!(DMH_WRW_ABLATE & 4)) store_raw(cur);
-            load_chunk(c_first + g + 3);
             // raw s_barrier + lgkmcnt only: __syncthreads() would also wait for the loads just issued (vmcnt(0))
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             if (!(DMH_WRW_ABLATE & 16)) __builtin_amdgcn_s_barrier();   // every wave has read the images of chunk g
