@@ -344,7 +344,10 @@ struct FRow {   // row sums of one image row: target (y, y^2) and per stream (x,
 // HINT: DepthHints' extra candidate (DH/trainer.py:510-525,629-636,700-725): the source view warped with the depth
 // HINT is one more stream (formed per pass, like the identity term), the per-pixel argmin runs over [reprojection,
 // identity, hint], and where the hint wins the proxy log-L1 term is accumulated.
-template <int NF, int SPP, int SPL, bool HINT, int MINW = DMH_FWD_WAVES>
+// FL >= 0: the option flags as compile-time constants (bit 0 automask, bit 1 no_ssim, bit 2 MD2 variant, bits 3-4 noise
+// mode): the hot configurations get straight-line code without the flag branches and their merge copies; FL = -1 reads the
+// flags at run time (every other combination).
+template <int NF, int SPP, int SPL, bool HINT, int MINW = DMH_FWD_WAVES, int FL = -1>
 __global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
     constexpr int NSTR = NF * (1 + SPP) + (HINT ? 1 : 0);      // streams with register-resident row sums
     constexpr int ST_HINT = NF * (1 + SPP);
@@ -378,7 +381,10 @@ __global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
         cam[f] = load_cam_w(a.K, a.inv_K, a.T[f], b);
         lp[f] = lane_proj(cam[f], xr);
     }
-    const bool automask = a.automask != 0, no_ssim = a.no_ssim != 0, md2 = a.variant == DMH_VARIANT_MD2;
+    const bool automask = FL >= 0 ? (FL & 1) != 0 : a.automask != 0;
+    const bool no_ssim = FL >= 0 ? (FL & 2) != 0 : a.no_ssim != 0;
+    const bool md2 = FL >= 0 ? (FL & 4) != 0 : a.variant == DMH_VARIANT_MD2;
+    const int noise_mode = FL >= 0 ? ((FL >> 3) & 3) : a.noise_mode;
     const int nf_noise = md2 ? NF : 1;
     const int npass = (NS + SPT - 1) / SPT;
     const Philox<7> rng(a.seed);
@@ -420,6 +426,7 @@ __global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
             const int yr = reflect_idx(r, H);
             const unsigned rowoff = (unsigned)(yr * W + xr) * 4u;
             const bool emit = kk >= 2;
+            const bool olane = out_lane && kk < nrows;   // (a row past the strip's end, see the loop below, emits nothing)
             const int qy = r - 1;
             float tv[3];
             TgtWin tw[3];
@@ -543,7 +550,7 @@ __global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
             // ---- per-pixel min / argmin for the centre row qy (MD2/trainer.py:640-660, DH/trainer.py:671-708)
             const size_t pix = ((size_t)b * H + qy) * W + col;
             float nz[4] = {0.f, 0.f, 0.f, 0.f};   // tie-break noise: slot j * NF + f of this pass
-            if (automask && a.noise_mode == DMH_NOISE_PHILOX) {
+            if (automask && noise_mode == DMH_NOISE_PHILOX) {
                 const uint4 rr = rng(a.offset + (uint64_t)pix * (uint64_t)npass + (uint64_t)pass, 0x646d68ull);
                 const float2 n01 = normal_pair_from_bits(rr.x, rr.y), n23 = normal_pair_from_bits(rr.z, rr.w);
                 nz[0] = n01.x * 0.00001f;
@@ -581,9 +588,9 @@ __global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
                     for (int f = 0; f < NF; ++f) {
                         float z = 0.f;
                         const int fi = md2 ? f : 0;
-                        if (a.noise_mode == DMH_NOISE_TENSOR) {
-                            if (out_lane) z = a.noise[s][(((size_t)b * nf_noise + fi) * H + qy) * W + col];
-                        } else if (a.noise_mode == DMH_NOISE_PHILOX) {
+                        if (noise_mode == DMH_NOISE_TENSOR) {
+                            if (olane) z = a.noise[s][(((size_t)b * nf_noise + fi) * H + qy) * W + col];
+                        } else if (noise_mode == DMH_NOISE_PHILOX) {
                             z = nz[(j * NF + fi) & 3];
                         }
                         // MD2: noise per identity channel, then min over channels (trainer.py:642-654);
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
                     const float pred = fast_rcp(sd_centre[j]);
                     hl = hint_wins ? __logf(fabsf(hint_d - pred) + 1.f) * hint_valid : 0.f;
                 }
-                if (out_lane) {
+                if (olane) {
                     if (k.to_opt[s]) k.to_opt[s][pix] = v;
                     acc1[j] += v;
                     acc2[j] += chosen ? 1.f : 0.f;
@@ -621,14 +628,17 @@ __global__ __launch_bounds__(NT, MINW) void photo_fwd_kernel(const KArgs k) {
                     bits |= (hint_wins ? 3u : (chosen ? (unsigned)(1 + bestf) : 0u)) << (2 * s);
                 }
             }
-            if (out_lane) {
+            if (olane) {
                 if (pass > 0) bits |= k.sel[pix];
                 k.sel[pix] = (uint8_t)bits;
             }
         };
+        // rows in pairs, unconditionally: after two steps the two records are back in their roles, so the loop carries its
+        // state in fixed registers (a conditional second step cost ~60 register copies per iteration at the merge); with an
+        // odd row count the last step runs on a row past the strip's end and emits nothing
         for (int kk = 0; kk < nrows; kk += 2) {
             step(kk, rowA, rowB, 0);
-            if (kk + 1 < nrows) step(kk + 1, rowB, rowA, 1);
+            step(kk + 1, rowB, rowA, 1);
         }
         // fixed-order wave sums -> one partial pair per (scale, strip)
 #pragma unroll
@@ -1104,7 +1114,17 @@ int dmh_photo_loss_fwd(const dmh_photo_args* a, uint8_t* sel, float* const to_op
             static const int variant = getenv("DMH_K1_FWD_VARIANT") ? atoi(getenv("DMH_K1_FWD_VARIANT")) : 0;
             if (a->depth_hint) hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 0, true>), grid, block, 0, (hipStream_t)stream, k);
             else if (variant == 2) hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 2, false>), grid, block, 0, (hipStream_t)stream, k);
-            else hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 0, false>), grid, block, 0, (hipStream_t)stream, k);
+            else if (variant == 1 || !a->automask || a->no_ssim)
+                hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 0, false>), grid, block, 0, (hipStream_t)stream, k);
+            else {      // the training configurations: flags as constants
+                const bool md2 = a->variant == DMH_VARIANT_MD2;
+#define DMH_K1_FWD_FL(MD2, NOISE) \
+    hipLaunchKernelGGL((photo_fwd_kernel<1, 2, 0, false, 3, 1 | ((MD2) << 2) | ((NOISE) << 3)>), grid, block, 0, (hipStream_t)stream, k)
+                if (a->noise_mode == DMH_NOISE_PHILOX) { if (md2) DMH_K1_FWD_FL(1, DMH_NOISE_PHILOX); else DMH_K1_FWD_FL(0, DMH_NOISE_PHILOX); }
+                else if (a->noise_mode == DMH_NOISE_TENSOR) { if (md2) DMH_K1_FWD_FL(1, DMH_NOISE_TENSOR); else DMH_K1_FWD_FL(0, DMH_NOISE_TENSOR); }
+                else { if (md2) DMH_K1_FWD_FL(1, DMH_NOISE_NONE); else DMH_K1_FWD_FL(0, DMH_NOISE_NONE); }
+#undef DMH_K1_FWD_FL
+            }
             break;
         }
         case 2: hipLaunchKernelGGL((photo_fwd_kernel<2, 2, 0, false>), grid, block, 0, (hipStream_t)stream, k); break;
