@@ -316,8 +316,14 @@ __host__ inline int pick_rows(int B, int H, int W, int out_cols) {
         const int v = atoi(e);
         if (v >= 2 && v <= 1024) return v;
     }
-    int R = 32;
-    while (R > 8 && (int64_t)B * tx * ((H + R - 1) / R) < want) R >>= 1;
+    if (out_cols == FW_OUT) {
+        int R = 32;
+        while (R > 8 && (int64_t)B * tx * ((H + R - 1) / R) < want) R >>= 1;
+        return R;
+    }
+    // backward: the row loop runs in threes, so strip heights are multiples of 3 (33 / 18 / 9)
+    int R = 33;
+    while (R > 9 && (int64_t)B * tx * ((H + R - 1) / R) < want) R = R > 18 ? 18 : 9;
     return R;
 }
 
@@ -676,7 +682,8 @@ struct BRow {   // record of one processed row: its row sums, the coefficient ro
 // With G = d loss / d pix of a pixel, den = a_z + sd m (so cam[2] + eps = depth den), p = (x, y, 1), X = depth inv_K p:
 //     a = G_x / den, b = G_y / den, c = -(a pix_x + b pix_y):   d loss / d P[i][j<3] = sum_k invK[j][k] sum_pix (a,b,c)_i p_k,
 //     d loss / d P[i][3] = sum_pix (a,b,c)_i sd   -> twelve sums per (strip, frame), finished on the host side of the C ABI's caller.
-template <int NF, bool SAME, bool POSE>
+// PLAIN: the training configuration (SSIM on, no depth hints) with those two flags as constants; otherwise read at run time.
+template <int NF, bool SAME, bool POSE, bool PLAIN>
 __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, const int tile, float* sA, float* sB) {
     const dmh_photo_args& a = k.a;
     const int lane = threadIdx.x & (WAVE - 1);
@@ -694,7 +701,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
     const size_t img_off = (size_t)b * 3 * H * W;
     const rsrc_t rt = make_rsrc(a.target + img_off, 3u * plane);
     const rsrc_t rsel = make_rsrc(k.csel + (size_t)b * H * W, (unsigned)(H * W));
-    const bool no_ssim = a.no_ssim != 0;
+    const bool no_ssim = PLAIN ? false : a.no_ssim != 0;
     float up = k.gvec[DMH_FIN_LOSS] / (float)a.num_scales + k.gvec[DMH_FIN_LOSS_S + s] + k.gvec[DMH_FIN_REPROJ_S + s];
     up *= (a.variant == DMH_VARIANT_MD2) ? 1.0f / ((float)B * (float)H * (float)W) : 1.0f / (k.fin[DMH_FIN_COUNT_S + s] + 1e-7f);
     up = uni(up);
@@ -714,7 +721,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
     const unsigned sel_shift = 2u * (unsigned)s;
     // depth hints: where the hint won (selection code 3) the reprojection term of frame 0 applies too, plus the proxy
     // term log(|hint - depth| + 1) * valid / (count + 1e-7)                       (DH/trainer.py:541-555,713-725)
-    const bool hints = a.depth_hint != nullptr;
+    const bool hints = PLAIN ? false : a.depth_hint != nullptr;
     const rsrc_t rhint = make_rsrc(hints ? a.depth_hint + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
     const rsrc_t rhmask = make_rsrc(hints ? a.depth_hint_mask + (size_t)b * H * W : a.target, (unsigned)(H * W) * 4u);
     float up_h = 0.f;
@@ -789,6 +796,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
         auto step = [&](const int kk, BRow& older, const BRow& newer, BRow& cur, auto stage_tag) __attribute__((always_inline)) {
             constexpr int STAGE = decltype(stage_tag)::value;
             const int r = Y0 - 2 + kk;
+            const bool olane = out_lane && kk < nrows;   // (rows past the strip's end, see the loop below, write nothing)
             // (1) this row: warped values and chain factors J_c = d warped_c / d disp from the operands requested a row ago
             const float sd_rq = older.sdv;  // of the row two above (read before `older` becomes the next row's record)
             if constexpr (POSE) {           // this row's request fields -> fields that live for two more rows
@@ -865,7 +873,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
                     }
                 }
                 if constexpr (POSE) {
-                    if (out_lane) {
+                    if (olane) {
                         const float pa = Gx * older.qa, pb = Gy * older.qb, pc = -(pa * older.qx + pb * older.qy);
                         const float fx = (float)col, fy = (float)rq;
                         pacc[0] = fmaf(pa, fx, pacc[0]); pacc[1] = fmaf(pa, fy, pacc[1]); pacc[2] += pa; pacc[3] = fmaf(pa, sd_rq, pacc[3]);
@@ -873,7 +881,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
                         pacc[8] = fmaf(pc, fx, pacc[8]); pacc[9] = fmaf(pc, fy, pacc[9]); pacc[10] += pc; pacc[11] = fmaf(pc, sd_rq, pacc[11]);
                     }
                 }
-                if (hints && newer.sel == 3u && out_lane) {
+                if (hints && newer.sel == 3u && olane) {
                     const unsigned ho = (unsigned)(rq * W + col) * 4u;
                     const float hd = ldb(rhint, ho, 0u), hv = ldb(rhmask, ho, 0u);
                     const float pred = fast_rcp(sd_rq), df = pred - hd;
@@ -881,9 +889,9 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
                     // d log(|hint - pred| + 1) / d pred * d pred / d disp,  pred = 1 / sd,  sd = min_disp + dmul * disp
                     g = fmaf(up_h * hv * sg * fast_rcp(fabsf(df) + 1.f), -(pred * pred) * k.dmul, g);
                 }
-                if (!out_lane) g = 0.f;
+                if (!olane) g = 0.f;
                 if constexpr (SAME) {
-                    if (out_lane) {
+                    if (olane) {
                         float* p = k.g_disp[s] + ((size_t)b * H + rq) * W + col;
                         *p = (f > 0) ? *p + g : g;
                     }
@@ -932,10 +940,12 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
         step(1, recC, recA, recB, S0());
         step(2, recA, recB, recC, S1());
         step(3, recB, recC, recA, S1());
+        // rows in threes, unconditionally (after three steps the records are back in their roles: the loop carries its state
+        // in fixed registers, no copies at a merge); up to two steps run on rows past the strip's end and write nothing
         for (int kk = 4; kk < nrows; kk += 3) {
             step(kk, recC, recA, recB, S2());
-            if (kk + 1 < nrows) step(kk + 1, recA, recB, recC, S2());
-            if (kk + 2 < nrows) step(kk + 2, recB, recC, recA, S2());
+            step(kk + 1, recA, recB, recC, S2());
+            step(kk + 2, recB, recC, recA, S2());
         }
         if constexpr (!SAME) {
             flush(ja, accA);
@@ -952,7 +962,7 @@ __device__ __forceinline__ void photo_bwd_strip(const KArgs& k, const int s, con
     }
 }
 
-template <int NF, bool POSE = false>
+template <int NF, bool POSE = false, bool PLAIN = false>
 __global__ __launch_bounds__(NT, POSE ? 1 : DMH_BWD_WAVES) void photo_bwd_kernel(const KArgs k) {
     __shared__ float s_row[WPB][2][WAVE];     // horizontal up-sampling adjoint: g*(1-lx), g*lx of one row
     const int wv = threadIdx.x >> 6;
@@ -961,8 +971,8 @@ __global__ __launch_bounds__(NT, POSE ? 1 : DMH_BWD_WAVES) void photo_bwd_kernel
     // scale fastest: the waves of one workgroup take the scales of ONE strip and share its target / source / selection
     // lines in L1 and L2 (the opposite order re-fetched them per scale: 1.8x the algorithmic traffic, profiles/README.md)
     const int tile = item / k.a.num_scales, s = item - tile * k.a.num_scales;
-    if (k.a.Hs[s] == k.a.H) photo_bwd_strip<NF, true, POSE>(k, s, tile, s_row[wv][0], s_row[wv][1]);
-    else photo_bwd_strip<NF, false, POSE>(k, s, tile, s_row[wv][0], s_row[wv][1]);
+    if (k.a.Hs[s] == k.a.H) photo_bwd_strip<NF, true, POSE, PLAIN>(k, s, tile, s_row[wv][0], s_row[wv][1]);
+    else photo_bwd_strip<NF, false, POSE, PLAIN>(k, s, tile, s_row[wv][0], s_row[wv][1]);
 }
 
 // Coarse scales: add the (<= 4) overlapping strip blocks of every low-resolution texel in a fixed order.
@@ -1189,7 +1199,10 @@ int dmh_photo_loss_bwd_pose(const dmh_photo_args* a, const uint8_t* sel, const f
         }
     } else {
         switch (a->num_frames) {
-            case 1: hipLaunchKernelGGL((photo_bwd_kernel<1>), grid, block, 0, (hipStream_t)stream, k); break;
+            case 1:
+                if (!a->no_ssim && !a->depth_hint) hipLaunchKernelGGL((photo_bwd_kernel<1, false, true>), grid, block, 0, (hipStream_t)stream, k);
+                else hipLaunchKernelGGL((photo_bwd_kernel<1>), grid, block, 0, (hipStream_t)stream, k);
+                break;
             case 2: hipLaunchKernelGGL((photo_bwd_kernel<2>), grid, block, 0, (hipStream_t)stream, k); break;
             default: hipLaunchKernelGGL((photo_bwd_kernel<3>), grid, block, 0, (hipStream_t)stream, k); break;
         }
