@@ -154,6 +154,31 @@ if bs and bt:
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
         for n, (d, c) in sorted(agg.items(), key=lambda x: -x[1][0]):
             w.writerow([n, c, d, round(d / c, 1), round(100 * d / tot, 3)])
+    # the same per kernel family (the tables of DESIGN.md section 6 / profiles/README.md), ms per step
+    def family(n):
+        for key, fam in (("wino32", "K17 wino32_conv"), ("wino_wrw", "K18 wino_wrw"), ("wino_", "K10 wino_conv (+ filter transforms)"),
+                         ("small_conv", "K11 small_conv"), ("small_wrw", "K16 small_wrw"), ("head_wrw", "K13 head weight gradient"),
+                         ("down_conv", "K15 down_conv"), ("elu_pad", "K7 decoder glue"), ("up_cat_pad", "K7 decoder glue"),
+                         ("bn_", "K9 encoder glue / BatchNorm"), ("channel_sum", "K9 encoder glue / BatchNorm"),
+                         ("stem", "stem (K14 / K12 / K9 stem glue)"), ("head_", "K13 disparity heads"),
+                         ("photo_", "K1-K6 loss + attack"), ("smooth_", "K1-K6 loss + attack"), ("finalize", "K1-K6 loss + attack"),
+                         ("paste_", "K1-K6 loss + attack"), ("sq_mean", "K1-K6 loss + attack"), ("l0_", "K1-K6 loss + attack"),
+                         ("pgd_", "K1-K6 loss + attack"), ("unpack_sel", "K1-K6 loss + attack"), ("depth_err", "K1-K6 loss + attack"),
+                         ("igemm", "MIOpen"), ("miopen", "MIOpen"), ("MIOpen", "MIOpen"), ("batched_transpose", "MIOpen"),
+                         ("Sp3Asm", "MIOpen"), ("ck::", "MIOpen"), ("gridwise", "MIOpen"),
+                         ("at::native", "ATen / runtime"), ("rocclr", "ATen / runtime")):
+            if key in n:
+                return fam
+        return "other"
+    fam = collections.defaultdict(lambda: [0, 0])
+    for n, (d, c) in agg.items():
+        fam[family(n)][0] += d
+        fam[family(n)][1] += c
+    with open("profiles/%s_bench_families.csv" % tag, "w") as f:
+        w = csv.writer(f)
+        w.writerow(["Family", "ms_per_step", "launches_per_step", "Percentage"])
+        for n, (d, c) in sorted(fam.items(), key=lambda x: -x[1][0]):
+            w.writerow([n, round(d / 1e6 / j["steps"], 3), round(c / j["steps"], 1), round(100 * d / tot, 2)])
     print("bench timed region: %d steps, %.1f ms kernel time of %.1f ms wall" % (j["steps"], tot / 1e6, window / 1e6))
     for n, (d, c) in sorted(agg.items(), key=lambda x: -x[1][0])[:12]:
         print("  %-80s %8.2f ms %5d calls" % (n[:80], d / 1e6, c))
