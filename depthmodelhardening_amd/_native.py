@@ -43,6 +43,13 @@ class PasteArgs(C.Structure):
                 ("flip", _fp)]
 
 
+class RoiGlueArgs(C.Structure):
+    _fields_ = [("y", _fp), ("skip", _fp), ("y_org", _fp), ("skip_org", _fp), ("dst_org", _fp),
+                ("B", C.c_int), ("C1", C.c_int), ("C2", C.c_int), ("sh", C.c_int), ("sw", C.c_int), ("kh", C.c_int),
+                ("kw", C.c_int), ("hc", C.c_int), ("wc", C.c_int), ("H", C.c_int), ("W", C.c_int), ("up", C.c_int),
+                ("elu", C.c_int)]
+
+
 _PtrArr = _fp * MAX_SCALES
 
 _SIGNATURES = {
@@ -80,6 +87,11 @@ _SIGNATURES = {
     "dmh_dec_up_cat_pad_bwd": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp, _fp]),
     "dmh_elu_pad_fwd": (C.c_int, [_fp] + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_elu_pad_bwd": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp]),
+    "dmh_roi_glue_fwd": (C.c_int, [C.POINTER(RoiGlueArgs), _fp, _fp]),
+    "dmh_roi_glue_bwd": (C.c_int, [C.POINTER(RoiGlueArgs), _fp, _fp, _fp, _fp]),
+    "dmh_roi_cost_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dmh_roi_cost_fwd": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 5 + [_fp] * 4),
+    "dmh_roi_cost_bwd": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 5 + [_fp] * 3),
     "dmh_bn_act_fwd": (C.c_int, [_fp] * 4 + [C.c_int] * 4 + [_fp, _fp]),
     "dmh_bn_act_bwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp, _fp, _fp]),
     "dmh_bn_stats_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

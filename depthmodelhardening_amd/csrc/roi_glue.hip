@@ -1,0 +1,236 @@
+// K19 -- windowed decoder glue and the windowed attack cost: the attack computed only where its loss lives.
+//
+// The attack's cost is -mean((disp * mask)^2) (torchattacks/attacks/phy_obj_atk.py:88-97, phy_obj_atk_l0.py:118-134):
+// the disparity is read under the pasted object only, so d cost / d disp is zero outside the object's bounding box, and
+// the patch gradient reads d cost / d image under the object only (physicalTrans.py:156-165: adv = scene (1 - m) + patch m).
+// The high-resolution tail of the depth decoder (MD2/networks/depth_decoder.py:51-63: upconv(1,0) ... dispconv(0)) has a
+// receptive field of a dozen pixels, so inside an attack it is evaluated -- forward and backward, exactly -- on a window
+// around each sample's box instead of the whole 320 x 1024 frame.  The convolutions are the unchanged K10 / K11 / K13 / K17
+// kernels run with padding 0 on compact [B, C, hc + 2, wc + 2] windows; what changes is the glue between them:
+//
+//   roi_glue : out[b, :, i, j] = pad1_reflect(cat(up2_nearest(ELU(y)), skip)) at frame position (org_b + (i, j) - 1)
+//
+// i.e. the up_cat_pad / elu_pad pass of decoder_glue.hip restricted to a per-sample window of the destination frame, with
+// sources that are themselves windows (origin table) or whole frames (no table).  The reflection is the frame's, not the
+// window's: a window that touches the image border sees exactly the padded values the full pass would produce.
+// Backward = a gather over the same index map (deterministic, no atomics); positions no window entry reads get 0.
+//
+//   roi_cost : cost = sum_b sum_window (sigmoid(d_pre) * mask)^2 / (B H W)        (mask is the full-frame K3 output)
+#include "common.hpp"
+
+using namespace dmh;
+
+namespace {
+
+constexpr int NT = 256;
+
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expf(x) - 1.f; }
+__device__ __forceinline__ float elu_grad(float x) { return x > 0.f ? 1.f : expf(x); }
+
+__global__ __launch_bounds__(NT) void roi_glue_fwd_kernel(const dmh_roi_glue_args a, float* __restrict__ out) {
+    const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
+    const int idx = (blockIdx.x * NT + threadIdx.x) * 2;        // PW is even: a pair never straddles two rows
+    if (idx >= PH * PW) return;
+    const int plane = blockIdx.y, b = plane / C, c = plane - b * C;
+    const int i = idx / PW, j = idx - i * PW;
+    const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
+    const int Y = reflect_idx(oy + i - 1, a.H);
+    const int X0 = reflect_idx(ox + j - 1, a.W), X1 = reflect_idx(ox + j, a.W);
+    float v0, v1;
+    if (c < a.C1) {
+        const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
+        const int yy = min(max((a.up ? Y >> 1 : Y) - sy0, 0), a.sh - 1);
+        const int x0 = min(max((a.up ? X0 >> 1 : X0) - sx0, 0), a.sw - 1);
+        const int x1 = min(max((a.up ? X1 >> 1 : X1) - sx0, 0), a.sw - 1);
+        const float* row = a.y + ((size_t)(b * a.C1 + c) * a.sh + yy) * a.sw;
+        v0 = row[x0];
+        v1 = row[x1];
+        if (a.elu) {
+            v0 = elu_f(v0);
+            v1 = elu_f(v1);
+        }
+    } else {
+        const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
+        const int yy = min(max(Y - ky0, 0), a.kh - 1);
+        const int x0 = min(max(X0 - kx0, 0), a.kw - 1), x1 = min(max(X1 - kx0, 0), a.kw - 1);
+        const float* row = a.skip + ((size_t)(b * a.C2 + (c - a.C1)) * a.kh + yy) * a.kw;
+        v0 = row[x0];
+        v1 = row[x1];
+    }
+    *reinterpret_cast<float2*>(out + (size_t)plane * PH * PW + idx) = make_float2(v0, v1);
+}
+
+// sum of the window's padded-gradient entries that read frame position (Y, X): the entry straight above it and, on
+// rows / columns 1 and H-2 / W-2, the reflected border entries -- each only if it lies inside this sample's window
+__device__ __forceinline__ float gather_pad(const float* __restrict__ gp, int Y, int X, int H, int W, int oy, int ox,
+                                            int PH, int PW) {
+    int rows[3], cols[3], nr = 0, nc = 0;
+    int r = Y + 1 - oy;
+    if (r >= 0 && r < PH) rows[nr++] = r;
+    if (Y == 1 && oy == 0) rows[nr++] = 0;
+    r = H + 1 - oy;
+    if (Y == H - 2 && r < PH) rows[nr++] = r;
+    int q = X + 1 - ox;
+    if (q >= 0 && q < PW) cols[nc++] = q;
+    if (X == 1 && ox == 0) cols[nc++] = 0;
+    q = W + 1 - ox;
+    if (X == W - 2 && q < PW) cols[nc++] = q;
+    float acc = 0.f;
+    for (int s = 0; s < nr; ++s)
+        for (int t = 0; t < nc; ++t) acc += gp[rows[s] * PW + cols[t]];
+    return acc;
+}
+
+// grid.y = B*C1 planes of g_y followed by B*C2 planes of g_skip; one thread per source element (whole source planes
+// are written: 0 where no window entry reads the element)
+__global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_args a, const float* __restrict__ g_out,
+                                                          float* __restrict__ g_y, float* __restrict__ g_skip) {
+    const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    const int plane = blockIdx.y;
+    if (plane < a.B * a.C1) {
+        if (t >= a.sh * a.sw) return;
+        const int b = plane / a.C1, c = plane - b * a.C1;
+        const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
+        const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
+        const int yy = t / a.sw, xx = t - yy * a.sw;
+        const int Ys = sy0 + yy, Xs = sx0 + xx;
+        const float* gp = g_out + (size_t)(b * C + c) * PH * PW;
+        float acc;
+        if (a.up) {
+            // quick reject: the 2 x 2 children and their reflections all lie outside the window
+            acc = 0.f;
+            const int Y0 = 2 * Ys, X0 = 2 * Xs;
+            const bool near_y = (Y0 + 2 >= oy && Y0 + 1 < oy + PH) || Y0 <= 1 || Y0 + 1 >= a.H - 2;
+            const bool near_x = (X0 + 2 >= ox && X0 + 1 < ox + PW) || X0 <= 1 || X0 + 1 >= a.W - 2;
+            if (near_y && near_x)
+                acc = gather_pad(gp, Y0, X0, a.H, a.W, oy, ox, PH, PW) + gather_pad(gp, Y0, X0 + 1, a.H, a.W, oy, ox, PH, PW) +
+                      gather_pad(gp, Y0 + 1, X0, a.H, a.W, oy, ox, PH, PW) +
+                      gather_pad(gp, Y0 + 1, X0 + 1, a.H, a.W, oy, ox, PH, PW);
+        } else {
+            acc = gather_pad(gp, Ys, Xs, a.H, a.W, oy, ox, PH, PW);
+        }
+        const size_t o = (size_t)plane * a.sh * a.sw + t;
+        g_y[o] = (a.elu && acc != 0.f) ? acc * elu_grad(a.y[o]) : acc;
+    } else {
+        if (t >= a.kh * a.kw) return;
+        const int q = plane - a.B * a.C1, b = q / a.C2, c = q - b * a.C2;
+        const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
+        const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
+        const int yy = t / a.kw, xx = t - yy * a.kw;
+        const float* gp = g_out + (size_t)(b * C + a.C1 + c) * PH * PW;
+        g_skip[(size_t)q * a.kh * a.kw + t] = gather_pad(gp, ky0 + yy, kx0 + xx, a.H, a.W, oy, ox, PH, PW);
+    }
+}
+
+// ---- windowed attack cost ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void roi_cost_fwd_kernel(const float* __restrict__ d_pre, const float* __restrict__ mask,
+                                                          const int* __restrict__ org, int hd, int wd, int H, int W,
+                                                          float* __restrict__ sig, float* __restrict__ partials) {
+    __shared__ float s_red[NT / WAVE];
+    const int b = blockIdx.y, n = hd * wd;
+    const int oy = org[2 * b], ox = org[2 * b + 1];
+    float acc = 0.f;
+    for (int t = blockIdx.x * NT + threadIdx.x; t < n; t += gridDim.x * NT) {
+        const int i = t / wd, j = t - i * wd;
+        const float s = 1.f / (1.f + expf(-d_pre[(size_t)b * n + t]));
+        sig[(size_t)b * n + t] = s;
+        const float v = s * mask[((size_t)b * H + oy + i) * W + ox + j];
+        acc += v * v;
+    }
+    const float r = block_sum<NT>(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+__global__ __launch_bounds__(NT) void roi_cost_finalize_kernel(const float* __restrict__ partials, int nblk, double n,
+                                                               float* __restrict__ cost) {
+    __shared__ double s_red[NT];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += NT) acc += (double)partials[i];
+    s_red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cost[0] = (float)(s_red[0] / n);
+}
+
+// g_pre = gscale * 2 s m^2 / n * s (1 - s)      (cost -> sigmoid -> pre-activation)
+__global__ __launch_bounds__(NT) void roi_cost_bwd_kernel(const float* __restrict__ sig, const float* __restrict__ mask,
+                                                          const int* __restrict__ org, int hd, int wd, int H, int W,
+                                                          const float* __restrict__ gscale, float inv_n,
+                                                          float* __restrict__ g_pre) {
+    const int b = blockIdx.y, n = hd * wd;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if (t >= n) return;
+    const int oy = org[2 * b], ox = org[2 * b + 1];
+    const int i = t / wd, j = t - i * wd;
+    const float s = sig[(size_t)b * n + t], m = mask[((size_t)b * H + oy + i) * W + ox + j];
+    g_pre[(size_t)b * n + t] = gscale[0] * 2.f * inv_n * s * m * m * s * (1.f - s);
+}
+
+inline unsigned blocks_for(int64_t n) { return (unsigned)((n + NT - 1) / NT); }
+inline int cost_blocks(int n) {
+    const int b = (n + NT * 4 - 1) / (NT * 4);
+    return b < 1 ? 1 : (b > 64 ? 64 : b);
+}
+
+int check_glue(const dmh_roi_glue_args* a) {
+    DMH_REQUIRE(a && a->y && a->dst_org && (a->skip || a->C2 == 0), "null pointer");
+    DMH_REQUIRE(a->B > 0 && a->C1 > 0 && a->C2 >= 0 && a->sh >= 1 && a->sw >= 1 && (a->C2 == 0 || (a->kh >= 1 && a->kw >= 1)),
+                "bad sizes");
+    DMH_REQUIRE(a->hc >= 2 && a->wc >= 2 && (a->wc & 1) == 0 && a->hc <= a->H && a->wc <= a->W && a->H >= 4 && a->W >= 4,
+                "window must be at least 2 x 2, of even width, inside a frame of at least 4 x 4");
+    DMH_REQUIRE((int64_t)a->B * (a->C1 + a->C2) <= 65535, "too many planes");
+    DMH_REQUIRE((int64_t)a->sh * a->sw < (1 << 30) && (int64_t)a->kh * a->kw < (1 << 30), "source plane too large");
+    return DMH_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dmh_roi_glue_fwd(const dmh_roi_glue_args* a, float* out, void* stream) {
+    if (int rc = check_glue(a)) return rc;
+    DMH_REQUIRE(out, "null pointer");
+    hipLaunchKernelGGL(roi_glue_fwd_kernel, dim3(blocks_for((int64_t)(a->hc + 2) * (a->wc + 2) / 2), a->B * (a->C1 + a->C2)),
+                       dim3(NT), 0, (hipStream_t)stream, *a, out);
+    return check_launch("dmh_roi_glue_fwd");
+}
+
+int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y, float* g_skip, void* stream) {
+    if (int rc = check_glue(a)) return rc;
+    DMH_REQUIRE(g_out && g_y, "null pointer");
+    const int planes = a->B * a->C1 + (g_skip ? a->B * a->C2 : 0);
+    const int64_t per_plane = (g_skip && a->C2 > 0 && (int64_t)a->kh * a->kw > (int64_t)a->sh * a->sw) ? (int64_t)a->kh * a->kw
+                                                                                                       : (int64_t)a->sh * a->sw;
+    hipLaunchKernelGGL(roi_glue_bwd_kernel, dim3(blocks_for(per_plane), planes), dim3(NT), 0, (hipStream_t)stream, *a, g_out,
+                       g_y, g_skip);
+    return check_launch("dmh_roi_glue_bwd");
+}
+
+int64_t dmh_roi_cost_partials_size(int B, int hd, int wd) { return (int64_t)B * cost_blocks(hd * wd); }
+
+int dmh_roi_cost_fwd(const float* d_pre, const float* mask, const int* org, int B, int hd, int wd, int H, int W, float* sig,
+                     float* partials, float* cost, void* stream) {
+    DMH_REQUIRE(d_pre && mask && org && sig && partials && cost, "null pointer");
+    DMH_REQUIRE(B > 0 && B <= 65535 && hd >= 1 && wd >= 1 && hd <= H && wd <= W && (int64_t)hd * wd < (1 << 30), "bad sizes");
+    const int nb = cost_blocks(hd * wd);
+    hipLaunchKernelGGL(roi_cost_fwd_kernel, dim3(nb, B), dim3(NT), 0, (hipStream_t)stream, d_pre, mask, org, hd, wd, H, W, sig,
+                       partials);
+    hipLaunchKernelGGL(roi_cost_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partials, nb * B,
+                       (double)B * (double)H * (double)W, cost);
+    return check_launch("dmh_roi_cost_fwd");
+}
+
+int dmh_roi_cost_bwd(const float* sig, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
+                     const float* gscale, float* g_pre, void* stream) {
+    DMH_REQUIRE(sig && mask && org && gscale && g_pre, "null pointer");
+    DMH_REQUIRE(B > 0 && B <= 65535 && hd >= 1 && wd >= 1 && hd <= H && wd <= W && (int64_t)hd * wd < (1 << 30), "bad sizes");
+    hipLaunchKernelGGL(roi_cost_bwd_kernel, dim3(blocks_for((int64_t)hd * wd), B), dim3(NT), 0, (hipStream_t)stream, sig, mask,
+                       org, hd, wd, H, W, gscale, (float)(1.0 / ((double)B * (double)H * (double)W)), g_pre);
+    return check_launch("dmh_roi_cost_bwd");
+}
+
+}  // extern "C"

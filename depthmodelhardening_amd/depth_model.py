@@ -22,6 +22,21 @@ class DepthModelWrapper(torch.nn.Module):
         return self.decoder(feats)[("disp", 0)]
 
 
+    def masked_sq_mean(self, input_image, mask, plan=None, tab=None):
+        """mean((disp_0(input_image) * mask)^2): the cost every object attack maximises (phy_obj_atk.py:92-94,
+        phy_obj_atk_l0.py:125-127).  With a window plan (roi.RoiPlan + its device table) around the pasted object, and a
+        decoder that supports it, the decoder's high-resolution tail runs on the windows only."""
+        from . import ops
+        feats = self.encoder(input_image)
+        if plan is not None and hasattr(self.decoder, "roi_ok") and self.decoder.roi_ok(feats):
+            return self.decoder.masked_sq_mean(feats, mask, plan, tab)
+        if feats[-1].is_cuda and hasattr(self.decoder, "_forward_fused"):
+            disp = self.decoder(feats, only_scales=(0,))[("disp", 0)]
+        else:
+            disp = self.decoder(feats)[("disp", 0)]
+        return ops.masked_sq_mean(disp, mask)
+
+
 def import_depth_model(scene_size, model_type='monodepth2', pre_model_path=None):
     """Build the Monodepth2 ResNet-18 depth model and load ``encoder.pth`` / ``depth.pth`` from
     ``pre_model_path`` when given (depth_model.py:117-153 filters the encoder dict by key the same way).

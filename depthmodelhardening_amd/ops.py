@@ -1486,6 +1486,159 @@ def down_block_eval(x, w3, scale1, shift1, wd, scale_d, shift_d, w2, scale2, shi
     return (y, skip) if return_skip else y
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# K19: the attack's cost evaluated on one window per scene (roi.py plans the windows, csrc/roi_glue.hip is the pass
+# between the convolutions).  The convolution kernels are the ones above, chosen here by what a kernel CAN take: a window
+# launch is smaller than the shapes the throughput thresholds of _wino_ok / _wino32_ok were measured on.
+# ---------------------------------------------------------------------------------------------------------------
+ROI_ENABLED = os.environ.get("DMH_ROI", "1") != "0"      # A/B switch: 0 = the attack runs the whole frame
+
+
+def _conv_any(x, weight, bias, pad, backward=False):
+    """conv2d(x, weight, padding=pad) -- or, with ``backward``, the same filter's backward-data pass on a gradient x with
+    pad' = 2 - pad_forward -- on whichever hand-written kernel takes the channel counts; ATen otherwise."""
+    B, n_in, H, W = x.shape
+    n_out = weight.shape[1] if backward else weight.shape[0]
+    Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+    if WINO_ENABLED and x.numel() < (1 << 30):
+        if not backward and n_out == 1 and pad == 0 and n_in % 4 == 0:
+            y = torch.empty((B, 1, Ho, Wo), device=x.device, dtype=torch.float32)
+            N.check(_timed("conv3x3_head", lambda: N.lib().dmh_conv3x3_head(
+                N.ptr(x), N.ptr(_c(weight.detach())), N.ptr(bias), B, n_in, H, W, 0, N.ptr(y), N.stream()),
+                4 * (x.numel() + y.numel())))
+            return y
+        if backward and n_in == 1 and pad == 2 and n_out % 4 == 0 and n_out <= 64 and Ho >= 3 and Wo >= 3:
+            y = torch.empty((B, n_out, Ho, Wo), device=x.device, dtype=torch.float32)
+            N.check(_timed("conv3x3_head_bwd", lambda: N.lib().dmh_conv3x3_head_bwd_data(
+                N.ptr(x), N.ptr(_c(weight.detach())), B, n_out, Ho, Wo, N.ptr(y), N.stream()), 4 * (x.numel() + y.numel())))
+            return y
+        if _small_ok(n_in, n_out):
+            return _small_conv(x, weight, bias, pad, backward)
+        if n_in % 8 == 0 and n_in >= 24 and Ho % 2 == 0 and Wo % 2 == 0 and Ho >= 2 and Wo >= 2:
+            if n_out % 32 == 0 and n_out % 64 and n_out <= 96:
+                return _wino32_conv(x, _wino32_filter(weight, backward), bias, n_out, pad)
+            if n_out >= 64:
+                return _wino_conv(x, _wino_filter(weight, backward), bias, n_out, pad)
+    if backward:
+        return torch.nn.functional.conv_transpose2d(x, weight, None, 1, 2 - pad)
+    return torch.conv2d(x, weight, bias, 1, pad)
+
+
+def _roi_glue_args(y, y_org, skip, skip_org, dst_org, size, frame, up, elu):
+    a = N.RoiGlueArgs()
+    a.y, a.skip = N.ptr(y), N.ptr(skip)
+    a.y_org, a.skip_org, a.dst_org = N.ptr(y_org), N.ptr(skip_org), N.ptr(dst_org)
+    a.B, a.C1, a.C2 = y.shape[0], y.shape[1], (0 if skip is None else skip.shape[1])
+    a.sh, a.sw = y.shape[2], y.shape[3]
+    a.kh, a.kw = (0, 0) if skip is None else (skip.shape[2], skip.shape[3])
+    a.hc, a.wc = size
+    a.H, a.W = frame
+    a.up, a.elu = int(up), int(elu)
+    return a
+
+
+def _roi_glue_fwd(a, device):
+    out = torch.empty((a.B, a.C1 + a.C2, a.hc + 2, a.wc + 2), device=device, dtype=torch.float32)
+    N.check(_timed("roi_glue_fwd", lambda: N.lib().dmh_roi_glue_fwd(C.byref(a), N.ptr(out), N.stream()), 8 * out.numel()))
+    return out
+
+
+def _roi_glue_bwd(a, g_out, device, want_skip):
+    g_y = torch.empty((a.B, a.C1, a.sh, a.sw), device=device, dtype=torch.float32)
+    g_skip = torch.empty((a.B, a.C2, a.kh, a.kw), device=device, dtype=torch.float32) if want_skip else None
+    nb = 4 * (g_out.numel() + 2 * g_y.numel() + (0 if g_skip is None else g_skip.numel()))
+    N.check(_timed("roi_glue_bwd", lambda: N.lib().dmh_roi_glue_bwd(C.byref(a), N.ptr(g_out), N.ptr(g_y), N.ptr(g_skip),
+                                                                   N.stream()), nb))
+    return g_y, g_skip
+
+
+class _RoiTail(torch.autograd.Function):
+    """mean((disp0 * mask)^2) from upconv(2,1)'s output and feature 0, through upconv(1,0) ... dispconv(0)
+    (MD2/networks/depth_decoder.py:51-63) evaluated on one window per scene.  Hand-written backward (parameters are
+    constants: inside ops.frozen_weights() only): gradients w.r.t. z21 and feat0, whole planes, zero outside the windows'
+    reach."""
+
+    @staticmethod
+    def forward(ctx, z21, feat0, mask, plan, tab, w10, b10, w11, b11, w00, b00, w01, b01, wd, bd):
+        lib = N.lib()
+        dev = z21.device
+        B, _, H2, W2 = z21.shape
+        f2, f1, f0 = (H2, W2), (2 * H2, 2 * W2), (4 * H2, 4 * W2)
+        if tuple(feat0.shape[2:]) != f1 or tuple(mask.shape) != (B, 1) + f0 or plan.B != B or (plan.H, plan.W) != f0:
+            raise RuntimeError("roi tail: feature / mask / plan shapes do not match")
+        org = {n: tab[k] for k, n in enumerate(("d", "z01", "y00", "z11", "y10"))}
+        sz = plan.size
+        a10 = _roi_glue_args(z21, None, None, None, org["y10"], sz["y10"], f2, 0, 1)
+        y10 = _conv_any(_roi_glue_fwd(a10, dev), w10, b10, 0)
+        a11 = _roi_glue_args(y10, org["y10"], feat0, None, org["z11"], sz["z11"], f1, 1, 1)
+        z11 = _conv_any(_roi_glue_fwd(a11, dev), w11, b11, 0)
+        a00 = _roi_glue_args(z11, org["z11"], None, None, org["y00"], sz["y00"], f1, 0, 1)
+        y00 = _conv_any(_roi_glue_fwd(a00, dev), w00, b00, 0)
+        a01 = _roi_glue_args(y00, org["y00"], None, None, org["z01"], sz["z01"], f0, 1, 1)
+        z01 = _conv_any(_roi_glue_fwd(a01, dev), w01, b01, 0)
+        ad = _roi_glue_args(z01, org["z01"], None, None, org["d"], sz["d"], f0, 0, 1)
+        d_pre = _conv_any(_roi_glue_fwd(ad, dev), wd, bd, 0)
+        hd, wd_ = sz["d"]
+        sig = torch.empty_like(d_pre)
+        part = torch.empty(lib.dmh_roi_cost_partials_size(B, hd, wd_), device=dev, dtype=torch.float32)
+        cost = torch.empty((), device=dev, dtype=torch.float32)
+        N.check(lib.dmh_roi_cost_fwd(N.ptr(d_pre), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, f0[0], f0[1], N.ptr(sig),
+                                     N.ptr(part), N.ptr(cost), N.stream()))
+        ctx.save_for_backward(z21, feat0, mask, tab, y10, z11, y00, z01, sig, w10, w11, w00, w01, wd)
+        ctx.plan = plan
+        return cost
+
+    @staticmethod
+    def backward(ctx, g):
+        z21, feat0, mask, tab, y10, z11, y00, z01, sig, w10, w11, w00, w01, wd = ctx.saved_tensors
+        plan = ctx.plan
+        lib = N.lib()
+        dev = z21.device
+        B, _, H2, W2 = z21.shape
+        f2, f1, f0 = (H2, W2), (2 * H2, 2 * W2), (4 * H2, 4 * W2)
+        org = {n: tab[k] for k, n in enumerate(("d", "z01", "y00", "z11", "y10"))}
+        sz = plan.size
+        hd, wd_ = sz["d"]
+        g_pre = torch.empty_like(sig)
+        N.check(lib.dmh_roi_cost_bwd(N.ptr(sig), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, f0[0], f0[1],
+                                     N.ptr(_c(g.to(torch.float32))), N.ptr(g_pre), N.stream()))
+        ad = _roi_glue_args(z01, org["z01"], None, None, org["d"], sz["d"], f0, 0, 1)
+        g_z01, _ = _roi_glue_bwd(ad, _conv_any(g_pre, wd, None, 2, True), dev, False)
+        a01 = _roi_glue_args(y00, org["y00"], None, None, org["z01"], sz["z01"], f0, 1, 1)
+        g_y00, _ = _roi_glue_bwd(a01, _conv_any(g_z01, w01, None, 2, True), dev, False)
+        a00 = _roi_glue_args(z11, org["z11"], None, None, org["y00"], sz["y00"], f1, 0, 1)
+        g_z11, _ = _roi_glue_bwd(a00, _conv_any(g_y00, w00, None, 2, True), dev, False)
+        a11 = _roi_glue_args(y10, org["y10"], feat0, None, org["z11"], sz["z11"], f1, 1, 1)
+        g_y10, g_feat0 = _roi_glue_bwd(a11, _conv_any(g_z11, w11, None, 2, True), dev, ctx.needs_input_grad[1])
+        a10 = _roi_glue_args(z21, None, None, None, org["y10"], sz["y10"], f2, 0, 1)
+        g_z21, _ = _roi_glue_bwd(a10, _conv_any(g_y10, w10, None, 2, True), dev, False)
+        return (g_z21, g_feat0) + (None,) * 13
+
+
+def roi_tail_ok(z21, feat0, convs):
+    """The cropped tail applies: inside frozen_weights() (its backward has no parameter gradients), fp32 CUDA tensors, the
+    reference decoder's channel plan (64 -> 32 -> [+64] 32 -> 16 -> 16 -> 1)."""
+    shapes = [tuple(c.weight.shape) for c in convs]
+    return (ROI_ENABLED and _wino_frozen > 0 and z21.is_cuda and z21.dtype == torch.float32 and feat0.dtype == torch.float32
+            and shapes == [(32, 64, 3, 3), (32, 96, 3, 3), (16, 32, 3, 3), (16, 16, 3, 3), (1, 16, 3, 3)]
+            and feat0.shape[1] == 64 and z21.shape[2] % 2 == 0 and z21.shape[3] % 2 == 0)
+
+
+def roi_tail_cost(z21, feat0, mask, plan, tab, convs):
+    """mean((sigmoid(dispconv0(...)) * mask)^2) of the decoder tail on the windows of ``plan`` (roi.RoiPlan; ``tab`` is
+    its origin table on the device, int32 [5, B, 2]).  ``convs``: the five nn.Conv2d modules upconv(1,0), upconv(1,1),
+    upconv(0,0), upconv(0,1), dispconv(0).  Equals ops.masked_sq_mean(decoder(...)[("disp", 0)], mask) when the mask is
+    zero outside the plan's boxes."""
+    if not roi_tail_ok(z21, feat0, convs):
+        raise RuntimeError("roi_tail_cost: needs ops.frozen_weights(), fp32 CUDA tensors and the Monodepth2 decoder tail")
+    if tab.dtype != torch.int32 or tuple(tab.shape) != (5, z21.shape[0], 2):
+        raise RuntimeError("roi_tail_cost: origin table must be int32 [5, B, 2]")
+    wb = []
+    for c in convs:
+        wb += [c.weight.detach(), None if c.bias is None else _c(c.bias.detach())]
+    return _RoiTail.apply(_c(z21), _c(feat0), _c(mask), plan, _c(tab), *wb)
+
+
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,
                         clamp_hi=80.0):
     """The eight attack-evaluation metrics of MD2/evaluate_depth.py:57-99 computed from two disparity maps in one

@@ -161,6 +161,22 @@ class PhysicalTrans(object):
             out[i] = c
         return out
 
+    def mask_boxes(self, z0_sample, alpha_sample, out_size):
+        """int [N, 4] = (y0, y1, x0, x1), half-open, in the Resize'd ``out_size`` frame: per sample a box that contains
+        every pixel the pasted object can touch -- the support of ``obj_masks_out`` of phy_obj_atk.py:87-90 -- from the
+        integer quad of objPosOnImage (roi.mask_box).  The attack evaluates its cost inside these boxes only."""
+        from .roi import mask_box
+        memo = self.__dict__.setdefault("_box_memo", {})
+        out = np.zeros((len(z0_sample), 4), dtype=np.int64)
+        for i in range(len(z0_sample)):
+            key = (float(z0_sample[i]), float(alpha_sample[i]), int(out_size[0]), int(out_size[1]))
+            b = memo.get(key)
+            if b is None:
+                b = memo[key] = mask_box(self.objPosOnImage(z0_sample[i], alpha_sample[i]),
+                                         (self.output_size[2], self.output_size[3]), out_size)
+            out[i] = b
+        return out
+
     def _warp(self, coeffs_np):
         dev = self.obj_img.device
         coeffs = torch.from_numpy(np.ascontiguousarray(coeffs_np)).to(dev)

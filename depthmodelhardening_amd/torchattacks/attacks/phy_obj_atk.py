@@ -19,6 +19,7 @@ import torch
 from ... import ops
 from ...my_utils import object_dataset_root, ori_H, ori_W, to_device_async
 from ...physicalTrans import PhysicalTrans
+from ...roi import RoiPlan
 from ..attack import Attack
 
 
@@ -53,6 +54,7 @@ class Phy_obj_atk(Attack):
         # of g consecutive scenes gets its own draw without replacement (physical_adv_training at batch 32: 13 + 13 + 6).
         # None = the reference's behaviour.
         self.pose_group = None
+        self.use_roi = True     # evaluate the cost on windows around the object when the model offers masked_sq_mean
         conf = {'path': f'{object_dataset_root}/training/calib/003086.txt'}
         self.phy_trans_adv = PhysicalTrans(self.obj_img.clone(), self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
@@ -105,12 +107,22 @@ class Phy_obj_atk(Attack):
         l_pad, t_pad = pt.l_pad, pt.t_pad
         mask = self.obj_mask.to(self.device)
 
+        # the cost reads the disparity under the object only: a model that can evaluate mean((disp * mask)^2) on windows
+        # around the object (DepthModelWrapper.masked_sq_mean: exact) gets the per-step boxes, all tables in one H2D copy
+        plans = tabs = None
+        if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
+            plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size) for z0, al in draws]
+            tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
+
         for s in range(self.steps):
             obj_img_adv.requires_grad_()
             adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[s], l_pad, t_pad,
                                                       self.scene_size)
-            adv_depth = self.model(adv_scenes)
-            cost = -ops.masked_sq_mean(adv_depth, obj_masks_out)  # -MSE(adv_depth * mask, 0)
+            if plans is not None:
+                cost = -self.model.masked_sq_mean(adv_scenes, obj_masks_out, plans[s], tabs[s])
+            else:
+                adv_depth = self.model(adv_scenes)
+                cost = -ops.masked_sq_mean(adv_depth, obj_masks_out)  # -MSE(adv_depth * mask, 0)
             grad = torch.autograd.grad(cost, obj_img_adv, retain_graph=False, create_graph=False)[0]
             obj_img_adv = ops.pgd_linf_step(obj_img_adv, self.obj_img, grad, self.alpha, self.eps)
 

@@ -254,6 +254,45 @@ int dmh_elu_pad_bwd(const float* z, const float* g_out, int B, int C, int H, int
                     void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K19 windowed decoder glue + windowed attack cost: the attack evaluated only where its loss lives.
+ *     cost = -mean((disp * mask)^2) (torchattacks/attacks/phy_obj_atk.py:88-97, phy_obj_atk_l0.py:118-134) reads the
+ *     disparity under the pasted object only, so inside an attack the high-resolution tail of the decoder
+ *     (MD2/networks/depth_decoder.py:51-63, upconv(1,0) ... dispconv(0)) runs -- exactly -- on one window per sample
+ *     around the object's bounding box: the convolution kernels take compact [B,C,hc+2,wc+2] windows with padding 0,
+ *     and this is the pass between them:
+ *       out[b, :, i, j] = pad1_reflect(cat(up2_nearest(ELU(y)), skip))  at frame position dst_org[b] + (i, j) - 1
+ *     for 0 <= i < hc + 2, 0 <= j < wc + 2: decoder_glue's up_cat_pad / elu_pad restricted to a window of the H x W
+ *     destination frame (the reflection is the FRAME's).  y [B,C1,sh,sw] and skip [B,C2,kh,kw] are windows of their own
+ *     frames with per-sample origins y_org / skip_org ([B,2] int32: row, column), or whole frames (origin table NULL).
+ *     up: y lives at half the destination resolution; elu: ELU is applied to y.  wc must be even.
+ *     Every read must fall inside the source windows (the caller's window plan guarantees it; indices are clamped).
+ *   bwd: g_y / g_skip over the WHOLE source planes (0 where no window entry reads the element); g_skip may be NULL.
+ *   roi_cost: cost = sum over the windows of (sigmoid(d_pre) * mask)^2 / (B H W); d_pre [B,1,hd,wd] is the disparity
+ *     head's output on the window at org[b] of the H x W frame, mask [B,1,H,W] the full-frame K3 mask; sig receives the
+ *     sigmoid.  bwd: g_pre = gscale[0] * 2 sig mask^2 / (B H W) * sig (1 - sig).
+ * ---------------------------------------------------------------------------------- */
+typedef struct dmh_roi_glue_args {
+    const float* y;
+    const float* skip;      /* NULL when C2 == 0 */
+    const int* y_org;       /* [B,2] or NULL (y is the whole frame) */
+    const int* skip_org;    /* [B,2] or NULL */
+    const int* dst_org;     /* [B,2] window origin in the destination frame (unpadded coordinates) */
+    int B, C1, C2;
+    int sh, sw;             /* plane size of y */
+    int kh, kw;             /* plane size of skip */
+    int hc, wc;             /* destination window (unpadded); out is [B, C1 + C2, hc + 2, wc + 2] */
+    int H, W;               /* destination frame (unpadded) */
+    int up, elu;
+} dmh_roi_glue_args;
+int dmh_roi_glue_fwd(const dmh_roi_glue_args* a, float* out, void* stream);
+int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y, float* g_skip, void* stream);
+int64_t dmh_roi_cost_partials_size(int B, int hd, int wd);
+int dmh_roi_cost_fwd(const float* d_pre, const float* mask, const int* org, int B, int hd, int wd, int H, int W, float* sig,
+                     float* partials, float* cost, void* stream);
+int dmh_roi_cost_bwd(const float* sig, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
+                     const float* gscale, float* g_pre, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K9  encoder glue: the element-wise passes between the MIOpen convolutions of the ResNet encoder while the model
  *     is in eval() mode (every attack step: torchattacks/attack.py:165-182 brackets the attack with model.eval()).
  *     Replaces, in MD2/networks/resnet_encoder.py:85-98 / torchvision BasicBlock.forward, the chains
