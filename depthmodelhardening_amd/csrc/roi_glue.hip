@@ -81,19 +81,31 @@ __device__ __forceinline__ float gather_pad(const float* __restrict__ gp, int Y,
     return acc;
 }
 
-// grid.y = B*C1 planes of g_y followed by B*C2 planes of g_skip; one thread per source element (whole source planes
-// are written: 0 where no window entry reads the element)
-__global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_args a, const float* __restrict__ g_out,
-                                                          float* __restrict__ g_y, float* __restrict__ g_skip) {
+// grid.y = B*C1 planes of g_y followed by B*C2 planes of g_skip; one thread per source element of the REGION to write: the
+// whole plane (0 where no window entry reads the element), or -- for a whole-frame source -- a per-sample rectangle that
+// holds everything the window reaches (the caller owns the rest of the plane: pre-zeroed, or never read)
+struct Region {
+    const int* y_org;       // [B,2] or NULL: whole plane
+    const int* skip_org;
+    int yh, yw, kh, kw;     // rectangle sizes (plane sizes when the table is NULL)
+};
+
+__global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_args a, const Region rg,
+                                                          const float* __restrict__ g_out, float* __restrict__ g_y,
+                                                          float* __restrict__ g_skip) {
     const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
     const int t = blockIdx.x * NT + threadIdx.x;
     const int plane = blockIdx.y;
     if (plane < a.B * a.C1) {
-        if (t >= a.sh * a.sw) return;
+        if (t >= rg.yh * rg.yw) return;
         const int b = plane / a.C1, c = plane - b * a.C1;
         const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
         const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
-        const int yy = t / a.sw, xx = t - yy * a.sw;
+        int yy = t / rg.yw, xx = t - yy * rg.yw;
+        if (rg.y_org) {
+            yy += rg.y_org[2 * b];
+            xx += rg.y_org[2 * b + 1];
+        }
         const int Ys = sy0 + yy, Xs = sx0 + xx;
         const float* gp = g_out + (size_t)(b * C + c) * PH * PW;
         float acc;
@@ -110,16 +122,20 @@ __global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_arg
         } else {
             acc = gather_pad(gp, Ys, Xs, a.H, a.W, oy, ox, PH, PW);
         }
-        const size_t o = (size_t)plane * a.sh * a.sw + t;
+        const size_t o = ((size_t)plane * a.sh + yy) * a.sw + xx;
         g_y[o] = (a.elu && acc != 0.f) ? acc * elu_grad(a.y[o]) : acc;
     } else {
-        if (t >= a.kh * a.kw) return;
+        if (t >= rg.kh * rg.kw) return;
         const int q = plane - a.B * a.C1, b = q / a.C2, c = q - b * a.C2;
         const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
         const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
-        const int yy = t / a.kw, xx = t - yy * a.kw;
+        int yy = t / rg.kw, xx = t - yy * rg.kw;
+        if (rg.skip_org) {
+            yy += rg.skip_org[2 * b];
+            xx += rg.skip_org[2 * b + 1];
+        }
         const float* gp = g_out + (size_t)(b * C + a.C1 + c) * PH * PW;
-        g_skip[(size_t)q * a.kh * a.kw + t] = gather_pad(gp, ky0 + yy, kx0 + xx, a.H, a.W, oy, ox, PH, PW);
+        g_skip[((size_t)q * a.kh + yy) * a.kw + xx] = gather_pad(gp, ky0 + yy, kx0 + xx, a.H, a.W, oy, ox, PH, PW);
     }
 }
 
@@ -199,14 +215,26 @@ int dmh_roi_glue_fwd(const dmh_roi_glue_args* a, float* out, void* stream) {
     return check_launch("dmh_roi_glue_fwd");
 }
 
-int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y, float* g_skip, void* stream) {
+int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y, float* g_skip, const int* y_reg_org,
+                     int y_reg_h, int y_reg_w, const int* skip_reg_org, int skip_reg_h, int skip_reg_w, void* stream) {
     if (int rc = check_glue(a)) return rc;
     DMH_REQUIRE(g_out && g_y, "null pointer");
-    const int planes = a->B * a->C1 + (g_skip ? a->B * a->C2 : 0);
-    const int64_t per_plane = (g_skip && a->C2 > 0 && (int64_t)a->kh * a->kw > (int64_t)a->sh * a->sw) ? (int64_t)a->kh * a->kw
-                                                                                                       : (int64_t)a->sh * a->sw;
-    hipLaunchKernelGGL(roi_glue_bwd_kernel, dim3(blocks_for(per_plane), planes), dim3(NT), 0, (hipStream_t)stream, *a, g_out,
-                       g_y, g_skip);
+    DMH_REQUIRE(!y_reg_org || (!a->y_org && y_reg_h >= 1 && y_reg_w >= 1 && y_reg_h <= a->sh && y_reg_w <= a->sw),
+                "a y region needs a whole-frame y and must fit its plane");
+    DMH_REQUIRE(!skip_reg_org || (!a->skip_org && skip_reg_h >= 1 && skip_reg_w >= 1 && skip_reg_h <= a->kh && skip_reg_w <= a->kw),
+                "a skip region needs a whole-frame skip and must fit its plane");
+    Region rg;
+    rg.y_org = y_reg_org;
+    rg.skip_org = skip_reg_org;
+    rg.yh = y_reg_org ? y_reg_h : a->sh;
+    rg.yw = y_reg_org ? y_reg_w : a->sw;
+    rg.kh = skip_reg_org ? skip_reg_h : a->kh;
+    rg.kw = skip_reg_org ? skip_reg_w : a->kw;
+    const bool skip = g_skip && a->C2 > 0;
+    const int planes = a->B * a->C1 + (skip ? a->B * a->C2 : 0);
+    const int64_t ny = (int64_t)rg.yh * rg.yw, nk = skip ? (int64_t)rg.kh * rg.kw : 0;
+    hipLaunchKernelGGL(roi_glue_bwd_kernel, dim3(blocks_for(ny > nk ? ny : nk), planes), dim3(NT), 0, (hipStream_t)stream, *a,
+                       rg, g_out, g_y, g_skip);
     return check_launch("dmh_roi_glue_bwd");
 }
 

@@ -21,9 +21,20 @@ constexpr int BY = 8, BX = 32;              // 2x2 blocks per workgroup: 16 x 64
 constexpr int KC = 8;                       // gradient channels per LDS stage
 constexpr int RH = BY + 3, RW = BX + 3;     // g_y region: rows Y0-1 .. Y0+BY+1, cols X0-1 .. X0+BX+1
 
+// Window form (K19, the attack's patch gradient: only the image gradient under the pasted object is read): the workgroups
+// cover the wh x ww block window (2x2-pixel blocks = pixels of g_y's frame) at the per-sample, even image-pixel origin win_org, and
+// g_y is a compact [B, K, sh, sw] window of its Ho x Wo frame at per-sample origin gy_org -- it must hold everything the
+// image window reads (rows / columns -1 .. +2 around it); outside the frame g_y is zero as before.
+struct StemWin {
+    const int* win_org;     // [B,2] image pixels (even), or NULL: the whole image
+    const int* gy_org;      // [B,2] origin of the compact g_y window (NULL: g_y is the whole frame)
+    int wh, ww;             // window size in blocks
+    int sh, sw;             // plane size of g_y
+};
+
 template <int CIN>
 __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ w,
-                                                           int K, int Ho, int Wo, int gx, int gyb,
+                                                           int K, int Ho, int Wo, int gx, int gyb, const StemWin sw_,
                                                            float* __restrict__ gxo) {
     __shared__ float tile[KC * RH * RW];
     const int tid = threadIdx.x;
@@ -31,9 +42,12 @@ __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restri
     const int bxi = bid % gx;  bid /= gx;
     const int byi = bid % gyb;
     const int b = bid / gyb;
-    const int Y0 = byi * BY, X0 = bxi * BX;
+    const int wy0 = sw_.win_org ? sw_.win_org[2 * b] >> 1 : 0, wx0 = sw_.win_org ? sw_.win_org[2 * b + 1] >> 1 : 0;
+    const int gy0 = sw_.gy_org ? sw_.gy_org[2 * b] : 0, gx0 = sw_.gy_org ? sw_.gy_org[2 * b + 1] : 0;
+    const int Y0 = wy0 + byi * BY, X0 = wx0 + bxi * BX;
+    const int Yend = wy0 + sw_.wh, Xend = wx0 + sw_.ww;
     const int ty = tid / BX, tx = tid - ty * BX;
-    const size_t HWo = (size_t)Ho * Wo;
+    const size_t HWo = (size_t)sw_.sh * sw_.sw;
     const float* gb = gy + (size_t)b * K * HWo;
 
     float acc[2][2][CIN];
@@ -51,9 +65,10 @@ __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restri
         for (int i = 0; i < PER_T; ++i) {
             const int e = tid + NT * i;
             const int kk = e / (RH * RW), rem = e - kk * (RH * RW), r = rem / RW, xx = rem - r * RW;
-            const int oy = Y0 - 1 + r, ox = X0 - 1 + xx;
-            const bool ok = e < KC * RH * RW && oy >= 0 && oy < Ho && ox >= 0 && ox < Wo;
-            const float v = gb[(size_t)(k0 + (ok ? kk : 0)) * HWo + (size_t)min(max(oy, 0), Ho - 1) * Wo + min(max(ox, 0), Wo - 1)];
+            const int oy = Y0 - 1 + r - gy0, ox = X0 - 1 + xx - gx0;       // inside the (compact) g_y plane
+            const bool ok = e < KC * RH * RW && oy >= 0 && oy < sw_.sh && ox >= 0 && ox < sw_.sw;
+            const float v = gb[(size_t)(k0 + (ok ? kk : 0)) * HWo + (size_t)min(max(oy, 0), sw_.sh - 1) * sw_.sw +
+                               min(max(ox, 0), sw_.sw - 1)];
             stage[i] = ok ? v : 0.f;
         }
         __syncthreads();                    // the previous stage has been consumed
@@ -92,7 +107,7 @@ __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restri
         }
     }
     const int Y = Y0 + ty, X = X0 + tx;
-    if (Y < Ho && X < Wo) {
+    if (Y < Yend && X < Xend) {
         const int H = 2 * Ho, W = 2 * Wo;
 #pragma unroll
         for (int c = 0; c < CIN; ++c) {
@@ -107,6 +122,23 @@ __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restri
 
 extern "C" {
 
+static int launch_stem_bwd(const float* g_y, const float* w, int B, int K, int Cin, int H, int W, const StemWin& sw_,
+                           float* g_x, void* stream, const char* fn) {
+    const int Ho = H / 2, Wo = W / 2;
+    const int gx = (sw_.ww + BX - 1) / BX, gyb = (sw_.wh + BY - 1) / BY;
+    const long long blocks = (long long)B * gx * gyb;
+    if (blocks >= (1ll << 31)) return fail(DMH_EINVAL, "%s: grid too large", fn);
+    hipStream_t st = (hipStream_t)stream;
+#define DMH_LAUNCH(CIN) \
+    hipLaunchKernelGGL(stem_conv_bwd_kernel<CIN>, dim3((unsigned)blocks), dim3(NT), 0, st, g_y, w, K, Ho, Wo, gx, gyb, sw_, g_x)
+    if (Cin == 1) DMH_LAUNCH(1);
+    else if (Cin == 2) DMH_LAUNCH(2);
+    else if (Cin == 3) DMH_LAUNCH(3);
+    else DMH_LAUNCH(4);
+#undef DMH_LAUNCH
+    return check_launch(fn);
+}
+
 int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int Cin, int H, int W, float* g_x,
                            void* stream) {
     DMH_REQUIRE(g_y && w && g_x, "null pointer");
@@ -115,18 +147,24 @@ int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int C
     DMH_REQUIRE(H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "image height and width must be even");
     const int Ho = H / 2, Wo = W / 2;
     DMH_REQUIRE((int64_t)K * Ho * Wo < ((int64_t)1 << 31), "image too large");
-    const int gx = (Wo + BX - 1) / BX, gyb = (Ho + BY - 1) / BY;
-    const long long blocks = (long long)B * gx * gyb;
-    DMH_REQUIRE(blocks < (1ll << 31), "grid too large");
-    hipStream_t st = (hipStream_t)stream;
-#define DMH_LAUNCH(CIN) \
-    hipLaunchKernelGGL(stem_conv_bwd_kernel<CIN>, dim3((unsigned)blocks), dim3(NT), 0, st, g_y, w, K, Ho, Wo, gx, gyb, g_x)
-    if (Cin == 1) DMH_LAUNCH(1);
-    else if (Cin == 2) DMH_LAUNCH(2);
-    else if (Cin == 3) DMH_LAUNCH(3);
-    else DMH_LAUNCH(4);
-#undef DMH_LAUNCH
-    return check_launch("dmh_conv7x7s2_bwd_data");
+    StemWin sw_;
+    sw_.win_org = nullptr; sw_.gy_org = nullptr; sw_.wh = Ho; sw_.ww = Wo; sw_.sh = Ho; sw_.sw = Wo;
+    return launch_stem_bwd(g_y, w, B, K, Cin, H, W, sw_, g_x, stream, "dmh_conv7x7s2_bwd_data");
+}
+
+int dmh_conv7x7s2_bwd_data_win(const float* g_y, const float* w, const int* img_org, const int* gy_org, int B, int K, int Cin,
+                               int H, int W, int hwin, int wwin, int sh, int sw, float* g_x, void* stream) {
+    DMH_REQUIRE(g_y && w && g_x && img_org && gy_org, "null pointer");
+    DMH_REQUIRE(B > 0 && K > 0 && K % KC == 0, "gradient channel count must be a multiple of 8");
+    DMH_REQUIRE(Cin >= 1 && Cin <= 4, "1 to 4 image channels");
+    DMH_REQUIRE(H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "image height and width must be even");
+    DMH_REQUIRE(hwin >= 2 && wwin >= 2 && (hwin & 1) == 0 && (wwin & 1) == 0 && hwin <= H && wwin <= W,
+                "the image window must be even-sized and inside the image");
+    DMH_REQUIRE(sh >= 1 && sw >= 1 && sh <= H / 2 && sw <= W / 2 && (int64_t)K * sh * sw < ((int64_t)1 << 31),
+                "the g_y window must lie inside its frame");
+    StemWin sw_;
+    sw_.win_org = img_org; sw_.gy_org = gy_org; sw_.wh = hwin / 2; sw_.ww = wwin / 2; sw_.sh = sh; sw_.sw = sw;
+    return launch_stem_bwd(g_y, w, B, K, Cin, H, W, sw_, g_x, stream, "dmh_conv7x7s2_bwd_data_win");
 }
 
 }  // extern "C"

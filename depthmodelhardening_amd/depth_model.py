@@ -27,9 +27,15 @@ class DepthModelWrapper(torch.nn.Module):
         phy_obj_atk_l0.py:125-127).  With a window plan (roi.RoiPlan + its device table) around the pasted object, and a
         decoder that supports it, the decoder's high-resolution tail runs on the windows only."""
         from . import ops
-        feats = self.encoder(input_image)
-        if plan is not None and hasattr(self.decoder, "roi_ok") and self.decoder.roi_ok(feats):
+        roi_dec = plan is not None and hasattr(self.decoder, "roi_ok")
+        if roi_dec and getattr(self.encoder, "roi_backward", False):
+            feats = self.encoder(input_image, roi=(plan, tab))
+        else:
+            feats = self.encoder(input_image)
+        if roi_dec and self.decoder.roi_ok(feats):
             return self.decoder.masked_sq_mean(feats, mask, plan, tab)
+        if plan is not None and getattr(plan, "head_windowed", False):
+            raise RuntimeError("masked_sq_mean: the encoder ran its windowed head but the decoder cannot take the plan")
         if feats[-1].is_cuda and hasattr(self.decoder, "_forward_fused"):
             disp = self.decoder(feats, only_scales=(0,))[("disp", 0)]
         else:

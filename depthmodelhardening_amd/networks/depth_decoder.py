@@ -67,21 +67,22 @@ class DepthDecoder(nn.Module):
         if not (input_features[-1].is_cuda and self.use_skips and self.upsample_mode == 'nearest' and 0 in self.scales
                 and len(input_features) == 5 and self.num_output_channels == 1):
             return False
-        f0 = input_features[0]
-        z_shape = (f0.shape[2] // 2, f0.shape[3] // 2)
-        return (f0.shape[2] % 4 == 0 and f0.shape[3] % 4 == 0 and z_shape[0] >= 4 and z_shape[1] >= 4
-                and ops.roi_tail_ok(f0.new_empty((1, 64) + z_shape), f0, self._tail_convs()))
+        f0, f1, f2 = input_features[:3]
+        return (f0.shape[2] % 4 == 0 and f0.shape[3] % 4 == 0 and tuple(f1.shape[2:]) == (f0.shape[2] // 2, f0.shape[3] // 2)
+                and tuple(f2.shape[2:]) == (f0.shape[2] // 4, f0.shape[3] // 4) and f2.shape[2] >= 2 and f2.shape[3] >= 2
+                and ops.roi_tail_ok(f1, f1, f0, self._tail_convs()))
 
     def _tail_convs(self):
         c = self.convs
-        return [c[("upconv", 1, 0)].conv.conv, c[("upconv", 1, 1)].conv.conv, c[("upconv", 0, 0)].conv.conv,
-                c[("upconv", 0, 1)].conv.conv, c[("dispconv", 0)].conv]
+        return [c[("upconv", 2, 1)].conv.conv, c[("upconv", 1, 0)].conv.conv, c[("upconv", 1, 1)].conv.conv,
+                c[("upconv", 0, 0)].conv.conv, c[("upconv", 0, 1)].conv.conv, c[("dispconv", 0)].conv]
 
     def masked_sq_mean(self, input_features, mask, plan, tab):
         """mean((disp_0 * mask)^2) -- the attack's cost (phy_obj_atk.py:92-94) -- with the decoder's high-resolution tail
-        evaluated on the windows of ``plan`` only (roi.RoiPlan around the pasted object, where the mask lives): stages 4, 3
-        and 2 run on the whole maps, upconv(1,0) ... dispconv(0) inside the windows.  Exact, not an approximation: the
-        mask is zero outside the plan's boxes, so nothing outside the windows' receptive field reaches the cost."""
+        evaluated on the windows of ``plan`` only (roi.RoiPlan around the pasted object, where the mask lives): stages 4
+        and 3 and upconv(2,0) run on the whole maps, upconv(2,1) ... dispconv(0) inside the windows.  Exact, not an
+        approximation: the mask is zero outside the plan's boxes, so nothing outside the windows' receptive field reaches
+        the cost."""
         from .. import ops
 
         def conv(block, t):
@@ -89,14 +90,12 @@ class DepthDecoder(nn.Module):
             return ops.conv3x3(t, c.weight, c.bias, 0)
 
         p = ops.elu_pad(input_features[-1], apply_elu=False)
-        z = None
-        for i in range(4, 1, -1):
+        for i in (4, 3):
             y = conv(self.convs[("upconv", i, 0)].conv, p)
             p = ops.up_cat_pad(y, input_features[i - 1])
-            z = conv(self.convs[("upconv", i, 1)].conv, p)
-            if i > 2:
-                p = ops.elu_pad(z)
-        return ops.roi_tail_cost(z, input_features[0], mask, plan, tab, self._tail_convs())
+            p = ops.elu_pad(conv(self.convs[("upconv", i, 1)].conv, p))
+        y20 = conv(self.convs[("upconv", 2, 0)].conv, p)
+        return ops.roi_tail_cost(y20, input_features[1], input_features[0], mask, plan, tab, self._tail_convs())
 
     def _forward_reference(self, input_features):
         self.outputs = {}

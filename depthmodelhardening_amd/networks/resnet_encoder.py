@@ -231,6 +231,7 @@ class ResnetEncoder(nn.Module):
         self.num_ch_enc = np.array([64, 64, 128, 256, 512])
         block, layers = _CONFIGS[num_layers]
         self.encoder = ResNet(block, layers, num_input_images)
+        self.roi_backward = True    # forward(x, roi=...) may run the head's backward on the attack's windows (ops.encoder_head_eval)
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
@@ -245,10 +246,12 @@ class ResnetEncoder(nn.Module):
             return ops.stem_conv_norm(input_image, c.weight, 0.45, 0.225)
         return self._conv1((input_image - 0.45) / 0.225)
 
-    def forward(self, input_image):
+    def forward(self, input_image, roi=None):
+        """``roi`` = (roi.RoiPlan, its device table): the caller (an object attack, DepthModelWrapper.masked_sq_mean) reads
+        d / d input_image inside the plan's image window only, so the head's backward may run on the plan's windows."""
         e = self.encoder
         if e.fused_eval_ok(input_image):
-            self.features = self._forward_fused_eval(input_image)
+            self.features = self._forward_fused_eval(input_image, roi)
             return self.features
         z = self._stem(input_image)
         if _train_fused(e.bn1, z) and z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
@@ -270,17 +273,37 @@ class ResnetEncoder(nn.Module):
             return ops.stem_conv(x, c.weight)
         return c(x)
 
-    def _forward_fused_eval(self, input_image):
+    def _head_blocks(self, aff):
+        """layer1 as the argument list of ops.encoder_head_eval, or None when it is not two plain stride-1 BasicBlocks."""
+        l1 = self.encoder.layer1
+        if len(l1) != 2 or not all(isinstance(b, BasicBlock) and b.downsample is None and _plain3x3(b.conv1)
+                                   and _plain3x3(b.conv2) for b in l1):
+            return None
+        return [(b.conv1.weight, aff[b.bn1], b.conv2.weight, aff[b.bn2]) for b in l1]
+
+    def _forward_fused_eval(self, input_image, roi=None):
         e = self.encoder
         aff = e.eval_affine()
-        z = self._stem(input_image)
-        if z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
-            f0, y = ops.stem_bn_relu_pool(z, *aff[e.bn1])
-        else:
-            f0 = ops.bn_act(z, *aff[e.bn1])
-            y = e.maxpool(f0)
-        feats = [f0]
-        for li, layer in enumerate((e.layer1, e.layer2, e.layer3, e.layer4)):
+        layers = (e.layer1, e.layer2, e.layer3, e.layer4)
+        feats = None
+        if roi is not None:
+            blocks = self._head_blocks(aff)
+            c = e.conv1
+            if (blocks is not None and c.stride == (2, 2) and c.padding == (3, 3) and c.dilation == (1, 1) and c.groups == 1
+                    and c.bias is None and ops.encoder_head_ok(input_image, c.weight, [(b[0], b[2]) for b in blocks])):
+                # the attack's encoder head: one node, backward on the plan's windows (K19)
+                f0, y = ops.encoder_head_eval(input_image, roi[0], roi[1], c.weight, aff[e.bn1], blocks)
+                feats, layers = [f0, y], layers[1:]
+        if feats is None:
+            z = self._stem(input_image)
+            if z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
+                f0, y = ops.stem_bn_relu_pool(z, *aff[e.bn1])
+            else:
+                f0 = ops.bn_act(z, *aff[e.bn1])
+                y = e.maxpool(f0)
+            feats = [f0]
+        first = len(feats) - 1          # index (0: layer1, 1: layer2, ...) of the first layer still to run
+        for li, layer in enumerate(layers, start=first):
             for bi, blk in enumerate(layer):
                 if li > 0 and bi == 0 and hasattr(blk, "_is_down_pair"):
                     # y is the previous layer's output = a pyramid feature with two consumers (this block and the decoder)

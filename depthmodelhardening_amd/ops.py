@@ -1543,100 +1543,251 @@ def _roi_glue_fwd(a, device):
     return out
 
 
-def _roi_glue_bwd(a, g_out, device, want_skip):
-    g_y = torch.empty((a.B, a.C1, a.sh, a.sw), device=device, dtype=torch.float32)
-    g_skip = torch.empty((a.B, a.C2, a.kh, a.kw), device=device, dtype=torch.float32) if want_skip else None
-    nb = 4 * (g_out.numel() + 2 * g_y.numel() + (0 if g_skip is None else g_skip.numel()))
+def _roi_glue_bwd(a, g_out, device, want_skip, y_region=None, skip_region=None, skip_prezero=True):
+    """``y_region`` / ``skip_region`` = (org table [B,2], (rows, cols)): for a whole-frame source only that rectangle is
+    computed; the rest of g_y is zero-filled, and so is the rest of g_skip unless ``skip_prezero`` is False (its consumer
+    reads inside the rectangle only)."""
+    new = torch.zeros if y_region is not None else torch.empty
+    g_y = new((a.B, a.C1, a.sh, a.sw), device=device, dtype=torch.float32)
+    g_skip = None
+    if want_skip:
+        new = torch.zeros if (skip_region is not None and skip_prezero) else torch.empty
+        g_skip = new((a.B, a.C2, a.kh, a.kw), device=device, dtype=torch.float32)
+    yo, (yh, yw) = y_region if y_region is not None else (None, (0, 0))
+    ko, (kh, kw) = skip_region if (skip_region is not None and want_skip) else (None, (0, 0))
+    nb = 4 * (g_out.numel() + 2 * a.B * a.C1 * (yh * yw if yo is not None else a.sh * a.sw) +
+              (0 if g_skip is None else a.B * a.C2 * (kh * kw if ko is not None else a.kh * a.kw)))
     N.check(_timed("roi_glue_bwd", lambda: N.lib().dmh_roi_glue_bwd(C.byref(a), N.ptr(g_out), N.ptr(g_y), N.ptr(g_skip),
-                                                                   N.stream()), nb))
+                                                                   N.ptr(yo), yh, yw, N.ptr(ko), kh, kw, N.stream()), nb))
     return g_y, g_skip
 
 
+from .roi import TABLE as _ROI_NAMES     # noqa: E402  (row order of the device table of window origins)
+
+
 class _RoiTail(torch.autograd.Function):
-    """mean((disp0 * mask)^2) from upconv(2,1)'s output and feature 0, through upconv(1,0) ... dispconv(0)
+    """mean((disp0 * mask)^2) from upconv(2,0)'s output and features 1 and 0, through upconv(2,1) ... dispconv(0)
     (MD2/networks/depth_decoder.py:51-63) evaluated on one window per scene.  Hand-written backward (parameters are
-    constants: inside ops.frozen_weights() only): gradients w.r.t. z21 and feat0, whole planes, zero outside the windows'
-    reach."""
+    constants: inside ops.frozen_weights() only): gradients w.r.t. y20, feat1 and feat0, whole planes, zero outside the
+    windows' reach."""
 
     @staticmethod
-    def forward(ctx, z21, feat0, mask, plan, tab, w10, b10, w11, b11, w00, b00, w01, b01, wd, bd):
+    def _stages(y20, feat1, feat0, org, sz, y10, z11, y00, z01, z21):
+        """The six glue passes as argument structs (shared by forward and backward)."""
+        H3, W3 = y20.shape[2], y20.shape[3]
+        f2, f1, f0 = (2 * H3, 2 * W3), (4 * H3, 4 * W3), (8 * H3, 8 * W3)
+        return (_roi_glue_args(y20, None, feat1, None, org["z21"], sz["z21"], f2, 1, 1),
+                None if z21 is None else _roi_glue_args(z21, org["z21"], None, None, org["y10"], sz["y10"], f2, 0, 1),
+                None if y10 is None else _roi_glue_args(y10, org["y10"], feat0, None, org["z11"], sz["z11"], f1, 1, 1),
+                None if z11 is None else _roi_glue_args(z11, org["z11"], None, None, org["y00"], sz["y00"], f1, 0, 1),
+                None if y00 is None else _roi_glue_args(y00, org["y00"], None, None, org["z01"], sz["z01"], f0, 1, 1),
+                None if z01 is None else _roi_glue_args(z01, org["z01"], None, None, org["d"], sz["d"], f0, 0, 1))
+
+    @staticmethod
+    def forward(ctx, y20, feat1, feat0, mask, plan, tab, w21, b21, w10, b10, w11, b11, w00, b00, w01, b01, wd, bd):
         lib = N.lib()
-        dev = z21.device
-        B, _, H2, W2 = z21.shape
-        f2, f1, f0 = (H2, W2), (2 * H2, 2 * W2), (4 * H2, 4 * W2)
-        if tuple(feat0.shape[2:]) != f1 or tuple(mask.shape) != (B, 1) + f0 or plan.B != B or (plan.H, plan.W) != f0:
+        dev = y20.device
+        B, _, H3, W3 = y20.shape
+        f0 = (8 * H3, 8 * W3)
+        if (tuple(feat1.shape[2:]) != (2 * H3, 2 * W3) or tuple(feat0.shape[2:]) != (4 * H3, 4 * W3)
+                or tuple(mask.shape) != (B, 1) + f0 or plan.B != B or (plan.H, plan.W) != f0):
             raise RuntimeError("roi tail: feature / mask / plan shapes do not match")
-        org = {n: tab[k] for k, n in enumerate(("d", "z01", "y00", "z11", "y10"))}
+        org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
         sz = plan.size
-        a10 = _roi_glue_args(z21, None, None, None, org["y10"], sz["y10"], f2, 0, 1)
-        y10 = _conv_any(_roi_glue_fwd(a10, dev), w10, b10, 0)
-        a11 = _roi_glue_args(y10, org["y10"], feat0, None, org["z11"], sz["z11"], f1, 1, 1)
-        z11 = _conv_any(_roi_glue_fwd(a11, dev), w11, b11, 0)
-        a00 = _roi_glue_args(z11, org["z11"], None, None, org["y00"], sz["y00"], f1, 0, 1)
-        y00 = _conv_any(_roi_glue_fwd(a00, dev), w00, b00, 0)
-        a01 = _roi_glue_args(y00, org["y00"], None, None, org["z01"], sz["z01"], f0, 1, 1)
-        z01 = _conv_any(_roi_glue_fwd(a01, dev), w01, b01, 0)
-        ad = _roi_glue_args(z01, org["z01"], None, None, org["d"], sz["d"], f0, 0, 1)
-        d_pre = _conv_any(_roi_glue_fwd(ad, dev), wd, bd, 0)
+        st = _RoiTail._stages
+        z21 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, None, None, None)[0], dev), w21, b21, 0)
+        y10 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, None, None, z21)[1], dev), w10, b10, 0)
+        z11 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, y10, None, None, None, None)[2], dev), w11, b11, 0)
+        y00 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, z11, None, None, None)[3], dev), w00, b00, 0)
+        z01 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, y00, None, None)[4], dev), w01, b01, 0)
+        d_pre = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, None, z01, None)[5], dev), wd, bd, 0)
         hd, wd_ = sz["d"]
         sig = torch.empty_like(d_pre)
         part = torch.empty(lib.dmh_roi_cost_partials_size(B, hd, wd_), device=dev, dtype=torch.float32)
         cost = torch.empty((), device=dev, dtype=torch.float32)
         N.check(lib.dmh_roi_cost_fwd(N.ptr(d_pre), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, f0[0], f0[1], N.ptr(sig),
                                      N.ptr(part), N.ptr(cost), N.stream()))
-        ctx.save_for_backward(z21, feat0, mask, tab, y10, z11, y00, z01, sig, w10, w11, w00, w01, wd)
+        ctx.save_for_backward(y20, feat1, feat0, mask, tab, z21, y10, z11, y00, z01, sig, w21, w10, w11, w00, w01, wd)
         ctx.plan = plan
         return cost
 
     @staticmethod
     def backward(ctx, g):
-        z21, feat0, mask, tab, y10, z11, y00, z01, sig, w10, w11, w00, w01, wd = ctx.saved_tensors
+        y20, feat1, feat0, mask, tab, z21, y10, z11, y00, z01, sig, w21, w10, w11, w00, w01, wd = ctx.saved_tensors
         plan = ctx.plan
         lib = N.lib()
-        dev = z21.device
-        B, _, H2, W2 = z21.shape
-        f2, f1, f0 = (H2, W2), (2 * H2, 2 * W2), (4 * H2, 4 * W2)
-        org = {n: tab[k] for k, n in enumerate(("d", "z01", "y00", "z11", "y10"))}
+        dev = y20.device
+        B, _, H3, W3 = y20.shape
+        f0 = (8 * H3, 8 * W3)
+        org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
         sz = plan.size
         hd, wd_ = sz["d"]
+        a21, a10, a11, a00, a01, ad = _RoiTail._stages(y20, feat1, feat0, org, sz, y10, z11, y00, z01, z21)
         g_pre = torch.empty_like(sig)
         N.check(lib.dmh_roi_cost_bwd(N.ptr(sig), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, f0[0], f0[1],
                                      N.ptr(_c(g.to(torch.float32))), N.ptr(g_pre), N.stream()))
-        ad = _roi_glue_args(z01, org["z01"], None, None, org["d"], sz["d"], f0, 0, 1)
         g_z01, _ = _roi_glue_bwd(ad, _conv_any(g_pre, wd, None, 2, True), dev, False)
-        a01 = _roi_glue_args(y00, org["y00"], None, None, org["z01"], sz["z01"], f0, 1, 1)
         g_y00, _ = _roi_glue_bwd(a01, _conv_any(g_z01, w01, None, 2, True), dev, False)
-        a00 = _roi_glue_args(z11, org["z11"], None, None, org["y00"], sz["y00"], f1, 0, 1)
         g_z11, _ = _roi_glue_bwd(a00, _conv_any(g_y00, w00, None, 2, True), dev, False)
-        a11 = _roi_glue_args(y10, org["y10"], feat0, None, org["z11"], sz["z11"], f1, 1, 1)
-        g_y10, g_feat0 = _roi_glue_bwd(a11, _conv_any(g_z11, w11, None, 2, True), dev, ctx.needs_input_grad[1])
-        a10 = _roi_glue_args(z21, None, None, None, org["y10"], sz["y10"], f2, 0, 1)
+        # feature 0's gradient is zero outside "r_f0"; an encoder head that runs its backward on the plan's windows reads it
+        # inside that rectangle only, so the rest of the 252 MB tensor is not even zero-filled then
+        g_y10, g_feat0 = _roi_glue_bwd(a11, _conv_any(g_z11, w11, None, 2, True), dev, ctx.needs_input_grad[2],
+                                       skip_region=(org["r_f0"], sz["r_f0"]), skip_prezero=not plan.head_windowed)
         g_z21, _ = _roi_glue_bwd(a10, _conv_any(g_y10, w10, None, 2, True), dev, False)
-        return (g_z21, g_feat0) + (None,) * 13
+        g_y20, g_feat1 = _roi_glue_bwd(a21, _conv_any(g_z21, w21, None, 2, True), dev, ctx.needs_input_grad[1],
+                                       y_region=(org["r_y20"], sz["r_y20"]), skip_region=(org["r_f1"], sz["r_f1"]))
+        return (g_y20, g_feat1, g_feat0) + (None,) * 15
 
 
-def roi_tail_ok(z21, feat0, convs):
+def roi_tail_ok(y20, feat1, feat0, convs):
     """The cropped tail applies: inside frozen_weights() (its backward has no parameter gradients), fp32 CUDA tensors, the
-    reference decoder's channel plan (64 -> 32 -> [+64] 32 -> 16 -> 16 -> 1)."""
+    reference decoder's channel plan (64 [+64] -> 64 -> 32 [+64] -> 32 -> 16 -> 16 -> 1)."""
     shapes = [tuple(c.weight.shape) for c in convs]
-    return (ROI_ENABLED and _wino_frozen > 0 and z21.is_cuda and z21.dtype == torch.float32 and feat0.dtype == torch.float32
-            and shapes == [(32, 64, 3, 3), (32, 96, 3, 3), (16, 32, 3, 3), (16, 16, 3, 3), (1, 16, 3, 3)]
-            and feat0.shape[1] == 64 and z21.shape[2] % 2 == 0 and z21.shape[3] % 2 == 0)
+    return (ROI_ENABLED and _wino_frozen > 0 and y20.is_cuda and all(t.dtype == torch.float32 for t in (y20, feat1, feat0))
+            and shapes == [(64, 128, 3, 3), (32, 64, 3, 3), (32, 96, 3, 3), (16, 32, 3, 3), (16, 16, 3, 3), (1, 16, 3, 3)]
+            and y20.shape[1] == 64 and feat1.shape[1] == 64 and feat0.shape[1] == 64
+            and y20.shape[2] >= 2 and y20.shape[3] >= 2)
 
 
-def roi_tail_cost(z21, feat0, mask, plan, tab, convs):
+def roi_tail_cost(y20, feat1, feat0, mask, plan, tab, convs):
     """mean((sigmoid(dispconv0(...)) * mask)^2) of the decoder tail on the windows of ``plan`` (roi.RoiPlan; ``tab`` is
-    its origin table on the device, int32 [5, B, 2]).  ``convs``: the five nn.Conv2d modules upconv(1,0), upconv(1,1),
-    upconv(0,0), upconv(0,1), dispconv(0).  Equals ops.masked_sq_mean(decoder(...)[("disp", 0)], mask) when the mask is
-    zero outside the plan's boxes."""
-    if not roi_tail_ok(z21, feat0, convs):
+    its origin table on the device, int32 [len(roi.TABLE), B, 2]).  ``y20``: upconv(2,0)'s output (before its ELU); ``convs``: the six
+    nn.Conv2d modules upconv(2,1), upconv(1,0), upconv(1,1), upconv(0,0), upconv(0,1), dispconv(0).  Equals
+    ops.masked_sq_mean(decoder(...)[("disp", 0)], mask) when the mask is zero outside the plan's boxes."""
+    if not roi_tail_ok(y20, feat1, feat0, convs):
         raise RuntimeError("roi_tail_cost: needs ops.frozen_weights(), fp32 CUDA tensors and the Monodepth2 decoder tail")
-    if tab.dtype != torch.int32 or tuple(tab.shape) != (5, z21.shape[0], 2):
-        raise RuntimeError("roi_tail_cost: origin table must be int32 [5, B, 2]")
+    if tab.dtype != torch.int32 or tuple(tab.shape) != (len(_ROI_NAMES), y20.shape[0], 2):
+        raise RuntimeError("roi_tail_cost: origin table must be int32 [%d, B, 2] (roi.TABLE)" % len(_ROI_NAMES))
     wb = []
     for c in convs:
         wb += [c.weight.detach(), None if c.bias is None else _c(c.bias.detach())]
-    return _RoiTail.apply(_c(z21), _c(feat0), _c(mask), plan, _c(tab), *wb)
+    return _RoiTail.apply(_c(y20), _c(feat1), _c(feat0), _c(mask), plan, _c(tab), *wb)
+
+
+def _roi_crop(src, gate, g, org, size):
+    """Compact [B, C, h, w] window of a whole-frame tensor (roi_crop / roi_mask of csrc/roi_encoder.hip)."""
+    ref = src if src is not None else gate
+    B, Cc, H, W = ref.shape
+    out = torch.empty((B, Cc) + tuple(size), device=ref.device, dtype=torch.float32)
+    N.check(_timed("roi_crop", lambda: N.lib().dmh_roi_crop(N.ptr(src), N.ptr(gate), N.ptr(g), N.ptr(org), B, Cc, H, W, size[0],
+                                                           size[1], N.ptr(out), N.stream()),
+                   4 * out.numel() * (2 + (gate is not None))))
+    return out
+
+
+class _EncHeadEval(torch.autograd.Function):
+    """conv1((x - 0.45) / 0.225) -> bn1 -> relu -> maxpool -> layer1 (two stride-1 BasicBlocks) of the ResNet encoder in
+    eval() with constant parameters (MD2/networks/resnet_encoder.py:85-98), as ONE autograd node whose backward runs on the
+    windows of a roi.RoiPlan: the attack reads d cost / d image under the pasted object only.  Forward = the same launches as
+    the separate nodes (K14, K9 stem, four K10 launches).  Backward: layer1 on the "l1" window of the 1/4 map (four K10
+    launches on compact tensors; each spoils one ring of the window, which is four rings larger than what is read of it),
+    the stem's max-pool / ReLU / BatchNorm adjoint on the "gz" window of the 1/2 map, K12 on the image window "d"."""
+
+    @staticmethod
+    def forward(ctx, x, plan, tab, w_stem, s0, b0, w1a, s1a, b1a, w2a, s2a, b2a, w1b, s1b, b1b, w2b, s2b, b2b):
+        lib = N.lib()
+        B, _, H, W = x.shape
+        dev = x.device
+        st = N.stream()
+        z = torch.empty((B, 64, H // 2, W // 2), device=dev, dtype=torch.float32)
+        N.check(_timed("stem_conv_fwd", lambda: lib.dmh_stem_conv_norm_fwd(N.ptr(x), N.ptr(_c(w_stem)), B, H, W, 0.45, 0.225,
+                                                                          N.ptr(z), st), 4 * (x.numel() + z.numel()),
+                       2 * 147 * z.numel()))
+        f0 = torch.empty_like(z)
+        pooled = torch.empty((B, 64, H // 4, W // 4), device=dev, dtype=torch.float32)
+        arg = torch.empty((B, 64, H // 4, W // 4), device=dev, dtype=torch.uint8)
+        N.check(_timed("stem_fwd", lambda: lib.dmh_stem_bn_relu_pool_fwd(N.ptr(z), N.ptr(s0), N.ptr(b0), B, 64, H // 2, W // 2,
+                                                                        N.ptr(f0), N.ptr(pooled), N.ptr(arg), st),
+                       4 * (2 * z.numel() + pooled.numel()) + arg.numel()))
+        del z
+
+        def conv_act(inp, w, s, b, res):
+            y = torch.empty_like(inp)
+            N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+                N.ptr(inp), N.ptr(_wino_filter(w, False, s)), N.ptr(b), N.ptr(res), 1, B, 64, 64, H // 4, W // 4, 1, N.ptr(y), st),
+                4 * (2 + (res is not None)) * inp.numel(), 18 * 64 * inp.numel()))
+            return y
+
+        o1a = conv_act(pooled, w1a, s1a, b1a, None)
+        ya = conv_act(o1a, w2a, s2a, b2a, pooled)
+        o1b = conv_act(ya, w1b, s1b, b1b, None)
+        f1 = conv_act(o1b, w2b, s2b, b2b, ya)
+        ctx.save_for_backward(f0, arg, s0, o1a, ya, o1b, f1, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b)
+        ctx.plan, ctx.img = plan, (H, W)
+        ctx.set_materialize_grads(False)
+        return f0, f1
+
+    @staticmethod
+    def backward(ctx, g_f0, g_f1):
+        f0, arg, s0, o1a, ya, o1b, f1, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b = ctx.saved_tensors
+        plan, (H, W) = ctx.plan, ctx.img
+        lib = N.lib()
+        dev = f0.device
+        B = f0.shape[0]
+        st = N.stream()
+        org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
+        sz = plan.size
+        hq, wq = sz["l1"]
+        if g_f1 is None:
+            g_pool = torch.zeros((B, 64, hq, wq), device=dev, dtype=torch.float32)
+        else:
+            def conv_bwd(g, w, s, res, flag):
+                y = torch.empty_like(g)
+                N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+                    N.ptr(g), N.ptr(_wino_filter(w, True, s)), None, N.ptr(res), flag, B, 64, 64, hq, wq, 1, N.ptr(y), st),
+                    4 * 3 * g.numel(), 18 * 64 * g.numel()))
+                return y
+
+            g2b = _roi_crop(_c(g_f1), f1, None, org["l1"], (hq, wq))                    # g * [y_b > 0] on the window
+            g1b = conv_bwd(g2b, w2b, s2b, _roi_crop(o1b, None, None, org["l1"], (hq, wq)), 2)      # ... * [out1_b > 0]
+            g_ya = conv_bwd(g1b, w1b, s1b, g2b, 0)                                      # + the identity branch
+            g2a = _roi_crop(None, ya, g_ya, org["l1"], (hq, wq))                        # * [y_a > 0]
+            g1a = conv_bwd(g2a, w2a, s2a, _roi_crop(o1a, None, None, org["l1"], (hq, wq)), 2)
+            g_pool = conv_bwd(g1a, w1a, s1a, g2a, 0)
+        hs, ws = sz["gz"]
+        g_z = torch.empty((B, 64, hs, ws), device=dev, dtype=torch.float32)
+        N.check(_timed("stem_bwd_win", lambda: lib.dmh_stem_bn_relu_pool_bwd_win(
+            N.ptr(f0), N.ptr(arg), N.ptr(None if g_f0 is None else _c(g_f0)), N.ptr(g_pool), N.ptr(s0), N.ptr(org["gz"]),
+            N.ptr(org["l1"]), B, 64, H // 2, W // 2, hs, ws, hq, wq, N.ptr(g_z), st), 4 * 4 * g_z.numel()))
+        w_s = frozen_memo(("stem_w_over_std", w_stem.data_ptr(), w_stem._version, 0.225),
+                          lambda: _c(w_stem.detach() * (1.0 / 0.225)))
+        g_x = torch.zeros((B, 3, H, W), device=dev, dtype=torch.float32)
+        hd, wd = sz["d"]
+        N.check(_timed("stem_conv_bwd_win", lambda: lib.dmh_conv7x7s2_bwd_data_win(
+            N.ptr(g_z), N.ptr(w_s), N.ptr(org["d"]), N.ptr(org["gz"]), B, 64, 3, H, W, hd, wd, hs, ws, N.ptr(g_x), st),
+            4 * (g_z.numel() + B * 3 * hd * wd)))
+        return (g_x,) + (None,) * 17
+
+
+def encoder_head_ok(x, conv1_weight, blocks):
+    """The windowed encoder head applies: inside frozen_weights(), an fp32 CUDA image [B,3,H,W] with H, W multiples of 8, the
+    standard 3 -> 64 7x7 first layer and a layer1 of two stride-1 64-channel BasicBlocks whose convolutions K10 takes."""
+    if not (ROI_ENABLED and _wino_frozen > 0 and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
+            and x.shape[2] % 8 == 0 and x.shape[3] % 8 == 0 and x.requires_grad and tuple(conv1_weight.shape) == (64, 3, 7, 7)):
+        return False
+    B, _, H, W = x.shape
+    return (len(blocks) == 2 and all(tuple(w.shape) == (64, 64, 3, 3) for blk in blocks for w in blk)
+            and _wino_ok(B, 64, 64, H // 4, W // 4, allow_split=False) and B * 64 * (H // 4) * (W // 4) < (1 << 30))
+
+
+def encoder_head_eval(x, plan, tab, conv1_weight, aff0, blocks):
+    """(feature 0, feature 1) of the ResNet-18 encoder in eval() -- MD2/networks/resnet_encoder.py:88-95: relu(bn1(conv1((x -
+    0.45) / 0.225))) and layer1(maxpool(.)) -- as one node whose backward runs on the windows of ``plan`` (see _EncHeadEval):
+    d / d x is exact inside the plan's image window "d" and ZERO outside it, which is all an object attack reads
+    (physicalTrans.py:156-165).  ``blocks``: per BasicBlock (w1, (scale1, shift1), w2, (scale2, shift2)); ``aff0``: bn1's
+    (scale, shift).  Marks the plan as head_windowed (the decoder tail then writes feature 0's gradient inside "r_f0" only)."""
+    ws = [(b[0], b[2]) for b in blocks]
+    if not encoder_head_ok(x, conv1_weight, ws):
+        raise RuntimeError("encoder_head_eval: needs ops.frozen_weights() and the ResNet-18 head (ops.encoder_head_ok)")
+    if tab.dtype != torch.int32 or tuple(tab.shape) != (len(_ROI_NAMES), x.shape[0], 2) or plan.B != x.shape[0] or \
+            (plan.H, plan.W) != tuple(x.shape[2:]):
+        raise RuntimeError("encoder_head_eval: plan / origin table do not match the image batch")
+    d = lambda t: _c(t.detach())        # noqa: E731
+    args = [d(conv1_weight), d(aff0[0]), d(aff0[1])]
+    for w1, a1, w2, a2 in blocks:
+        args += [w1.detach(), d(a1[0]), d(a1[1]), w2.detach(), d(a2[0]), d(a2[1])]
+    plan.head_windowed = True
+    return _EncHeadEval.apply(_c(x), plan, _c(tab), *args)
 
 
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from ... import ops
 from ...my_utils import object_dataset_root, ori_H, ori_W, to_device_async
 from ...physicalTrans import PhysicalTrans
+from ...roi import RoiPlan
 from ..attack import Attack
 
 
@@ -43,6 +44,7 @@ class Phy_obj_atk_l0(Attack):
                                            dist_range=dist_range)
         self.phy_trans_ben = PhysicalTrans(self.obj_img, self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
+        self.use_roi = True     # evaluate the adversarial cost on windows around the object when the model offers it
         self.trace = None  # set to a list to record (l0, mask_weight, adv_cost, mask_cost) per iteration
 
     def cal_l0(self):
@@ -90,6 +92,11 @@ class Phy_obj_atk_l0(Attack):
         coeffs = to_device_async(coeffs_host, self.device)
         l_pad, t_pad = pt.l_pad, pt.t_pad
         mask = self.obj_mask.to(self.device)
+        # the adversarial cost reads the disparity under the object only: see Phy_obj_atk.forward
+        plans = tabs = None
+        if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
+            plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size) for z0, al in draws]
+            tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
         thresh = torch.full((), float(self.l0_thresh), device=self.device)      # fill kernels: no host sync
         w_on = torch.full((), float(self.mask_weight_init), device=self.device)
         w_off = torch.zeros((), device=self.device)
@@ -108,8 +115,11 @@ class Phy_obj_atk_l0(Attack):
             mw = torch.where(below, w_off, w_on)
             adv_scenes, adv_obj_mask = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[stp], l_pad, t_pad,
                                                      self.scene_size)
-            adv_depth = self.model(adv_scenes)
-            adv_cost = ops.masked_sq_mean(adv_depth, adv_obj_mask)
+            if plans is not None:
+                adv_cost = self.model.masked_sq_mean(adv_scenes, adv_obj_mask, plans[stp], tabs[stp])
+            else:
+                adv_depth = self.model(adv_scenes)
+                adv_cost = ops.masked_sq_mean(adv_depth, adv_obj_mask)
             mask_cost = ops.l0_mask_cost(self.pattern_pos_tensor, self.pattern_neg_tensor)
             total_cost = adv_cost + mw * mask_cost
             # same update as zero_grad(); total_cost.backward(); step() (:136-138), but only the two

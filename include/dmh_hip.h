@@ -266,7 +266,8 @@ int dmh_elu_pad_bwd(const float* z, const float* g_out, int B, int C, int H, int
  *     frames with per-sample origins y_org / skip_org ([B,2] int32: row, column), or whole frames (origin table NULL).
  *     up: y lives at half the destination resolution; elu: ELU is applied to y.  wc must be even.
  *     Every read must fall inside the source windows (the caller's window plan guarantees it; indices are clamped).
- *   bwd: g_y / g_skip over the WHOLE source planes (0 where no window entry reads the element); g_skip may be NULL.
+ *   bwd: g_y / g_skip over the whole source planes (0 where no window entry reads the element) or, for whole-frame
+ *     sources, over a per-sample rectangle (below); g_skip may be NULL.
  *   roi_cost: cost = sum over the windows of (sigmoid(d_pre) * mask)^2 / (B H W); d_pre [B,1,hd,wd] is the disparity
  *     head's output on the window at org[b] of the H x W frame, mask [B,1,H,W] the full-frame K3 mask; sig receives the
  *     sigmoid.  bwd: g_pre = gscale[0] * 2 sig mask^2 / (B H W) * sig (1 - sig).
@@ -285,12 +286,30 @@ typedef struct dmh_roi_glue_args {
     int up, elu;
 } dmh_roi_glue_args;
 int dmh_roi_glue_fwd(const dmh_roi_glue_args* a, float* out, void* stream);
-int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y, float* g_skip, void* stream);
+/* y_reg_org / skip_reg_org ([B,2] int32 or NULL): for a whole-frame source, write only the y_reg_h x y_reg_w rectangle at
+ * that per-sample origin (it must hold everything the window reaches; the caller owns the rest of the plane). */
+int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y, float* g_skip, const int* y_reg_org,
+                     int y_reg_h, int y_reg_w, const int* skip_reg_org, int skip_reg_h, int skip_reg_w, void* stream);
 int64_t dmh_roi_cost_partials_size(int B, int hd, int wd);
 int dmh_roi_cost_fwd(const float* d_pre, const float* mask, const int* org, int B, int hd, int wd, int H, int W, float* sig,
                      float* partials, float* cost, void* stream);
 int dmh_roi_cost_bwd(const float* sig, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
                      const float* gscale, float* g_pre, void* stream);
+
+/* K19, encoder side: the backward of conv1 / bn1 / relu / maxpool and layer1 (torchvision ResNet under
+ * MD2/networks/resnet_encoder.py:85-98) on one window per scene -- the patch gradient reads d cost / d image under the pasted
+ * object only (physicalTrans.py:156-165, phy_obj_atk.py:96).
+ *   roi_crop: out[B,C,hc,wc] = src[b, c, org_b + (i, j)] of a whole-frame src[B,C,H,W], times [gate > 0] (gate: whole-frame,
+ *             same window) when gate is given; or, with g (compact [B,C,hc,wc]) instead of src, out = g * [gate window > 0].
+ *             org [B,2] int32 with even columns, wc and W even.
+ *   stem_bn_relu_pool_bwd_win: dmh_stem_bn_relu_pool_bwd on the hs x ws window (even origin org, even sizes) of the H x W
+ *             map: g_z[B,C,hs,ws] compact; g_pool is a compact [B,C,hq,wq] window of the H/2 x W/2 map at pool_org (cells
+ *             outside it count as 0: it must hold the pooling cells that cover the window); g_feat whole-frame or NULL. */
+int dmh_roi_crop(const float* src, const float* gate, const float* g, const int* org, int B, int C, int H, int W, int hc,
+                 int wc, float* out, void* stream);
+int dmh_stem_bn_relu_pool_bwd_win(const float* feat, const unsigned char* argmax, const float* g_feat, const float* g_pool,
+                                  const float* scale, const int* org, const int* pool_org, int B, int C, int H, int W, int hs,
+                                  int ws, int hq, int wq, float* g_z, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K9  encoder glue: the element-wise passes between the MIOpen convolutions of the ResNet encoder while the model
@@ -407,6 +426,11 @@ int dmh_conv3x3_small(const float* x, const float* w, const float* bias, int B, 
  * ---------------------------------------------------------------------------------- */
 int dmh_conv7x7s2_bwd_data(const float* g_y, const float* w, int B, int K, int Cin, int H, int W, float* g_x,
                            void* stream);
+/* Window form (K19): only the hwin x wwin window of g_x at the per-sample, even pixel origin img_org [B,2] is written (at its
+ * place in the whole [B,Cin,H,W] tensor); g_y is a compact [B,K,sh,sw] window of the H/2 x W/2 frame at origin gy_org [B,2]
+ * that must hold rows / columns (img_org / 2 - 1) .. ((img_org + hwin) / 2 + 1) of that frame as far as they lie inside it. */
+int dmh_conv7x7s2_bwd_data_win(const float* g_y, const float* w, const int* img_org, const int* gy_org, int B, int K, int Cin,
+                               int H, int W, int hwin, int wwin, int sh, int sw, float* g_x, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K13 disparity head: 3x3 stride-1 convolution to ONE output channel (MD2/networks/depth_decoder.py:43-44 dispconv),
