@@ -131,7 +131,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         return c;
     };
     auto load_x = [&](const Chunk& c, const int k) __attribute__((always_inline)) {
-        const unsigned vo = (xm[k] & c.bad) ? 0xFFFFFF00u : (c.xbase + xg[k]) * 4u;
+        const unsigned vo = (xm[k] & c.bad) ? 0xFFFFFF00u : (c.xbase + xg[k]) * 4u;      // beyond num_records (<= 0xFFFFFF00, checked on the host): reads 0
         rx[k] = (DMH_WRW_ABLATE & 1) ? f32x4{1.f, 1.f, 1.f, 1.f}
                                      : __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, vo, 0, 0));
     };
@@ -446,7 +446,7 @@ int dmh_wino_wrw(const float* x, const float* dy, int B, int C, int K, int H, in
     a.x = x; a.dy = dy; a.ws = workspace;
     a.B = B; a.C = C; a.K = K; a.H = H; a.W = W; a.pad = pad; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2;
     DMH_REQUIRE(a.Ho >= 2 && a.Wo >= 2 && (a.Ho & 1) == 0 && (a.Wo & 1) == 0, "output height and width must be even");
-    DMH_REQUIRE((int64_t)B * C * H * W < ((int64_t)1 << 30) && (int64_t)B * K * a.Ho * a.Wo < ((int64_t)1 << 30),
+    DMH_REQUIRE((int64_t)B * C * H * W * 4 <= (int64_t)0xFFFFFF00 && (int64_t)B * K * a.Ho * a.Wo < ((int64_t)1 << 30),
                 "tensor larger than 4 GB (32-bit byte offsets of the buffer loads)");
     plan(a, kch, cch);
     int rc;

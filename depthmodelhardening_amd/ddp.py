@@ -39,6 +39,25 @@ def init_distributed(device_type="cuda"):
     return rank, world, device
 
 
+def shorten_timeout(minutes=None):
+    """After warm-up (rendezvous done, MIOpen's kernels built) a collective that does not finish within minutes is a hang,
+    not a slow rank: bring the process group's timeout down from the generous start-up value so that a stuck rank fails the
+    job in ``minutes`` (DMH_DIST_STEADY_TIMEOUT_MIN, default 10) instead of an hour.  No-op without a process group or
+    where this torch build does not expose the setter."""
+    if not dist.is_initialized():
+        return False
+    import datetime
+    minutes = int(os.environ.get("DMH_DIST_STEADY_TIMEOUT_MIN", "10")) if minutes is None else minutes
+    setter = getattr(torch.distributed.distributed_c10d, "_set_pg_timeout", None)
+    if setter is None:
+        return False
+    try:
+        setter(datetime.timedelta(minutes=minutes), dist.group.WORLD)
+        return True
+    except Exception:
+        return False
+
+
 class GradBucket(object):
     """Flat gradient bucket over the parameters that can receive a gradient.
 

@@ -889,6 +889,8 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     work items to fill the 256 CUs (measured crossover, tools/wino_bench.py)."""
     if not WINO_ENABLED or n_in % 8 or n_in < 24 or n_out < 64 or Ho % 2 or Wo % 2 or Ho < 2 or Wo < 2:
         return False
+    if B * n_in * (Ho + 2) * (Wo + 2) >= (1 << 30):     # 32-bit byte offsets of the kernel's buffer loads: ATen beyond
+        return False
     if n_in < 64 and n_out % 64:        # few chunks per item and a half-empty channel group: MIOpen is level or ahead
         return False
     ht, wt = Ho // 2, Wo // 2
@@ -925,7 +927,7 @@ def _wrw_ok(x, g, K, Cc):
     pad = (g.shape[2] + 2 - x.shape[2]) // 2
     if pad not in (0, 1) or (pad == 1 and x.shape[3] % 16):
         return False
-    if x.numel() >= (1 << 30) or g.numel() >= (1 << 30):
+    if x.numel() * 4 > 0xFFFFFF00 or g.numel() >= (1 << 30):      # the kernel's own limits (DMH_REQUIRE in csrc/wino_wrw.hip)
         return False
     chunks = g.shape[0] * (g.shape[2] // 2) * -(-(g.shape[3] // 2) // 8)
     return chunks * (K // kch) * (Cc // cch) >= 1024
@@ -934,7 +936,8 @@ def _wrw_ok(x, g, K, Cc):
 def _wino32_ok(B, n_in, n_out, Ho, Wo):
     """Shapes of K17, the 32-output-channel form of K10 (work item 32 channels x 4 x 32 tiles): output channels a multiple
     of 32 that K10's 64-channel items would half-fill, enough items to cover the chip and few empty tiles."""
-    if not WINO_ENABLED or n_in % 8 or n_in < 32 or n_out % 32 or n_out % 64 == 0 or n_out > 96 or Ho % 2 or Wo % 2:
+    if (not WINO_ENABLED or n_in % 8 or n_in < 32 or n_out % 32 or n_out % 64 == 0 or n_out > 96 or Ho % 2 or Wo % 2
+            or B * n_in * (Ho + 2) * (Wo + 2) >= (1 << 30)):
         return False        # (32 -> 96, the backward-data pass of upconv(1,1): 509 us against MIOpen's 566, tools/wino32_bench.py)
     ht, wt = Ho // 2, Wo // 2
     rows, cols = -(-ht // 4) * 4, -(-wt // 32) * 32
@@ -984,8 +987,10 @@ def _small_ok(n_in, n_out):
 
 def _small_conv(x, weight, bias, pad, backward):
     lib = N.lib()
-    if x.numel() >= (1 << 30):
-        raise RuntimeError("conv3x3_small: input larger than 4 GB")
+    if x.numel() >= (1 << 30):      # beyond the 32-bit byte offsets of the kernel's buffer loads: ATen, as for K15 / K18
+        if backward:
+            return torch.nn.functional.conv_transpose2d(x, weight, None, 1, 2 - pad)
+        return torch.conv2d(x, weight, bias, 1, pad)
     B, _, H, W = x.shape
     Kw, Cw = weight.shape[0], weight.shape[1]
     n_out = Cw if backward else Kw

@@ -171,3 +171,26 @@ def test_frozen_weights_scope_and_coefficient_memo():
         np.testing.assert_array_equal(c1[i], fresh.coeffs_for([z[i]], [a[i]])[0])
     assert len(fresh._coeff_memo) <= len(z)
     assert len(pt._coeff_memo) >= len(pt.dist_range) * len(pt.angle_range)
+
+
+def test_bench_presets_name_the_baseline_configs():
+    """bench.py --config N must run the workload BASELINE.json configs[N-1] names, and the default
+    metric string must be BASELINE.json's headline metric."""
+    import json
+    import os
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, repo)
+    import bench
+    base = json.load(open(os.path.join(repo, "BASELINE.json")))
+    norm = lambda t: t.replace("×", "x").replace("L∞", "L_inf").replace(" ", "")     # noqa: E731
+    for idx, (name, flags) in bench.BASELINE_CONFIGS.items():
+        assert norm(name) == norm(base["configs"][idx - 1]), (idx, name)
+    a = bench.parse([])
+    assert (a.config, a.batch_size, a.atk_steps, a.height, a.width, a.norm_type) == (2, 32, 10, 320, 1024, "l_inf")
+    assert norm(base["metric"]).startswith(norm("adv-train images/sec @1024x320, 10-step PGD, bs32"))
+    a4 = bench.parse(["--config", "4"])
+    assert (a4.batch_size, a4.atk_steps, a4.loss_variant, a4.contrastive_learning) == (64, 20, "dh", True)
+    # the step-FLOP model builds at any size (import_depth_model refuses everything but 1024x320)
+    f = bench.unet_flops(64, 192)
+    assert f["fwd"] > 0 and f["bwd_full"] > f["bwd_data"] > 0
