@@ -32,7 +32,7 @@ class DepthModelWrapper(torch.nn.Module):
             feats = self.encoder(input_image, roi=(plan, tab))
         else:
             feats = self.encoder(input_image)
-        if roi_dec and self.decoder.roi_ok(feats):
+        if roi_dec and self.decoder.roi_ok(feats, plan.depth):
             return self.decoder.masked_sq_mean(feats, mask, plan, tab)
         if plan is not None and getattr(plan, "head_windowed", False):
             raise RuntimeError("masked_sq_mean: the encoder ran its windowed head but the decoder cannot take the plan")

@@ -60,27 +60,35 @@ class DepthDecoder(nn.Module):
                 self.outputs[("disp", i)] = self.sigmoid(conv(self.convs[("dispconv", i)], p))
         return self.outputs
 
-    def roi_ok(self, input_features):
+    def roi_ok(self, input_features, depth=None):
         """The attack's windowed cost (ops.roi_tail_cost) applies to these features: the fused CUDA path, scale 0 among
         the heads, the reference's channel plan."""
         from .. import ops
+        depth = ops.ROI_DEPTH if depth is None else depth
         if not (input_features[-1].is_cuda and self.use_skips and self.upsample_mode == 'nearest' and 0 in self.scales
-                and len(input_features) == 5 and self.num_output_channels == 1):
+                and len(input_features) == 5 and self.num_output_channels == 1 and depth in (2, 3, 4)):
             return False
-        f0, f1, f2 = input_features[:3]
-        return (f0.shape[2] % 4 == 0 and f0.shape[3] % 4 == 0 and tuple(f1.shape[2:]) == (f0.shape[2] // 2, f0.shape[3] // 2)
-                and tuple(f2.shape[2:]) == (f0.shape[2] // 4, f0.shape[3] // 4) and f2.shape[2] >= 2 and f2.shape[3] >= 2
-                and ops.roi_tail_ok(f1, f1, f0, self._tail_convs()))
+        f0 = input_features[0]
+        if f0.shape[2] % 16 or f0.shape[3] % 16 or any(tuple(f.shape[2:]) != (f0.shape[2] >> k, f0.shape[3] >> k)
+                                                       for k, f in enumerate(input_features)):
+            return False
+        top = input_features[depth]     # stands in for upconv(depth,0)'s output: same size as feature `depth`
+        return ops.roi_tail_ok(top.new_empty((1, int(self.num_ch_dec[depth])) + tuple(top.shape[2:])),
+                               tuple(input_features[:depth]), self._tail_convs(depth), depth)
 
-    def _tail_convs(self):
+    def _tail_convs(self, depth):
         c = self.convs
-        return [c[("upconv", 2, 1)].conv.conv, c[("upconv", 1, 0)].conv.conv, c[("upconv", 1, 1)].conv.conv,
-                c[("upconv", 0, 0)].conv.conv, c[("upconv", 0, 1)].conv.conv, c[("dispconv", 0)].conv]
+        out = []
+        for i in range(depth, -1, -1):
+            if i < depth:
+                out.append(c[("upconv", i, 0)].conv.conv)
+            out.append(c[("upconv", i, 1)].conv.conv)
+        return out + [c[("dispconv", 0)].conv]
 
     def masked_sq_mean(self, input_features, mask, plan, tab):
-        """mean((disp_0 * mask)^2) -- the attack's cost (phy_obj_atk.py:92-94) -- with the decoder's high-resolution tail
-        evaluated on the windows of ``plan`` only (roi.RoiPlan around the pasted object, where the mask lives): stages 4
-        and 3 and upconv(2,0) run on the whole maps, upconv(2,1) ... dispconv(0) inside the windows.  Exact, not an
+        """mean((disp_0 * mask)^2) -- the attack's cost (phy_obj_atk.py:92-94) -- with the decoder below stage
+        (plan.depth, 0) evaluated on the windows of ``plan`` only (roi.RoiPlan around the pasted object, where the mask
+        lives): the stages above run on the whole maps, upconv(depth,1) ... dispconv(0) inside the windows.  Exact, not an
         approximation: the mask is zero outside the plan's boxes, so nothing outside the windows' receptive field reaches
         the cost."""
         from .. import ops
@@ -89,13 +97,14 @@ class DepthDecoder(nn.Module):
             c = block.conv
             return ops.conv3x3(t, c.weight, c.bias, 0)
 
+        depth = plan.depth
         p = ops.elu_pad(input_features[-1], apply_elu=False)
-        for i in (4, 3):
+        for i in range(4, depth, -1):
             y = conv(self.convs[("upconv", i, 0)].conv, p)
             p = ops.up_cat_pad(y, input_features[i - 1])
             p = ops.elu_pad(conv(self.convs[("upconv", i, 1)].conv, p))
-        y20 = conv(self.convs[("upconv", 2, 0)].conv, p)
-        return ops.roi_tail_cost(y20, input_features[1], input_features[0], mask, plan, tab, self._tail_convs())
+        y_top = conv(self.convs[("upconv", depth, 0)].conv, p)
+        return ops.roi_tail_cost(y_top, input_features[:depth], mask, plan, tab, self._tail_convs(depth))
 
     def _forward_reference(self, input_features):
         self.outputs = {}

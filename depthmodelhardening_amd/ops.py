@@ -1567,106 +1567,131 @@ def _roi_glue_bwd(a, g_out, device, want_skip, y_region=None, skip_region=None, 
     return g_y, g_skip
 
 
-from .roi import TABLE as _ROI_NAMES     # noqa: E402  (row order of the device table of window origins)
+from .roi import STAGES as _ROI_STAGES, TABLE as _ROI_NAMES     # noqa: E402  (row order of the device table of origins)
+
+ROI_DEPTH = int(os.environ.get("DMH_ROI_DEPTH", "3"))      # level of the deepest windowed decoder stage (2, 3 or 4)
+# channel plan of the reference decoder's stages (MD2/networks/depth_decoder.py:22-37), by window name: (out, in)
+_ROI_CHANNELS = {"d": (1, 16), "z01": (16, 16), "y00": (16, 32), "z11": (32, 96), "y10": (32, 64), "z21": (64, 128),
+                 "y20": (64, 128), "z31": (128, 256), "y30": (128, 256), "z41": (256, 512)}
+
+
+def _roi_chain(depth):
+    """The windowed stages from z{depth}1 down to the disparity head, in execution order: (name, level, up, skip index)."""
+    names = [st[0] for st in _ROI_STAGES]
+    return list(reversed(_ROI_STAGES[:names.index("z%d1" % depth) + 1]))
 
 
 class _RoiTail(torch.autograd.Function):
-    """mean((disp0 * mask)^2) from upconv(2,0)'s output and features 1 and 0, through upconv(2,1) ... dispconv(0)
-    (MD2/networks/depth_decoder.py:51-63) evaluated on one window per scene.  Hand-written backward (parameters are
-    constants: inside ops.frozen_weights() only): gradients w.r.t. y20, feat1 and feat0, whole planes, zero outside the
-    windows' reach."""
+    """mean((disp0 * mask)^2) from upconv(depth,0)'s whole-frame output and the encoder features below it, through
+    upconv(depth,1) ... dispconv(0) (MD2/networks/depth_decoder.py:51-63) evaluated on one window per scene.  Hand-written
+    backward (parameters are constants: inside ops.frozen_weights() only): gradients w.r.t. that output and the features,
+    zero outside the rectangles the windows reach.  Tensor arguments: x_top, feat_0 .. feat_{depth-1}, mask, tab, then
+    (weight, bias) per stage in execution order."""
 
     @staticmethod
-    def _stages(y20, feat1, feat0, org, sz, y10, z11, y00, z01, z21):
-        """The six glue passes as argument structs (shared by forward and backward)."""
-        H3, W3 = y20.shape[2], y20.shape[3]
-        f2, f1, f0 = (2 * H3, 2 * W3), (4 * H3, 4 * W3), (8 * H3, 8 * W3)
-        return (_roi_glue_args(y20, None, feat1, None, org["z21"], sz["z21"], f2, 1, 1),
-                None if z21 is None else _roi_glue_args(z21, org["z21"], None, None, org["y10"], sz["y10"], f2, 0, 1),
-                None if y10 is None else _roi_glue_args(y10, org["y10"], feat0, None, org["z11"], sz["z11"], f1, 1, 1),
-                None if z11 is None else _roi_glue_args(z11, org["z11"], None, None, org["y00"], sz["y00"], f1, 0, 1),
-                None if y00 is None else _roi_glue_args(y00, org["y00"], None, None, org["z01"], sz["z01"], f0, 1, 1),
-                None if z01 is None else _roi_glue_args(z01, org["z01"], None, None, org["d"], sz["d"], f0, 0, 1))
+    def _glue(chain, k, src, feats, org, sz, H0, W0):
+        name, lvl, up, skip = chain[k]
+        src_org = None if k == 0 else org[chain[k - 1][0]]
+        return _roi_glue_args(src, src_org, None if skip is None else feats[skip], None, org[name], sz[name],
+                              (H0 >> lvl, W0 >> lvl), up, 1)
 
     @staticmethod
-    def forward(ctx, y20, feat1, feat0, mask, plan, tab, w21, b21, w10, b10, w11, b11, w00, b00, w01, b01, wd, bd):
+    def forward(ctx, plan, depth, x_top, *rest):
         lib = N.lib()
-        dev = y20.device
-        B, _, H3, W3 = y20.shape
-        f0 = (8 * H3, 8 * W3)
-        if (tuple(feat1.shape[2:]) != (2 * H3, 2 * W3) or tuple(feat0.shape[2:]) != (4 * H3, 4 * W3)
-                or tuple(mask.shape) != (B, 1) + f0 or plan.B != B or (plan.H, plan.W) != f0):
+        dev = x_top.device
+        feats, mask, tab = rest[:depth], rest[depth], rest[depth + 1]
+        wb = rest[depth + 2:]
+        chain = _roi_chain(depth)
+        B = x_top.shape[0]
+        H0, W0 = x_top.shape[2] << (depth + 1), x_top.shape[3] << (depth + 1)
+        if (any(tuple(f.shape[2:]) != (H0 >> (k + 1), W0 >> (k + 1)) for k, f in enumerate(feats))
+                or tuple(mask.shape) != (B, 1, H0, W0) or plan.B != B or (plan.H, plan.W) != (H0, W0)):
             raise RuntimeError("roi tail: feature / mask / plan shapes do not match")
         org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
         sz = plan.size
-        st = _RoiTail._stages
-        z21 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, None, None, None)[0], dev), w21, b21, 0)
-        y10 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, None, None, z21)[1], dev), w10, b10, 0)
-        z11 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, y10, None, None, None, None)[2], dev), w11, b11, 0)
-        y00 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, z11, None, None, None)[3], dev), w00, b00, 0)
-        z01 = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, y00, None, None)[4], dev), w01, b01, 0)
-        d_pre = _conv_any(_roi_glue_fwd(st(y20, feat1, feat0, org, sz, None, None, None, z01, None)[5], dev), wd, bd, 0)
+        outs, src = [], x_top
+        for k in range(len(chain)):
+            a = _RoiTail._glue(chain, k, src, feats, org, sz, H0, W0)
+            src = _conv_any(_roi_glue_fwd(a, dev), wb[2 * k], wb[2 * k + 1], 0)
+            outs.append(src)
+        d_pre = outs.pop()
         hd, wd_ = sz["d"]
         sig = torch.empty_like(d_pre)
         part = torch.empty(lib.dmh_roi_cost_partials_size(B, hd, wd_), device=dev, dtype=torch.float32)
         cost = torch.empty((), device=dev, dtype=torch.float32)
-        N.check(lib.dmh_roi_cost_fwd(N.ptr(d_pre), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, f0[0], f0[1], N.ptr(sig),
+        N.check(lib.dmh_roi_cost_fwd(N.ptr(d_pre), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, H0, W0, N.ptr(sig),
                                      N.ptr(part), N.ptr(cost), N.stream()))
-        ctx.save_for_backward(y20, feat1, feat0, mask, tab, z21, y10, z11, y00, z01, sig, w21, w10, w11, w00, w01, wd)
-        ctx.plan = plan
+        ctx.save_for_backward(x_top, mask, tab, sig, *feats, *outs, *wb[0::2])
+        ctx.plan, ctx.depth = plan, depth
         return cost
 
     @staticmethod
     def backward(ctx, g):
-        y20, feat1, feat0, mask, tab, z21, y10, z11, y00, z01, sig, w21, w10, w11, w00, w01, wd = ctx.saved_tensors
-        plan = ctx.plan
+        plan, depth = ctx.plan, ctx.depth
+        sv = ctx.saved_tensors
+        x_top, mask, tab, sig = sv[:4]
+        chain = _roi_chain(depth)
+        n = len(chain)
+        feats, outs, ws = sv[4:4 + depth], sv[4 + depth:4 + depth + n - 1], sv[4 + depth + n - 1:]
         lib = N.lib()
-        dev = y20.device
-        B, _, H3, W3 = y20.shape
-        f0 = (8 * H3, 8 * W3)
-        org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
+        dev = x_top.device
+        B = x_top.shape[0]
+        H0, W0 = plan.H, plan.W
+        org = {nm: tab[k] for k, nm in enumerate(_ROI_NAMES)}
         sz = plan.size
         hd, wd_ = sz["d"]
-        a21, a10, a11, a00, a01, ad = _RoiTail._stages(y20, feat1, feat0, org, sz, y10, z11, y00, z01, z21)
-        g_pre = torch.empty_like(sig)
-        N.check(lib.dmh_roi_cost_bwd(N.ptr(sig), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, f0[0], f0[1],
-                                     N.ptr(_c(g.to(torch.float32))), N.ptr(g_pre), N.stream()))
-        g_z01, _ = _roi_glue_bwd(ad, _conv_any(g_pre, wd, None, 2, True), dev, False)
-        g_y00, _ = _roi_glue_bwd(a01, _conv_any(g_z01, w01, None, 2, True), dev, False)
-        g_z11, _ = _roi_glue_bwd(a00, _conv_any(g_y00, w00, None, 2, True), dev, False)
-        # feature 0's gradient is zero outside "r_f0"; an encoder head that runs its backward on the plan's windows reads it
-        # inside that rectangle only, so the rest of the 252 MB tensor is not even zero-filled then
-        g_y10, g_feat0 = _roi_glue_bwd(a11, _conv_any(g_z11, w11, None, 2, True), dev, ctx.needs_input_grad[2],
-                                       skip_region=(org["r_f0"], sz["r_f0"]), skip_prezero=not plan.head_windowed)
-        g_z21, _ = _roi_glue_bwd(a10, _conv_any(g_y10, w10, None, 2, True), dev, False)
-        g_y20, g_feat1 = _roi_glue_bwd(a21, _conv_any(g_z21, w21, None, 2, True), dev, ctx.needs_input_grad[1],
-                                       y_region=(org["r_y20"], sz["r_y20"]), skip_region=(org["r_f1"], sz["r_f1"]))
-        return (g_y20, g_feat1, g_feat0) + (None,) * 15
+        g_cur = torch.empty_like(sig)
+        N.check(lib.dmh_roi_cost_bwd(N.ptr(sig), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, H0, W0,
+                                     N.ptr(_c(g.to(torch.float32))), N.ptr(g_cur), N.stream()))
+        g_feats = [None] * depth
+        for k in range(n - 1, -1, -1):
+            name, lvl, up, skip = chain[k]
+            src = x_top if k == 0 else outs[k - 1]
+            a = _RoiTail._glue(chain, k, src, feats, org, sz, H0, W0)
+            want_skip = skip is not None and ctx.needs_input_grad[3 + skip]
+            y_reg = ("r_y%d0" % lvl) if k == 0 else None
+            s_reg = None if skip is None else "r_f%d" % skip
+            # feature 0's gradient is zero outside "r_f0"; an encoder head that runs its backward on the plan's windows reads
+            # it inside that rectangle only, so the rest of the 252 MB tensor is not even zero-filled then
+            g_cur, g_skip = _roi_glue_bwd(a, _conv_any(g_cur, ws[k], None, 2, True), dev, want_skip,
+                                          y_region=None if y_reg is None else (org[y_reg], sz[y_reg]),
+                                          skip_region=None if s_reg is None else (org[s_reg], sz[s_reg]),
+                                          skip_prezero=not (skip == 0 and plan.head_windowed))
+            if skip is not None:
+                g_feats[skip] = g_skip
+        return (None, None, g_cur) + tuple(g_feats) + (None,) * (2 + 2 * n)
 
 
-def roi_tail_ok(y20, feat1, feat0, convs):
+def roi_tail_ok(x_top, feats, convs, depth):
     """The cropped tail applies: inside frozen_weights() (its backward has no parameter gradients), fp32 CUDA tensors, the
-    reference decoder's channel plan (64 [+64] -> 64 -> 32 [+64] -> 32 -> 16 -> 16 -> 1)."""
+    reference decoder's channel plan for the stages upconv(depth,1) ... dispconv(0)."""
+    if depth not in (2, 3, 4) or len(feats) != depth:
+        return False
+    chain = _roi_chain(depth)
     shapes = [tuple(c.weight.shape) for c in convs]
-    return (ROI_ENABLED and _wino_frozen > 0 and y20.is_cuda and all(t.dtype == torch.float32 for t in (y20, feat1, feat0))
-            and shapes == [(64, 128, 3, 3), (32, 64, 3, 3), (32, 96, 3, 3), (16, 32, 3, 3), (16, 16, 3, 3), (1, 16, 3, 3)]
-            and y20.shape[1] == 64 and feat1.shape[1] == 64 and feat0.shape[1] == 64
-            and y20.shape[2] >= 2 and y20.shape[3] >= 2)
+    return (ROI_ENABLED and _wino_frozen > 0 and x_top.is_cuda and all(t.dtype == torch.float32 for t in (x_top,) + tuple(feats))
+            and shapes == [_ROI_CHANNELS[st[0]] + (3, 3) for st in chain]
+            and x_top.shape[1] == _ROI_CHANNELS["z%d1" % depth][0]
+            and all(f.shape[1] == _ROI_CHANNELS["z%d1" % (k + 1)][1] - _ROI_CHANNELS["z%d1" % (k + 1)][0] for k, f in enumerate(feats))
+            and x_top.shape[2] >= 2 and x_top.shape[3] >= 2)
 
 
-def roi_tail_cost(y20, feat1, feat0, mask, plan, tab, convs):
+def roi_tail_cost(x_top, feats, mask, plan, tab, convs):
     """mean((sigmoid(dispconv0(...)) * mask)^2) of the decoder tail on the windows of ``plan`` (roi.RoiPlan; ``tab`` is
-    its origin table on the device, int32 [len(roi.TABLE), B, 2]).  ``y20``: upconv(2,0)'s output (before its ELU); ``convs``: the six
-    nn.Conv2d modules upconv(2,1), upconv(1,0), upconv(1,1), upconv(0,0), upconv(0,1), dispconv(0).  Equals
-    ops.masked_sq_mean(decoder(...)[("disp", 0)], mask) when the mask is zero outside the plan's boxes."""
-    if not roi_tail_ok(y20, feat1, feat0, convs):
+    its origin table on the device, int32 [len(roi.TABLE), B, 2]).  ``x_top``: upconv(depth,0)'s whole-frame output (before
+    its ELU), depth = plan.depth; ``feats``: encoder features 0 .. depth-1; ``convs``: the nn.Conv2d modules of upconv(depth,1)
+    ... upconv(0,1), dispconv(0) in execution order.  Equals ops.masked_sq_mean(decoder(...)[("disp", 0)], mask) when the
+    mask is zero outside the plan's boxes."""
+    depth = plan.depth
+    feats = tuple(feats)
+    if not roi_tail_ok(x_top, feats, convs, depth):
         raise RuntimeError("roi_tail_cost: needs ops.frozen_weights(), fp32 CUDA tensors and the Monodepth2 decoder tail")
-    if tab.dtype != torch.int32 or tuple(tab.shape) != (len(_ROI_NAMES), y20.shape[0], 2):
+    if tab.dtype != torch.int32 or tuple(tab.shape) != (len(_ROI_NAMES), x_top.shape[0], 2):
         raise RuntimeError("roi_tail_cost: origin table must be int32 [%d, B, 2] (roi.TABLE)" % len(_ROI_NAMES))
     wb = []
     for c in convs:
         wb += [c.weight.detach(), None if c.bias is None else _c(c.bias.detach())]
-    return _RoiTail.apply(_c(y20), _c(feat1), _c(feat0), _c(mask), plan, _c(tab), *wb)
+    return _RoiTail.apply(plan, depth, _c(x_top), *[_c(f) for f in feats], _c(mask), _c(tab), *wb)
 
 
 def _roi_crop(src, gate, g, org, size):

@@ -1,42 +1,53 @@
-"""Window plan of the attack's cropped decoder tail (host side, numpy only).
+"""Window plan of the attack's cropped network passes (host side, numpy only).
 
 The attack's cost is ``-mean((disp * mask)^2)`` (torchattacks/attacks/phy_obj_atk.py:88-97): it reads the disparity under
-the pasted object only.  The last six convolutions of the depth decoder (MD2/networks/depth_decoder.py:51-63 --
-upconv(2,1), upconv(1,0), upconv(1,1), upconv(0,0), upconv(0,1), dispconv(0)) reach two dozen pixels, so inside an attack they are
-evaluated on one window per scene instead of the whole frame.  This module turns the per-scene bounding boxes of the
-pasted object's mask into those windows:
+the pasted object only, and the patch gradient reads ``d cost / d image`` under the object only (physicalTrans.py:156-165).
+A 3x3 convolution reaches one pixel, so inside an attack the depth decoder (MD2/networks/depth_decoder.py:51-63) below its
+first stage is evaluated -- forward and backward, exactly -- on one window per scene instead of the whole frame, and so is the
+backward pass of the encoder's head (conv1 ... layer1, MD2/networks/resnet_encoder.py:85-98).  This module turns the per-scene
+bounding boxes of the pasted object's mask into those windows.  Decoder chain, from the disparity head upwards (STAGES):
 
-    level 0 (H x W)        d    dispconv(0) output           >= the mask's box
-                           z01  upconv(0,1) output           >= d dilated by 1 (what dispconv(0) reads)
-    level 1 (H/2 x W/2)    y00  upconv(0,0) output           >= half of (z01 dilated by 1)
-                           z11  upconv(1,1) output           >= y00 dilated by 1
-    level 2 (H/4 x W/4)    y10  upconv(1,0) output           >= half of (z11 dilated by 1)
-                           z21  upconv(2,1) output           >= y10 dilated by 1
+    level 0 (H x W)        d    dispconv(0) output     >= the mask's box
+                           z01  upconv(0,1) output     >= d dilated by 1 (what dispconv(0) reads)
+    level 1 (H/2 x W/2)    y00  upconv(0,0) output     >= half of (z01 dilated by 1)       (nearest x2 upsampling between them)
+                           z11  upconv(1,1) output     >= y00 dilated by 1
+    level 2                y10, z21        level 3     y20, z31        level 4     y30, z41       ... the same pattern
 
-Every window of a step has the same size for all scenes (the convolution kernels take [B, C, h, w] tensors) and its own
-origin per scene; sizes are even (the Winograd kernels' tiles) and origins even, so that a window's 2 x 2 tiles and its
-nearest-upsampling phase coincide with the full frame's.  A dilated box is clipped to the frame: what lies outside is the
+``depth`` (2, 3 or 4) is the level of the deepest windowed stage: z{depth}1 reads the whole-frame output of upconv(depth,0)
+and encoder feature depth-1.  Every window of a step has the same size for all scenes (the convolution kernels take
+[B, C, h, w] tensors) and its own origin per scene; sizes and origins are even, so that a window's 2 x 2 Winograd tiles and
+its nearest-upsampling phase coincide with the full frame's.  A dilated box is clipped to the frame: what lies outside is the
 reflection padding, which the glue kernel (csrc/roi_glue.hip) takes from inside the window.
 """
 import numpy as np
 
-WINDOWS = ("d", "z01", "y00", "z11", "y10", "z21")
-LEVEL = {"d": 0, "z01": 0, "y00": 1, "z11": 1, "y10": 2, "z21": 2, "r_y20": 3, "r_f1": 2, "r_f0": 1, "gz": 1, "l1": 2}
-_UPSAMPLED_INPUT = ("z01", "z11", "z21")    # the convolution producing these reads the nearest-x2 upsampling of its source
-# rectangles of whole-frame tensors: what the tail reaches of upconv(2,0)'s output, feature 1 and feature 0 (the regions its
-# backward writes), and the encoder head's backward windows: "gz" the gradient of conv1's output that the image window reads,
-# "l1" the common window of layer1's four backward convolutions
-REGIONS = ("r_y20", "r_f1", "r_f0", "gz", "l1")
+# (window, level, its convolution reads an upsampled source, index of the encoder feature concatenated to that source)
+STAGES = (("d", 0, False, None), ("z01", 0, True, None), ("y00", 1, False, None), ("z11", 1, True, 0),
+          ("y10", 2, False, None), ("z21", 2, True, 1), ("y20", 3, False, None), ("z31", 3, True, 2),
+          ("y30", 4, False, None), ("z41", 4, True, 3))
+WINDOWS = tuple(s[0] for s in STAGES)
+LEVEL = {s[0]: s[1] for s in STAGES}
+MAX_DEPTH = 4
+# rectangles of whole-frame tensors.  r_f{k}: what the tail reads of encoder feature k (= the region its backward writes of
+# that feature's gradient); r_y{k}0: what it reads of upconv(k,0)'s whole-frame output when the chain starts at level k;
+# "gz": the gradient of conv1's output that the image window reads; "l1": the common window of layer1's four backward
+# convolutions (encoder head)
+REGIONS = ("r_f0", "r_f1", "r_f2", "r_f3", "r_y20", "r_y30", "r_y40", "gz", "l1")
+LEVEL.update({"r_f0": 1, "r_f1": 2, "r_f2": 3, "r_f3": 4, "r_y20": 3, "r_y30": 4, "r_y40": 5, "gz": 1, "l1": 2})
 TABLE = WINDOWS + REGIONS
-_ROW_ALIGN, _COL_ALIGN = 2, 4
 _L1_RING = 4                                # layer1 = two BasicBlocks = four 3x3 convolutions: each spoils one ring
 
 
-def _fit(lo, hi, frame, align):
-    """One axis: a common even size >= every (hi - lo) + 1 and per-scene even origins with origin <= lo, origin + size >= hi,
-    inside [0, frame]."""
-    need = int((hi - lo).max())
-    size = -(-(need + 1) // align) * align
+def _size_for(need, frame, level, axis):
+    """Common window size along one axis: the smallest even size >= need + 1 (origins are rounded down to even).  Rounding up
+    to whole Winograd regions (4 x 16 tiles = 8 x 32 pixels) was tried: the slack of one level is the need of the next, and
+    three levels up the windows had grown by half; a ragged last region costs less."""
+    return min(-(-(need + 1) // 2) * 2, frame)
+
+
+def _fit(lo, hi, frame, level, axis):
+    """One axis: a common size and per-scene even origins with origin <= lo, origin + size >= hi, inside [0, frame]."""
+    size = _size_for(int((hi - lo).max()), frame, level, axis)
     if size >= frame:
         return frame, np.zeros_like(lo)
     org = np.minimum(lo, frame - size) & ~1
@@ -53,13 +64,16 @@ def _half(lo, hi):
 
 class RoiPlan(object):
     """Windows of one attack step.  ``boxes``: int array [B, 4] = (y0, y1, x0, x1), half-open, in the H x W frame of the
-    disparity.  ``size[name]`` = (rows, columns), ``org[name]`` = int32 [B, 2] for every name in TABLE."""
+    disparity.  ``size[name]`` = (rows, columns), ``org[name]`` = int32 [B, 2] for every name in TABLE; ``depth`` = level of
+    the deepest windowed decoder stage (the windows above it are planned too, and simply unused)."""
 
-    def __init__(self, boxes, H, W):
+    def __init__(self, boxes, H, W, depth=3):
         boxes = np.asarray(boxes, dtype=np.int64).reshape(-1, 4)
-        if H % 8 or W % 8 or H < 16 or W < 16:
-            raise RuntimeError("RoiPlan: frame must be a multiple of 8 and at least 16 x 16")
-        self.H, self.W, self.B = int(H), int(W), boxes.shape[0]
+        if H % 32 or W % 32 or H < 64 or W < 64:
+            raise RuntimeError("RoiPlan: frame must be a multiple of 32 and at least 64 x 64")
+        if depth not in (2, 3, 4):
+            raise RuntimeError("RoiPlan: depth must be 2, 3 or 4")
+        self.H, self.W, self.B, self.depth = int(H), int(W), boxes.shape[0], int(depth)
         self.head_windowed = False      # set by the encoder when its head's backward will run on the windows below
         y0 = np.clip(boxes[:, 0], 0, H - 1)
         y1 = np.clip(boxes[:, 1], y0 + 1, H)
@@ -68,40 +82,44 @@ class RoiPlan(object):
         self.size, self.org = {}, {}
         reads = {}
         ry, rx = (y0, y1), (x0, x1)
-        for name in WINDOWS:
-            lvl = LEVEL[name]
+        for name, lvl, up, skip in STAGES:
             fh, fw = H >> lvl, W >> lvl
-            self._put(name, ry, rx, _ROW_ALIGN, _COL_ALIGN)
+            self._put(name, ry, rx)
             # what the convolution producing this window reads: the window dilated by 1, inside the frame
             (hc, wc), o = self.size[name], self.org[name].astype(np.int64)
             ry = _dilate_clip(o[:, 0], hc, fh)
             rx = _dilate_clip(o[:, 1], wc, fw)
             reads[name] = (ry, rx)
-            if name in _UPSAMPLED_INPUT:    # its input is the nearest-x2 upsampling of the next (coarser) window
+            if up:                      # its input is the nearest-x2 upsampling of the next (coarser) window
                 ry, rx = _half(*ry), _half(*rx)
+                if lvl >= 2:
+                    self._put("r_y%d0" % lvl, ry, rx)
+                if skip is not None and skip >= 1:
+                    self._put("r_f%d" % skip, *reads[name])
         # ---- encoder head (backward only).  The image window is "d" (it holds the box); conv1's 7x7/2 adjoint reads rows
         # Y-1 .. Y+2 of its output gradient for image rows 2Y, 2Y+1
         (hd, wd), od = self.size["d"], self.org["d"].astype(np.int64)
         gy = np.maximum((od[:, 0] >> 1) - 1, 0), np.minimum(((od[:, 0] + hd) >> 1) + 2, H >> 1)
         gx = np.maximum((od[:, 1] >> 1) - 1, 0), np.minimum(((od[:, 1] + wd) >> 1) + 2, W >> 1)
-        self._put("gz", gy, gx, _ROW_ALIGN, _COL_ALIGN)
+        self._put("gz", gy, gx)
         (hs, ws), os_ = self.size["gz"], self.org["gz"].astype(np.int64)
         # pooling cells that cover rows [a, b) of the 1/2 map: a >> 1 .. b >> 1; layer1's four convolutions spoil four rings
         qy = np.maximum((os_[:, 0] >> 1) - _L1_RING, 0), np.minimum(((os_[:, 0] + hs) >> 1) + 1 + _L1_RING, H >> 2)
         qx = np.maximum((os_[:, 1] >> 1) - _L1_RING, 0), np.minimum(((os_[:, 1] + ws) >> 1) + 1 + _L1_RING, W >> 2)
-        self._put("l1", qy, qx, 4, 16)
-        # ---- regions of the whole-frame sources the tail's backward writes
-        self._put("r_y20", *(_half(*reads["z21"][0]), _half(*reads["z21"][1])), 2, 2)
-        self._put("r_f1", reads["z21"][0], reads["z21"][1], 2, 2)
-        # feature 0's gradient is read by the encoder head on "gz": the written rectangle holds both
+        hq = min(-(-(int((qy[1] - qy[0]).max()) + 1) // 8) * 8, H >> 2)      # same-size convolutions: whole 4 x 16-tile regions
+        wq = min(-(-(int((qx[1] - qx[0]).max()) + 1) // 32) * 32, W >> 2)
+        self.size["l1"] = (int(hq), int(wq))
+        self.org["l1"] = np.stack([np.minimum(qy[0], (H >> 2) - hq) & ~1, np.minimum(qx[0], (W >> 2) - wq) & ~1], 1).astype(np.int32)
+        # feature 0's gradient is read by the encoder head on "gz": the rectangle the tail writes holds both
         fy = np.minimum(reads["z11"][0][0], os_[:, 0]), np.maximum(reads["z11"][0][1], os_[:, 0] + hs)
         fx = np.minimum(reads["z11"][1][0], os_[:, 1]), np.maximum(reads["z11"][1][1], os_[:, 1] + ws)
-        self._put("r_f0", fy, fx, 2, 2)
+        self._put("r_f0", fy, fx)
 
-    def _put(self, name, ry, rx, row_align, col_align):
+    def _put(self, name, ry, rx):
         lvl = LEVEL[name]
-        hc, oy = _fit(ry[0], ry[1], self.H >> lvl, row_align)
-        wc, ox = _fit(rx[0], rx[1], self.W >> lvl, col_align)
+        align_lvl = 0 if name.startswith("r_") or name == "gz" else lvl      # plain rectangles: no tile alignment wanted
+        hc, oy = _fit(ry[0], ry[1], self.H >> lvl, align_lvl, 0)
+        wc, ox = _fit(rx[0], rx[1], self.W >> lvl, align_lvl, 1)
         self.size[name] = (int(hc), int(wc))
         self.org[name] = np.stack([oy, ox], 1).astype(np.int32)
 

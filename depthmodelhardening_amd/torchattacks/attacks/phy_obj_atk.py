@@ -111,7 +111,7 @@ class Phy_obj_atk(Attack):
         # around the object (DepthModelWrapper.masked_sq_mean: exact) gets the per-step boxes, all tables in one H2D copy
         plans = tabs = None
         if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
-            plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size) for z0, al in draws]
+            plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
 
         for s in range(self.steps):

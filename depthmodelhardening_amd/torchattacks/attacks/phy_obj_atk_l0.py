@@ -95,7 +95,7 @@ class Phy_obj_atk_l0(Attack):
         # the adversarial cost reads the disparity under the object only: see Phy_obj_atk.forward
         plans = tabs = None
         if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
-            plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size) for z0, al in draws]
+            plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
         thresh = torch.full((), float(self.l0_thresh), device=self.device)      # fill kernels: no host sync
         w_on = torch.full((), float(self.mask_weight_init), device=self.device)

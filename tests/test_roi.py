@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from depthmodelhardening_amd.roi import LEVEL, TABLE, WINDOWS, RoiPlan, mask_box
+from depthmodelhardening_amd.roi import LEVEL, STAGES, TABLE, WINDOWS, RoiPlan, mask_box
 
 H, W = 320, 1024
 
@@ -47,14 +47,16 @@ def test_plan_covers_every_read_for_all_training_poses():
         d = plan.org["d"]
         assert (d[:, 0] <= boxes[:, 0]).all() and (d[:, 0] + plan.size["d"][0] >= boxes[:, 1]).all()
         assert (d[:, 1] <= boxes[:, 2]).all() and (d[:, 1] + plan.size["d"][1] >= boxes[:, 3]).all()
-        chain = [("z01", "d", False), ("y00", "z01", True), ("z11", "y00", False), ("y10", "z11", True), ("z21", "y10", False)]
+        chain = [(STAGES[k + 1][0], STAGES[k][0], STAGES[k][2]) for k in range(len(STAGES) - 1)]
+        assert chain[:3] == [("z01", "d", False), ("y00", "z01", True), ("z11", "y00", False)] and len(chain) == 9
         for src, dst, halve in chain:
             for ax, frame in ((0, H >> LEVEL[dst]), (1, W >> LEVEL[dst])):
                 assert _covers(plan.org[src][:, ax], plan.size[src][ax], plan.org[dst][:, ax], plan.size[dst][ax], frame,
                                halve), (trial, src, dst, ax)
         assert plan.table().shape == (len(TABLE), 12, 2) and plan.table().dtype == np.int32
         # regions of the whole-frame sources hold what the tail reads of them; the encoder head's windows hold what it reads
-        for reg, dst, halve in (("r_y20", "z21", True), ("r_f1", "z21", False), ("r_f0", "z11", False)):
+        for reg, dst, halve in (("r_y20", "z21", True), ("r_f1", "z21", False), ("r_f0", "z11", False), ("r_y30", "z31", True),
+                                ("r_f2", "z31", False), ("r_y40", "z41", True), ("r_f3", "z41", False)):
             for ax, frame in ((0, H >> LEVEL[dst]), (1, W >> LEVEL[dst])):
                 assert _covers(plan.org[reg][:, ax], plan.size[reg][ax], plan.org[dst][:, ax], plan.size[dst][ax], frame, halve)
         for ax, (fd, fs, fq) in enumerate(((H, H >> 1, H >> 2), (W, W >> 1, W >> 2))):
@@ -224,21 +226,25 @@ def test_windowed_attack_step_equals_the_full_frame_step():
                 poses = [grid[i] for i in rng.choice(len(grid), 12, replace=False)]
             z0, al = [p[0] for p in poses], [p[1] for p in poses]
             coeffs = to_device_async(pt.coeffs_for(z0, al), dev)
-            plan = RoiPlan(pt.mask_boxes(z0, al, (H, W)), H, W)
-            tab = to_device_async(plan.table(), dev)
             res = []
-            for use_plan in (False, True):
+            for depth in (None, 2, 3, 4):
+                plan = tab = None
+                if depth is not None:
+                    plan = RoiPlan(pt.mask_boxes(z0, al, (H, W)), H, W, depth=depth)
+                    tab = to_device_async(plan.table(), dev)
                 patch = obj.clone().requires_grad_(True)
                 adv, m = ops.eot_paste(scenes, patch, pmask, coeffs, pt.l_pad, pt.t_pad, (H, W))
-                cost = -(model.masked_sq_mean(adv, m, plan, tab) if use_plan else ops.masked_sq_mean(model(adv), m))
+                cost = -(model.masked_sq_mean(adv, m, plan, tab) if plan is not None else ops.masked_sq_mean(model(adv), m))
                 (grad,) = torch.autograd.grad(cost, patch)
                 res.append((cost.detach().double().cpu(), grad.detach().double().cpu()))
-            (c0, g0), (c1, g1) = res
-            worst_c = max(worst_c, abs(float(c1 - c0)) / abs(float(c0)))
-            worst_g = max(worst_g, float((g1 - g0).norm() / g0.norm()))
+                assert plan is None or plan.head_windowed
+            c0, g0 = res[0]
             assert float(g0.abs().max()) > 0
-            # element-wise: the same convolution arithmetic on the same tiles, only the reduction of the cost differs
-            assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()), trial
+            for c1, g1 in res[1:]:
+                worst_c = max(worst_c, abs(float(c1 - c0)) / abs(float(c0)))
+                worst_g = max(worst_g, float((g1 - g0).norm() / g0.norm()))
+                # element-wise: the same convolution arithmetic on the same tiles, only the reduction of the cost differs
+                assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()), trial
     print("windowed vs full frame: cost rel %.3g, patch gradient rel-L2 %.3g" % (worst_c, worst_g))
     assert worst_c <= 1e-6 and worst_g <= 1e-6
 
