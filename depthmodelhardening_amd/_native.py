@@ -89,7 +89,9 @@ _SIGNATURES = {
     "dmh_elu_pad_bwd": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_roi_glue_fwd": (C.c_int, [C.POINTER(RoiGlueArgs), _fp, _fp]),
     "dmh_roi_glue_bwd": (C.c_int, [C.POINTER(RoiGlueArgs), _fp, _fp, _fp, _fp, C.c_int, C.c_int, _fp, C.c_int, C.c_int, _fp]),
-    "dmh_roi_crop": (C.c_int, [_fp] * 4 + [C.c_int] * 6 + [_fp, _fp]),
+    "dmh_roi_crop": (C.c_int, [_fp] * 4 + [C.c_int] * 7 + [_fp, _fp]),
+    "dmh_roi_paste": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp] + [C.c_int] * 6 + [_fp, _fp]),
+    "dmh_stem_conv_norm_fwd_win": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 5 + [C.c_float, C.c_float, _fp, _fp]),
     "dmh_stem_bn_relu_pool_bwd_win": (C.c_int, [_fp] * 7 + [C.c_int] * 8 + [_fp, _fp]),
     "dmh_conv7x7s2_bwd_data_win": (C.c_int, [_fp] * 4 + [C.c_int] * 9 + [_fp, _fp]),
     "dmh_roi_cost_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

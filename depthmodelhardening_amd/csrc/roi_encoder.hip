@@ -9,6 +9,7 @@
 //
 //   roi_crop      out[b, c, i, j] = src[b, c, org_b + (i, j)]  (* [gate > 0])     compact windows of whole-frame tensors
 //   roi_mask      out = g * [gate[b, c, org_b + (i, j)] > 0]                      ReLU mask of a compact gradient
+//   roi_paste     dst[b, c, win_b + (i, j)] = src[...]                            a window written back into a whole-frame tensor
 //   stem_bwd_win  g_z = scale[c] [feat > 0] (g_feat + maxpool3x3/2 adjoint of g_pool)   on a window of the 1/2-resolution map,
 //                 g_pool given as a compact window of the 1/4-resolution map      (encoder_glue.hip: stem_bwd_kernel)
 #include "common.hpp"
@@ -19,7 +20,8 @@ namespace {
 
 constexpr int NT = 256;
 
-// mode 0: crop src; 1: crop src and mask by gate's window; 2: mask the compact g by gate's window
+// mode 0: crop src; 1: crop src and mask by gate's window; 2: mask the compact g by gate's window; +4: gate is itself a
+// compact window (same origin and size)
 __global__ __launch_bounds__(NT) void roi_crop_kernel(const float* __restrict__ src, const float* __restrict__ gate,
                                                       const float* __restrict__ g, const int* __restrict__ org, int C, int H,
                                                       int W, int hc, int wc, int mode, float* __restrict__ out) {
@@ -30,14 +32,28 @@ __global__ __launch_bounds__(NT) void roi_crop_kernel(const float* __restrict__ 
     const size_t so = ((size_t)plane * H + org[2 * b] + i) * W + org[2 * b + 1] + j;      // even: 8-byte aligned
     const size_t co = (size_t)plane * hc * wc + t;
     float2 v;
-    if (mode == 2) v = *reinterpret_cast<const float2*>(g + co);
+    if ((mode & 3) == 2) v = *reinterpret_cast<const float2*>(g + co);
     else v = *reinterpret_cast<const float2*>(src + so);
-    if (mode != 0) {
-        const float2 q = *reinterpret_cast<const float2*>(gate + so);
+    if ((mode & 3) != 0) {
+        const float2 q = *reinterpret_cast<const float2*>(gate + ((mode & 4) ? co : so));
         v.x = q.x > 0.f ? v.x : 0.f;
         v.y = q.y > 0.f ? v.y : 0.f;
     }
     *reinterpret_cast<float2*>(out + co) = v;
+}
+
+// dst[b, c, win_b + (i, j)] = src[...] for the h x w window at frame position win_org: src is a compact [B,C,sh,sw] window at
+// frame origin src_org, or (src_org == NULL) a whole-frame tensor like dst
+__global__ __launch_bounds__(NT) void roi_paste_kernel(const float* __restrict__ src, const int* __restrict__ src_org, int sh,
+                                                       int sw, const int* __restrict__ win_org, int C, int H, int W, int h,
+                                                       int w, float* __restrict__ dst) {
+    const int t = blockIdx.x * NT + threadIdx.x;
+    if (t >= h * w) return;
+    const int plane = blockIdx.y, b = plane / C;
+    const int i = t / w, j = t - i * w;
+    const int Y = win_org[2 * b] + i, X = win_org[2 * b + 1] + j;
+    const int sy = Y - (src_org ? src_org[2 * b] : 0), sx = X - (src_org ? src_org[2 * b + 1] : 0);
+    dst[((size_t)plane * H + Y) * W + X] = src[((size_t)plane * sh + sy) * sw + sx];
 }
 
 // one thread = one 2 x 2 quad of the window of the H x W map (quad (i, j) = rows 2i, 2i+1: aligned with pooling cell (i, j))
@@ -100,14 +116,25 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + NT - 1) / NT); }
 
 extern "C" {
 
+int dmh_roi_paste(const float* src, const int* src_org, int sh, int sw, const int* win_org, int B, int C, int H, int W, int h,
+                  int w, float* dst, void* stream) {
+    DMH_REQUIRE(src && win_org && dst, "null pointer");
+    DMH_REQUIRE(B > 0 && C > 0 && (int64_t)B * C <= 65535 && h >= 1 && w >= 1 && h <= H && w <= W && (int64_t)H * W < (1 << 30),
+                "bad sizes (window inside the frame)");
+    DMH_REQUIRE(src_org ? (h <= sh && w <= sw) : (sh == H && sw == W), "the source must hold the window");
+    hipLaunchKernelGGL(roi_paste_kernel, dim3(blocks_for((int64_t)h * w), B * C), dim3(NT), 0, (hipStream_t)stream, src, src_org,
+                       sh, sw, win_org, C, H, W, h, w, dst);
+    return check_launch("dmh_roi_paste");
+}
+
 int dmh_roi_crop(const float* src, const float* gate, const float* g, const int* org, int B, int C, int H, int W, int hc,
-                 int wc, float* out, void* stream) {
+                 int wc, int gate_compact, float* out, void* stream) {
     DMH_REQUIRE(org && out && (src || (g && gate)), "null pointer");
     DMH_REQUIRE(!(src && g), "give either a whole-frame src or a compact g");
     DMH_REQUIRE(B > 0 && C > 0 && (int64_t)B * C <= 65535 && hc >= 1 && wc >= 2 && (wc & 1) == 0 && (W & 1) == 0 && hc <= H &&
                     wc <= W && (int64_t)H * W < (1 << 30),
                 "bad sizes (window inside the frame, even widths)");
-    const int mode = g ? 2 : (gate ? 1 : 0);
+    const int mode = (g ? 2 : (gate ? 1 : 0)) | ((gate && gate_compact) ? 4 : 0);
     hipLaunchKernelGGL(roi_crop_kernel, dim3(blocks_for((int64_t)hc * wc / 2), B * C), dim3(NT), 0, (hipStream_t)stream, src,
                        gate, g, org, C, H, W, hc, wc, mode, out);
     return check_launch("dmh_roi_crop");

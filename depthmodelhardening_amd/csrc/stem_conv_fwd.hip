@@ -55,6 +55,10 @@ struct SArgs {
     float* y;
     int B, H, W, Ho, Wo, gx, gy, ntiles;
     float mean, inv_std;
+    // window form (K19): only the hw x ww window of the Ho x Wo output at the per-sample origin org [B,2] is computed, into
+    // a compact [B,64,hw,ww] tensor; org == NULL: the whole output
+    const int* org;
+    int hw, ww;
 };
 
 __global__ __launch_bounds__(NT, 2) void stem_conv_fwd_kernel(const SArgs a) {
@@ -77,13 +81,14 @@ __global__ __launch_bounds__(NT, 2) void stem_conv_fwd_kernel(const SArgs a) {
     const float* b1 = tile + base + (h ? RW : 0);
     const float* b2 = tile + base + (h ? PLANE : 0);
 
-    const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.Ho * a.Wo;
+    const size_t HW = (size_t)a.H * a.W, HWo = (size_t)a.hw * a.ww;
     for (int t = blockIdx.x; t < a.ntiles; t += gridDim.x) {
         int q = t;
         const int bxi = q % a.gx;  q /= a.gx;
         const int byi = q % a.gy;
         const int b = q / a.gy;
-        const int oy0 = byi * TR, ox0 = bxi * TC;
+        const int wy0 = a.org ? a.org[2 * b] : 0, wx0 = a.org ? a.org[2 * b + 1] : 0;
+        const int oy0 = wy0 + byi * TR, ox0 = wx0 + bxi * TC;
         const int iy0 = 2 * oy0 - 3, ix0 = 2 * ox0 - 3;
         const float* xb = a.x + (size_t)b * 3 * HW;
         __syncthreads();                              // the previous tile's reads are done
@@ -108,9 +113,9 @@ __global__ __launch_bounds__(NT, 2) void stem_conv_fwd_kernel(const SArgs a) {
             accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wB[j], bv, accB, 0, 0, 0);
         }
         // D[i][n]: lane holds column n, rows i = 8*(v/4) + 4*h + v%4
-        const int oy = oy0 + wv, ox = ox0 + n;
-        if (oy < a.Ho && ox < a.Wo) {
-            float* yb = a.y + (size_t)b * 64 * HWo + (size_t)oy * a.Wo + ox;
+        const int oy = oy0 + wv - wy0, ox = ox0 + n - wx0;        // inside the (compact) output plane
+        if (oy < a.hw && ox < a.ww) {
+            float* yb = a.y + (size_t)b * 64 * HWo + (size_t)oy * a.ww + ox;
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int i = 8 * (v >> 2) + 4 * h + (v & 3);
@@ -125,12 +130,8 @@ __global__ __launch_bounds__(NT, 2) void stem_conv_fwd_kernel(const SArgs a) {
 
 extern "C" {
 
-int dmh_stem_conv_norm_fwd(const float* x, const float* w, int B, int H, int W, float mean, float std, float* y,
-                           void* stream) {
-    DMH_REQUIRE(x && w && y, "null pointer");
-    DMH_REQUIRE(B > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "image height and width must be even");
-    DMH_REQUIRE(std > 0.f, "std must be positive");
-    DMH_REQUIRE((int64_t)B * 64 * (H / 2) * (W / 2) < ((int64_t)1 << 40), "tensor too large");
+static int launch_stem_fwd(const float* x, const float* w, const int* org, int B, int H, int W, int hw, int ww, float mean,
+                           float std, float* y, void* stream, const char* fn) {
     SArgs a;
     a.x = x;
     a.w = w;
@@ -140,16 +141,37 @@ int dmh_stem_conv_norm_fwd(const float* x, const float* w, int B, int H, int W, 
     a.W = W;
     a.Ho = H / 2;
     a.Wo = W / 2;
-    a.gx = (a.Wo + TC - 1) / TC;
-    a.gy = (a.Ho + TR - 1) / TR;
+    a.org = org;
+    a.hw = hw;
+    a.ww = ww;
+    a.gx = (ww + TC - 1) / TC;
+    a.gy = (hw + TR - 1) / TR;
     const long long tiles = (long long)B * a.gx * a.gy;
-    DMH_REQUIRE(tiles < (1ll << 31), "grid too large");
+    if (tiles >= (1ll << 31)) return fail(DMH_EINVAL, "%s: grid too large", fn);
     a.ntiles = (int)tiles;
     a.mean = mean;
     a.inv_std = 1.0f / std;
     const int blocks = (int)(tiles < 512 ? tiles : 512);        // 2 workgroups per CU, persistent over the tiles
     hipLaunchKernelGGL(stem_conv_fwd_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, a);
-    return check_launch("dmh_stem_conv_norm_fwd");
+    return check_launch(fn);
+}
+
+int dmh_stem_conv_norm_fwd(const float* x, const float* w, int B, int H, int W, float mean, float std, float* y,
+                           void* stream) {
+    DMH_REQUIRE(x && w && y, "null pointer");
+    DMH_REQUIRE(B > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "image height and width must be even");
+    DMH_REQUIRE(std > 0.f, "std must be positive");
+    DMH_REQUIRE((int64_t)B * 64 * (H / 2) * (W / 2) < ((int64_t)1 << 40), "tensor too large");
+    return launch_stem_fwd(x, w, nullptr, B, H, W, H / 2, W / 2, mean, std, y, stream, "dmh_stem_conv_norm_fwd");
+}
+
+int dmh_stem_conv_norm_fwd_win(const float* x, const float* w, const int* org, int B, int H, int W, int hw, int ww, float mean,
+                               float std, float* y, void* stream) {
+    DMH_REQUIRE(x && w && y && org, "null pointer");
+    DMH_REQUIRE(B > 0 && H >= 2 && W >= 2 && (H & 1) == 0 && (W & 1) == 0, "image height and width must be even");
+    DMH_REQUIRE(std > 0.f, "std must be positive");
+    DMH_REQUIRE(hw >= 1 && ww >= 1 && hw <= H / 2 && ww <= W / 2, "the window must lie inside the H/2 x W/2 output");
+    return launch_stem_fwd(x, w, org, B, H, W, hw, ww, mean, std, y, stream, "dmh_stem_conv_norm_fwd_win");
 }
 
 }  // extern "C"

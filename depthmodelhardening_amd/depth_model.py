@@ -22,19 +22,21 @@ class DepthModelWrapper(torch.nn.Module):
         return self.decoder(feats)[("disp", 0)]
 
 
-    def masked_sq_mean(self, input_image, mask, plan=None, tab=None):
+    def masked_sq_mean(self, input_image, mask, plan=None, tab=None, clean=None):
         """mean((disp_0(input_image) * mask)^2): the cost every object attack maximises (phy_obj_atk.py:92-94,
         phy_obj_atk_l0.py:125-127).  With a window plan (roi.RoiPlan + its device table) around the pasted object, and a
-        decoder that supports it, the decoder's high-resolution tail runs on the windows only."""
+        decoder that supports it, the decoder below its first stage and the encoder head's backward run on the windows only;
+        with ``clean`` (the same frames without the object: input_image equals it outside the plan's boxes) the encoder
+        head's forward does too."""
         from . import ops
         roi_dec = plan is not None and hasattr(self.decoder, "roi_ok")
         if roi_dec and getattr(self.encoder, "roi_backward", False):
-            feats = self.encoder(input_image, roi=(plan, tab))
+            feats = self.encoder(input_image, roi=(plan, tab), clean=clean)
         else:
             feats = self.encoder(input_image)
-        if roi_dec and self.decoder.roi_ok(feats, plan.depth):
+        if roi_dec and self.decoder.roi_ok(feats, plan):
             return self.decoder.masked_sq_mean(feats, mask, plan, tab)
-        if plan is not None and getattr(plan, "head_windowed", False):
+        if plan is not None and (plan.head_windowed or plan.f0_compact):
             raise RuntimeError("masked_sq_mean: the encoder ran its windowed head but the decoder cannot take the plan")
         if feats[-1].is_cuda and hasattr(self.decoder, "_forward_fused"):
             disp = self.decoder(feats, only_scales=(0,))[("disp", 0)]

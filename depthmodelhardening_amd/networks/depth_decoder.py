@@ -60,17 +60,20 @@ class DepthDecoder(nn.Module):
                 self.outputs[("disp", i)] = self.sigmoid(conv(self.convs[("dispconv", i)], p))
         return self.outputs
 
-    def roi_ok(self, input_features, depth=None):
-        """The attack's windowed cost (ops.roi_tail_cost) applies to these features: the fused CUDA path, scale 0 among
-        the heads, the reference's channel plan."""
+    def roi_ok(self, input_features, plan):
+        """The attack's windowed cost (ops.roi_tail_cost) applies to these features under ``plan`` (roi.RoiPlan): the fused
+        CUDA path, scale 0 among the heads, the reference's channel plan, the frame sizes of a five-level pyramid (feature 0
+        may be its compact "hz" window: plan.f0_compact)."""
         from .. import ops
-        depth = ops.ROI_DEPTH if depth is None else depth
+        depth = plan.depth
         if not (input_features[-1].is_cuda and self.use_skips and self.upsample_mode == 'nearest' and 0 in self.scales
                 and len(input_features) == 5 and self.num_output_channels == 1 and depth in (2, 3, 4)):
             return False
+        h1, w1 = plan.H >> 2, plan.W >> 2
+        if any(tuple(f.shape[2:]) != (h1 >> (k - 1), w1 >> (k - 1)) for k, f in enumerate(input_features) if k >= 1):
+            return False
         f0 = input_features[0]
-        if f0.shape[2] % 16 or f0.shape[3] % 16 or any(tuple(f.shape[2:]) != (f0.shape[2] >> k, f0.shape[3] >> k)
-                                                       for k, f in enumerate(input_features)):
+        if tuple(f0.shape[2:]) != (plan.size["hz"] if plan.f0_compact else (2 * h1, 2 * w1)):
             return False
         top = input_features[depth]     # stands in for upconv(depth,0)'s output: same size as feature `depth`
         return ops.roi_tail_ok(top.new_empty((1, int(self.num_ch_dec[depth])) + tuple(top.shape[2:])),

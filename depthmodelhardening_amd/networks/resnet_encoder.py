@@ -10,6 +10,8 @@ the convolutions (BatchNorm with running statistics, identity add, ReLU, the ste
 kernels of libdmh_hip (``ops.bn_act``, ``ops.stem_bn_relu_pool``); train() mode and CPU tensors take the module
 path below, which is the reference's.  ``ResNet.fuse_eval_bn = False`` switches the fused path off.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -232,6 +234,7 @@ class ResnetEncoder(nn.Module):
         block, layers = _CONFIGS[num_layers]
         self.encoder = ResNet(block, layers, num_input_images)
         self.roi_backward = True    # forward(x, roi=...) may run the head's backward on the attack's windows (ops.encoder_head_eval)
+        self.roi_incremental = os.environ.get("DMH_ROI_INCREMENTAL", "1") != "0"     # ... and, given the clean frames, its forward
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
@@ -246,12 +249,15 @@ class ResnetEncoder(nn.Module):
             return ops.stem_conv_norm(input_image, c.weight, 0.45, 0.225)
         return self._conv1((input_image - 0.45) / 0.225)
 
-    def forward(self, input_image, roi=None):
+    def forward(self, input_image, roi=None, clean=None):
         """``roi`` = (roi.RoiPlan, its device table): the caller (an object attack, DepthModelWrapper.masked_sq_mean) reads
-        d / d input_image inside the plan's image window only, so the head's backward may run on the plan's windows."""
+        d / d input_image inside the plan's image window only, so the head's backward may run on the plan's windows.
+        ``clean`` [B,3,H,W]: the same frames without the pasted object -- input_image equals it outside the plan's boxes --
+        so the head's FORWARD may run on windows too, on top of the clean frames' cached feature (ops.encoder_head_incremental;
+        the cache lives as long as the enclosing ops.frozen_weights() scope, i.e. one attack)."""
         e = self.encoder
         if e.fused_eval_ok(input_image):
-            self.features = self._forward_fused_eval(input_image, roi)
+            self.features = self._forward_fused_eval(input_image, roi, clean)
             return self.features
         z = self._stem(input_image)
         if _train_fused(e.bn1, z) and z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
@@ -281,7 +287,7 @@ class ResnetEncoder(nn.Module):
             return None
         return [(b.conv1.weight, aff[b.bn1], b.conv2.weight, aff[b.bn2]) for b in l1]
 
-    def _forward_fused_eval(self, input_image, roi=None):
+    def _forward_fused_eval(self, input_image, roi=None, clean=None):
         e = self.encoder
         aff = e.eval_affine()
         layers = (e.layer1, e.layer2, e.layer3, e.layer4)
@@ -291,8 +297,15 @@ class ResnetEncoder(nn.Module):
             c = e.conv1
             if (blocks is not None and c.stride == (2, 2) and c.padding == (3, 3) and c.dilation == (1, 1) and c.groups == 1
                     and c.bias is None and ops.encoder_head_ok(input_image, c.weight, [(b[0], b[2]) for b in blocks])):
-                # the attack's encoder head: one node, backward on the plan's windows (K19)
-                f0, y = ops.encoder_head_eval(input_image, roi[0], roi[1], c.weight, aff[e.bn1], blocks)
+                if (clean is not None and self.roi_incremental and ops.weights_frozen() and roi[0].head_incremental_ok
+                        and clean.shape == input_image.shape and clean.is_cuda and clean.dtype == torch.float32):
+                    # forward AND backward of the head on one window per scene, on top of the clean frames' feature 1
+                    cache = ops.frozen_memo(("clean_head", id(self), clean.data_ptr(), clean._version),
+                                            lambda: ops.clean_head(clean, c.weight, aff[e.bn1], blocks))
+                    f0, y = ops.encoder_head_incremental(input_image, roi[0], roi[1], cache, c.weight, aff[e.bn1], blocks)
+                else:
+                    # the attack's encoder head: one node, backward on the plan's windows (K19)
+                    f0, y = ops.encoder_head_eval(input_image, roi[0], roi[1], c.weight, aff[e.bn1], blocks)
                 feats, layers = [f0, y], layers[1:]
         if feats is None:
             z = self._stem(input_image)

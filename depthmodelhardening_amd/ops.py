@@ -1569,7 +1569,7 @@ def _roi_glue_bwd(a, g_out, device, want_skip, y_region=None, skip_region=None, 
 
 from .roi import STAGES as _ROI_STAGES, TABLE as _ROI_NAMES     # noqa: E402  (row order of the device table of origins)
 
-ROI_DEPTH = int(os.environ.get("DMH_ROI_DEPTH", "3"))      # level of the deepest windowed decoder stage (2, 3 or 4)
+ROI_DEPTH = int(os.environ.get("DMH_ROI_DEPTH", "4"))      # level of the deepest windowed decoder stage (2, 3 or 4)
 # channel plan of the reference decoder's stages (MD2/networks/depth_decoder.py:22-37), by window name: (out, in)
 _ROI_CHANNELS = {"d": (1, 16), "z01": (16, 16), "y00": (16, 32), "z11": (32, 96), "y10": (32, 64), "z21": (64, 128),
                  "y20": (64, 128), "z31": (128, 256), "y30": (128, 256), "z41": (256, 512)}
@@ -1589,10 +1589,11 @@ class _RoiTail(torch.autograd.Function):
     (weight, bias) per stage in execution order."""
 
     @staticmethod
-    def _glue(chain, k, src, feats, org, sz, H0, W0):
+    def _glue(chain, k, src, feats, org, sz, H0, W0, f0_compact):
         name, lvl, up, skip = chain[k]
         src_org = None if k == 0 else org[chain[k - 1][0]]
-        return _roi_glue_args(src, src_org, None if skip is None else feats[skip], None, org[name], sz[name],
+        skip_org = org["hz"] if (skip == 0 and f0_compact) else None      # feature 0 handed on as its "hz" window only
+        return _roi_glue_args(src, src_org, None if skip is None else feats[skip], skip_org, org[name], sz[name],
                               (H0 >> lvl, W0 >> lvl), up, 1)
 
     @staticmethod
@@ -1604,14 +1605,16 @@ class _RoiTail(torch.autograd.Function):
         chain = _roi_chain(depth)
         B = x_top.shape[0]
         H0, W0 = x_top.shape[2] << (depth + 1), x_top.shape[3] << (depth + 1)
-        if (any(tuple(f.shape[2:]) != (H0 >> (k + 1), W0 >> (k + 1)) for k, f in enumerate(feats))
+        f0c = bool(plan.f0_compact)
+        if (any(tuple(f.shape[2:]) != ((H0 >> (k + 1), W0 >> (k + 1)) if (k or not f0c) else plan.size["hz"])
+                for k, f in enumerate(feats))
                 or tuple(mask.shape) != (B, 1, H0, W0) or plan.B != B or (plan.H, plan.W) != (H0, W0)):
             raise RuntimeError("roi tail: feature / mask / plan shapes do not match")
         org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
         sz = plan.size
         outs, src = [], x_top
         for k in range(len(chain)):
-            a = _RoiTail._glue(chain, k, src, feats, org, sz, H0, W0)
+            a = _RoiTail._glue(chain, k, src, feats, org, sz, H0, W0, f0c)
             src = _conv_any(_roi_glue_fwd(a, dev), wb[2 * k], wb[2 * k + 1], 0)
             outs.append(src)
         d_pre = outs.pop()
@@ -1622,7 +1625,7 @@ class _RoiTail(torch.autograd.Function):
         N.check(lib.dmh_roi_cost_fwd(N.ptr(d_pre), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, H0, W0, N.ptr(sig),
                                      N.ptr(part), N.ptr(cost), N.stream()))
         ctx.save_for_backward(x_top, mask, tab, sig, *feats, *outs, *wb[0::2])
-        ctx.plan, ctx.depth = plan, depth
+        ctx.plan, ctx.depth, ctx.f0c = plan, depth, f0c
         return cost
 
     @staticmethod
@@ -1647,10 +1650,10 @@ class _RoiTail(torch.autograd.Function):
         for k in range(n - 1, -1, -1):
             name, lvl, up, skip = chain[k]
             src = x_top if k == 0 else outs[k - 1]
-            a = _RoiTail._glue(chain, k, src, feats, org, sz, H0, W0)
+            a = _RoiTail._glue(chain, k, src, feats, org, sz, H0, W0, ctx.f0c)
             want_skip = skip is not None and ctx.needs_input_grad[3 + skip]
             y_reg = ("r_y%d0" % lvl) if k == 0 else None
-            s_reg = None if skip is None else "r_f%d" % skip
+            s_reg = None if (skip is None or (skip == 0 and ctx.f0c)) else "r_f%d" % skip      # a compact feature: all of it
             # feature 0's gradient is zero outside "r_f0"; an encoder head that runs its backward on the plan's windows reads
             # it inside that rectangle only, so the rest of the 252 MB tensor is not even zero-filled then
             g_cur, g_skip = _roi_glue_bwd(a, _conv_any(g_cur, ws[k], None, 2, True), dev, want_skip,
@@ -1700,7 +1703,7 @@ def _roi_crop(src, gate, g, org, size):
     B, Cc, H, W = ref.shape
     out = torch.empty((B, Cc) + tuple(size), device=ref.device, dtype=torch.float32)
     N.check(_timed("roi_crop", lambda: N.lib().dmh_roi_crop(N.ptr(src), N.ptr(gate), N.ptr(g), N.ptr(org), B, Cc, H, W, size[0],
-                                                           size[1], N.ptr(out), N.stream()),
+                                                           size[1], 0, N.ptr(out), N.stream()),
                    4 * out.numel() * (2 + (gate is not None))))
     return out
 
@@ -1818,6 +1821,156 @@ def encoder_head_eval(x, plan, tab, conv1_weight, aff0, blocks):
         args += [w1.detach(), d(a1[0]), d(a1[1]), w2.detach(), d(a2[0]), d(a2[1])]
     plan.head_windowed = True
     return _EncHeadEval.apply(_c(x), plan, _c(tab), *args)
+
+
+class CleanHead(object):
+    """What the incremental encoder head keeps of the CLEAN scenes for the length of one attack: encoder feature 1 (layer1's
+    output) of the un-pasted frames, twice -- ``pristine`` is never written; ``work`` is the tensor handed to the rest of the
+    network, into which each attack step writes the cells the pasted object changes ("f1s") and puts the clean values back
+    before the next step."""
+
+    def __init__(self, f1):
+        self.pristine, self.work = f1, f1.clone()
+        self.dirty = None           # (origin table [B,2], (rows, cols)) of the window written by the last step
+
+    def restore(self):
+        if self.dirty is not None:
+            org, (h, w) = self.dirty
+            B, Cc, H, W = self.work.shape
+            N.check(N.lib().dmh_roi_paste(N.ptr(self.pristine), None, H, W, N.ptr(org), B, Cc, H, W, h, w, N.ptr(self.work),
+                                          N.stream()))
+            self.dirty = None
+
+
+class _EncHeadInc(torch.autograd.Function):
+    """The encoder head of an attack step, incrementally: the pasted scene differs from the clean scene inside the object's
+    box only (physicalTrans.py:156-165), so conv1 -> bn1 -> relu -> maxpool -> layer1 (MD2/networks/resnet_encoder.py:85-98)
+    are evaluated on ONE compact window per scene ("hz" on the 1/2 map, "hl" on the 1/4 map: K14's window form, then the
+    whole-tensor kernels on the compact tensors; zero padding / pooling padding at the window's edge spoil one ring per stage
+    and the plan makes the window that much larger than what is read of it).  Outputs: feature 0 as its "hz" window (its only
+    consumers, the decoder tail and this node's backward, read inside it) and feature 1 as the cached clean feature with the
+    changed cells ("f1s") written in.  Backward: the same compact tensors through layer1's four backward-data launches, the
+    stem's adjoint and K12's window form -- d / d image inside the plan's image window "d", zero elsewhere."""
+
+    @staticmethod
+    def forward(ctx, x, plan, tab, clean, w_stem, s0, b0, w1a, s1a, b1a, w2a, s2a, b2a, w1b, s1b, b1b, w2b, s2b, b2b):
+        lib = N.lib()
+        B, _, H, W = x.shape
+        dev = x.device
+        st = N.stream()
+        org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
+        hl, wl = plan.size["hl"]
+        hz, wz = 2 * hl, 2 * wl
+        z = torch.empty((B, 64, hz, wz), device=dev, dtype=torch.float32)
+        N.check(_timed("stem_conv_fwd", lambda: lib.dmh_stem_conv_norm_fwd_win(
+            N.ptr(x), N.ptr(_c(w_stem)), N.ptr(org["hz"]), B, H, W, hz, wz, 0.45, 0.225, N.ptr(z), st),
+            4 * (z.numel() + 12 * B * hz * wz), 2 * 147 * z.numel()))
+        f0 = torch.empty_like(z)
+        pooled = torch.empty((B, 64, hl, wl), device=dev, dtype=torch.float32)
+        arg = torch.empty((B, 64, hl, wl), device=dev, dtype=torch.uint8)
+        N.check(_timed("stem_fwd", lambda: lib.dmh_stem_bn_relu_pool_fwd(N.ptr(z), N.ptr(s0), N.ptr(b0), B, 64, hz, wz, N.ptr(f0),
+                                                                        N.ptr(pooled), N.ptr(arg), st),
+                       4 * (2 * z.numel() + pooled.numel()) + arg.numel()))
+        del z
+
+        def conv_act(inp, w, s, b, res):
+            y = torch.empty_like(inp)
+            N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+                N.ptr(inp), N.ptr(_wino_filter(w, False, s)), N.ptr(b), N.ptr(res), 1, B, 64, 64, hl, wl, 1, N.ptr(y), st),
+                4 * (2 + (res is not None)) * inp.numel(), 18 * 64 * inp.numel()))
+            return y
+
+        o1a = conv_act(pooled, w1a, s1a, b1a, None)
+        ya = conv_act(o1a, w2a, s2a, b2a, pooled)
+        o1b = conv_act(ya, w1b, s1b, b1b, None)
+        f1c = conv_act(o1b, w2b, s2b, b2b, ya)
+        # feature 1 = the clean scenes' feature with the changed cells written in (the clean values return before the next step)
+        clean.restore()
+        hs_, ws_ = plan.size["f1s"]
+        N.check(_timed("roi_paste", lambda: lib.dmh_roi_paste(N.ptr(f1c), N.ptr(org["hl"]), hl, wl, N.ptr(org["f1s"]), B, 64,
+                                                             H // 4, W // 4, hs_, ws_, N.ptr(clean.work), st),
+                       8 * B * 64 * hs_ * ws_))
+        clean.dirty = (org["f1s"], (hs_, ws_))
+        ctx.save_for_backward(f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b)
+        ctx.plan, ctx.img = plan, (H, W)
+        ctx.set_materialize_grads(False)
+        return f0, clean.work.detach()      # a fresh alias per step: the cached tensor itself never enters an autograd graph
+
+    @staticmethod
+    def backward(ctx, g_f0, g_f1):
+        f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b = ctx.saved_tensors
+        plan, (H, W) = ctx.plan, ctx.img
+        lib = N.lib()
+        dev = f0.device
+        B = f0.shape[0]
+        st = N.stream()
+        org = {n: tab[k] for k, n in enumerate(_ROI_NAMES)}
+        hl, wl = plan.size["hl"]
+        hz, wz = 2 * hl, 2 * wl
+        g_pool = None
+        if g_f1 is not None:
+            def conv_bwd(g, w, s, res, flag):
+                y = torch.empty_like(g)
+                N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+                    N.ptr(g), N.ptr(_wino_filter(w, True, s)), None, N.ptr(res), flag, B, 64, 64, hl, wl, 1, N.ptr(y), st),
+                    4 * 3 * g.numel(), 18 * 64 * g.numel()))
+                return y
+
+            g_f1 = _c(g_f1)
+            g2b = torch.empty_like(f1c)                                     # g * [y_b > 0] on the window
+            N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(N.ptr(g_f1), N.ptr(f1c), None, N.ptr(org["hl"]), B, 64, H // 4,
+                                                               W // 4, hl, wl, 1, N.ptr(g2b), st), 12 * g2b.numel()))
+            g1b = conv_bwd(g2b, w2b, s2b, o1b, 2)                           # ... * [out1_b > 0]
+            g_ya = conv_bwd(g1b, w1b, s1b, g2b, 0)                          # + the identity branch
+            g2a = torch.empty_like(g_ya)                                    # * [y_a > 0]
+            N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(None, N.ptr(ya), N.ptr(g_ya), N.ptr(org["hl"]), B, 64, H // 4,
+                                                               W // 4, hl, wl, 1, N.ptr(g2a), st), 12 * g2a.numel()))
+            g1a = conv_bwd(g2a, w2a, s2a, o1a, 2)
+            g_pool = conv_bwd(g1a, w1a, s1a, g2a, 0)
+        if g_pool is None and g_f0 is None:
+            return (None,) * 19
+        g_z = torch.empty_like(f0)
+        N.check(_timed("stem_bwd", lambda: lib.dmh_stem_bn_relu_pool_bwd(
+            N.ptr(f0), N.ptr(arg), N.ptr(None if g_f0 is None else _c(g_f0)), N.ptr(g_pool), N.ptr(s0), B, 64, hz, wz, N.ptr(g_z),
+            st), 4 * 4 * g_z.numel()))
+        w_s = frozen_memo(("stem_w_over_std", w_stem.data_ptr(), w_stem._version, 0.225),
+                          lambda: _c(w_stem.detach() * (1.0 / 0.225)))
+        g_x = torch.zeros((B, 3, H, W), device=dev, dtype=torch.float32)
+        hd, wd = plan.size["d"]
+        N.check(_timed("stem_conv_bwd_win", lambda: lib.dmh_conv7x7s2_bwd_data_win(
+            N.ptr(g_z), N.ptr(w_s), N.ptr(org["d"]), N.ptr(org["hz"]), B, 64, 3, H, W, hd, wd, hz, wz, N.ptr(g_x), st),
+            4 * (g_z.numel() + B * 3 * hd * wd)))
+        return (g_x,) + (None,) * 18
+
+
+def clean_head(x_clean, conv1_weight, aff0, blocks):
+    """CleanHead of the clean frames ``x_clean`` [B,3,H,W]: feature 1 through the whole-frame head, no gradient."""
+    with torch.no_grad():
+        z = stem_conv_norm(x_clean, conv1_weight, 0.45, 0.225)
+        _, y = stem_bn_relu_pool(z, aff0[0], aff0[1])
+        for w1, a1, w2, a2 in blocks:
+            o = conv3x3_bn_act(y, w1, a1[0], a1[1], None, True, 1)
+            y = conv3x3_bn_act(o, w2, a2[0], a2[1], y, True, 1)
+    return CleanHead(y)
+
+
+def encoder_head_incremental(x, plan, tab, clean, conv1_weight, aff0, blocks):
+    """(feature 0 on its "hz" window, feature 1) of the ResNet-18 encoder for an attack step whose image ``x`` differs from
+    the clean frames behind ``clean`` (ops.clean_head) inside the plan's boxes only -- see _EncHeadInc.  Marks the plan:
+    head_windowed (feature 0's gradient is read inside the window) and f0_compact (feature 0 IS the window)."""
+    ws = [(b[0], b[2]) for b in blocks]
+    if not encoder_head_ok(x, conv1_weight, ws) or not plan.head_incremental_ok:
+        raise RuntimeError("encoder_head_incremental: needs ops.frozen_weights(), the ResNet-18 head and a plan whose \"hz\" "
+                           "window holds what is read of feature 0")
+    if tab.dtype != torch.int32 or tuple(tab.shape) != (len(_ROI_NAMES), x.shape[0], 2) or plan.B != x.shape[0] or \
+            (plan.H, plan.W) != tuple(x.shape[2:]) or tuple(clean.work.shape) != (x.shape[0], 64, x.shape[2] // 4, x.shape[3] // 4):
+        raise RuntimeError("encoder_head_incremental: plan / origin table / clean feature do not match the image batch")
+    d = lambda t: _c(t.detach())        # noqa: E731
+    args = [d(conv1_weight), d(aff0[0]), d(aff0[1])]
+    for w1, a1, w2, a2 in blocks:
+        args += [w1.detach(), d(a1[0]), d(a1[1]), w2.detach(), d(a2[0]), d(a2[1])]
+    plan.head_windowed = plan.f0_compact = True
+    return _EncHeadInc.apply(_c(x), plan, _c(tab), clean, *args)
 
 
 def masked_depth_errors(disp_gt, disp_pred, mask=None, min_depth=0.1, max_depth=100.0, scale=5.4, clamp_lo=1e-3,

@@ -32,8 +32,13 @@ MAX_DEPTH = 4
 # that feature's gradient); r_y{k}0: what it reads of upconv(k,0)'s whole-frame output when the chain starts at level k;
 # "gz": the gradient of conv1's output that the image window reads; "l1": the common window of layer1's four backward
 # convolutions (encoder head)
-REGIONS = ("r_f0", "r_f1", "r_f2", "r_f3", "r_y20", "r_y30", "r_y40", "gz", "l1")
-LEVEL.update({"r_f0": 1, "r_f1": 2, "r_f2": 3, "r_f3": 4, "r_y20": 3, "r_y30": 4, "r_y40": 5, "gz": 1, "l1": 2})
+# Incremental forward of the encoder head (ops.encoder_head_incremental): the pasted object changes the image inside the
+# box only, so conv1 ... layer1 are recomputed on "hl" (1/4 map; "hz" = the same window on the 1/2 map, twice the size) and
+# the part of feature 1 that really changes, "f1s", is written into the cached feature of the clean scenes
+REGIONS = ("r_f0", "r_f1", "r_f2", "r_f3", "r_y20", "r_y30", "r_y40", "gz", "l1", "hl", "hz", "f1s")
+LEVEL.update({"r_f0": 1, "r_f1": 2, "r_f2": 3, "r_f3": 4, "r_y20": 3, "r_y30": 4, "r_y40": 5, "gz": 1, "l1": 2, "hl": 2,
+              "hz": 1, "f1s": 2})
+_HEAD_RING = 9      # max-pool (1) + layer1 forward (4) + what layer1's backward needs around its own target (4)
 TABLE = WINDOWS + REGIONS
 _L1_RING = 4                                # layer1 = two BasicBlocks = four 3x3 convolutions: each spoils one ring
 
@@ -75,6 +80,7 @@ class RoiPlan(object):
             raise RuntimeError("RoiPlan: depth must be 2, 3 or 4")
         self.H, self.W, self.B, self.depth = int(H), int(W), boxes.shape[0], int(depth)
         self.head_windowed = False      # set by the encoder when its head's backward will run on the windows below
+        self.f0_compact = False         # set by the encoder when feature 0 is handed on as its "hz" window only
         y0 = np.clip(boxes[:, 0], 0, H - 1)
         y1 = np.clip(boxes[:, 1], y0 + 1, H)
         x0 = np.clip(boxes[:, 2], 0, W - 1)
@@ -114,6 +120,33 @@ class RoiPlan(object):
         fy = np.minimum(reads["z11"][0][0], os_[:, 0]), np.maximum(reads["z11"][0][1], os_[:, 0] + hs)
         fx = np.minimum(reads["z11"][1][0], os_[:, 1]), np.maximum(reads["z11"][1][1], os_[:, 1] + ws)
         self._put("r_f0", fy, fx)
+        # ---- incremental forward of the head.  Image rows [y0, y1) change; conv1 (7x7/2, pad 3) output row r reads rows
+        # 2r-3 .. 2r+3, the 3x3/2 max-pool cell i reads rows 2i-1 .. 2i+1, layer1's four convolutions reach one cell each
+        zy = np.maximum((y0 - 3) >> 1, 0), np.minimum(((y1 + 2) >> 1) + 1, H >> 1)
+        zx = np.maximum((x0 - 3) >> 1, 0), np.minimum(((x1 + 2) >> 1) + 1, W >> 1)
+        py = zy[0] >> 1, np.minimum((zy[1] >> 1) + 1, H >> 2)
+        px = zx[0] >> 1, np.minimum((zx[1] >> 1) + 1, W >> 2)
+        # (exactly the changed cells, no alignment slack: one more cell would lie in the ring the compact window spoils)
+        for ax, (lo, hi, frame) in enumerate(((np.maximum(py[0] - 4, 0), np.minimum(py[1] + 4, H >> 2), H >> 2),
+                                              (np.maximum(px[0] - 4, 0), np.minimum(px[1] + 4, W >> 2), W >> 2))):
+            size = int((hi - lo).max())
+            fs = (size, np.minimum(lo, frame - size)) if ax == 0 else fs + (size, np.minimum(lo, frame - size))
+        self.size["f1s"] = (fs[0], fs[2])
+        self.org["f1s"] = np.stack([fs[1], fs[3]], 1).astype(np.int32)
+        # one compact window serves forward and backward: it holds the changed cells and the cells the backward reads (the
+        # pooling cells under "gz"), plus the rings the same-size convolutions and the pooling spoil at its edge
+        by = np.minimum(py[0], os_[:, 0] >> 1), np.maximum(py[1], ((os_[:, 0] + hs) >> 1) + 1)
+        bx = np.minimum(px[0], os_[:, 1] >> 1), np.maximum(px[1], ((os_[:, 1] + ws) >> 1) + 1)
+        self._put("hl", (np.maximum(by[0] - _HEAD_RING, 0), np.minimum(by[1] + _HEAD_RING, H >> 2)),
+                  (np.maximum(bx[0] - _HEAD_RING, 0), np.minimum(bx[1] + _HEAD_RING, W >> 2)))
+        hl, ol = self.size["hl"], self.org["hl"]
+        self.size["hz"], self.org["hz"] = (2 * hl[0], 2 * hl[1]), (2 * ol).astype(np.int32)
+        # the tail reads feature 0 inside "r_f0" and the head's backward reads conv1's gradient inside "gz": both lie in "hz"
+        for nm in ("r_f0", "gz"):
+            (hh, ww), oo = self.size[nm], self.org[nm]
+            self.head_incremental_ok = bool((oo >= 2 * ol).all() and (oo[:, 0] + hh <= 2 * ol[:, 0] + 2 * hl[0]).all()
+                                            and (oo[:, 1] + ww <= 2 * ol[:, 1] + 2 * hl[1]).all()
+                                            and getattr(self, "head_incremental_ok", True))
 
     def _put(self, name, ry, rx):
         lvl = LEVEL[name]

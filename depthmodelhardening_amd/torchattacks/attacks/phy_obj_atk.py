@@ -109,17 +109,22 @@ class Phy_obj_atk(Attack):
 
         # the cost reads the disparity under the object only: a model that can evaluate mean((disp * mask)^2) on windows
         # around the object (DepthModelWrapper.masked_sq_mean: exact) gets the per-step boxes, all tables in one H2D copy
-        plans = tabs = None
+        plans = tabs = clean = None
         if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
             plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
+            # the frames without the object (a paste with an all-zero mask: scene (1 - 0) + patch 0, then the same Resize):
+            # every step's pasted frames equal them outside the step's boxes, so the model may start from their features
+            with torch.no_grad():
+                clean, _ = ops.eot_paste(scene_imgs, self.obj_img, torch.zeros_like(mask), coeffs[0], l_pad, t_pad,
+                                         self.scene_size)
 
         for s in range(self.steps):
             obj_img_adv.requires_grad_()
             adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[s], l_pad, t_pad,
                                                       self.scene_size)
             if plans is not None:
-                cost = -self.model.masked_sq_mean(adv_scenes, obj_masks_out, plans[s], tabs[s])
+                cost = -self.model.masked_sq_mean(adv_scenes, obj_masks_out, plans[s], tabs[s], clean)
             else:
                 adv_depth = self.model(adv_scenes)
                 cost = -ops.masked_sq_mean(adv_depth, obj_masks_out)  # -MSE(adv_depth * mask, 0)

@@ -93,10 +93,13 @@ class Phy_obj_atk_l0(Attack):
         l_pad, t_pad = pt.l_pad, pt.t_pad
         mask = self.obj_mask.to(self.device)
         # the adversarial cost reads the disparity under the object only: see Phy_obj_atk.forward
-        plans = tabs = None
+        plans = tabs = clean = None
         if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
             plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
+            with torch.no_grad():       # the frames without the object: see Phy_obj_atk.forward
+                clean, _ = ops.eot_paste(scene_imgs, self.obj_img, torch.zeros_like(mask), coeffs[0], l_pad, t_pad,
+                                         self.scene_size)
         thresh = torch.full((), float(self.l0_thresh), device=self.device)      # fill kernels: no host sync
         w_on = torch.full((), float(self.mask_weight_init), device=self.device)
         w_off = torch.zeros((), device=self.device)
@@ -116,7 +119,7 @@ class Phy_obj_atk_l0(Attack):
             adv_scenes, adv_obj_mask = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[stp], l_pad, t_pad,
                                                      self.scene_size)
             if plans is not None:
-                adv_cost = self.model.masked_sq_mean(adv_scenes, adv_obj_mask, plans[stp], tabs[stp])
+                adv_cost = self.model.masked_sq_mean(adv_scenes, adv_obj_mask, plans[stp], tabs[stp], clean)
             else:
                 adv_depth = self.model(adv_scenes)
                 adv_cost = ops.masked_sq_mean(adv_depth, adv_obj_mask)

@@ -300,13 +300,20 @@ int dmh_roi_cost_bwd(const float* sig, const float* mask, const int* org, int B,
  * MD2/networks/resnet_encoder.py:85-98) on one window per scene -- the patch gradient reads d cost / d image under the pasted
  * object only (physicalTrans.py:156-165, phy_obj_atk.py:96).
  *   roi_crop: out[B,C,hc,wc] = src[b, c, org_b + (i, j)] of a whole-frame src[B,C,H,W], times [gate > 0] (gate: whole-frame,
- *             same window) when gate is given; or, with g (compact [B,C,hc,wc]) instead of src, out = g * [gate window > 0].
+ *             same window; gate_compact != 0: gate is itself a compact [B,C,hc,wc] window at org) when gate is given; or, with g
+ *             (compact [B,C,hc,wc]) instead of src, out = g * [gate window > 0].
  *             org [B,2] int32 with even columns, wc and W even.
  *   stem_bn_relu_pool_bwd_win: dmh_stem_bn_relu_pool_bwd on the hs x ws window (even origin org, even sizes) of the H x W
  *             map: g_z[B,C,hs,ws] compact; g_pool is a compact [B,C,hq,wq] window of the H/2 x W/2 map at pool_org (cells
  *             outside it count as 0: it must hold the pooling cells that cover the window); g_feat whole-frame or NULL. */
 int dmh_roi_crop(const float* src, const float* gate, const float* g, const int* org, int B, int C, int H, int W, int hc,
-                 int wc, float* out, void* stream);
+                 int wc, int gate_compact, float* out, void* stream);
+/* roi_paste: dst[b, c, win_org_b + (i, j)] = src at the same frame position, for the h x w window: src is a compact
+ * [B,C,sh,sw] window at frame origin src_org [B,2] that holds it, or (src_org NULL, sh x sw = H x W) a whole-frame tensor.
+ * The incremental attack forward writes the part of encoder feature 1 that the pasted object changes into the cached
+ * feature of the clean scenes, and puts the clean values back afterwards. */
+int dmh_roi_paste(const float* src, const int* src_org, int sh, int sw, const int* win_org, int B, int C, int H, int W, int h,
+                  int w, float* dst, void* stream);
 int dmh_stem_bn_relu_pool_bwd_win(const float* feat, const unsigned char* argmax, const float* g_feat, const float* g_pool,
                                   const float* scale, const int* org, const int* pool_org, int B, int C, int H, int W, int hs,
                                   int ws, int hq, int wq, float* g_z, void* stream);
@@ -469,6 +476,10 @@ int dmh_conv3x3_small_wrw(const float* x, const float* g, int B, int C, int H, i
  * ---------------------------------------------------------------------------------- */
 int dmh_stem_conv_norm_fwd(const float* x, const float* w, int B, int H, int W, float mean, float std, float* y,
                            void* stream);
+/* Window form (K19): only the hw x ww window of the H/2 x W/2 output at the per-sample origin org [B,2] is computed, into a
+ * compact y[B,64,hw,ww]; x stays the whole image (zero padding outside it as above). */
+int dmh_stem_conv_norm_fwd_win(const float* x, const float* w, const int* org, int B, int H, int W, int hw, int ww, float mean,
+                               float std, float* y, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K15 the two convolutions that open a down-sampling ResNet block (torchvision BasicBlock.conv1 with stride 2 and
