@@ -509,6 +509,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
+__global__ __launch_bounds__(NT) void zero_fill_kernel(f32x4* __restrict__ p, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
+    if (i < n4) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -553,9 +558,14 @@ int launch_split(WArgs& a, hipStream_t st, bool epi) {
     // (a fused activation needs the complete sum in one item: no split)
     a.csplit = (!epi && regions < (3 * num_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
     a.nitems = (int)regions * a.csplit;
-    if (a.csplit > 1 &&
-        hipMemsetAsync(a.y, 0, sizeof(float) * (size_t)a.B * a.K * a.Ho * a.Wo, st) != hipSuccess)
-        return fail(DMH_ELAUNCH, "%s: hipMemsetAsync failed", "dmh_wino_conv3x3");
+    if (a.csplit > 1) {
+        // a fill KERNEL, not hipMemsetAsync: inside a stream capture (torch.cuda.graph) the runtime's memset was not replayed
+        // with the graph on this stack (ROCm 7.2) -- the two halves then accumulated onto the previous replay's output
+        const size_t n4 = ((size_t)a.B * a.K * a.Ho * a.Wo) / 4;        // Ho, Wo even: a multiple of 4 floats
+        hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)((n4 + NT - 1) / NT)), dim3(NT), 0, st,
+                           reinterpret_cast<f32x4*>(a.y), n4);
+        if (int rc = check_launch("dmh_wino_conv3x3 (zero fill)")) return rc;
+    }
     return epi ? launch<TRW, FLAT, true>(a, st) : launch<TRW, FLAT, false>(a, st);
 }
 

@@ -89,6 +89,11 @@ class MonodepthOptions:
         p.add_argument("--seed", type=int, default=1234)
         p.add_argument("--sync_attack", action="store_true",
                        help="strict reference order: wait for the gradient all-reduce + Adam before the next attack")
+        p.add_argument("--shared_patch", action="store_true",
+                       help="data-parallel runs: ONE patch for the whole job, as the reference's single process has (MD2/"
+                            "trainer.py:300-307) -- the --atk_batch_size attack scenes are sharded over the ranks and the patch "
+                            "gradient is summed over them before every sign step (SURVEY.md section 8e).  Default: every rank "
+                            "attacks its own --atk_batch_size scenes and keeps its own patch (no attack-time communication)")
         p.add_argument("--materialize_warps", action="store_true",
                        help="generate_images_pred also writes depth/sample/color tensors (the fused loss never reads them)")
         p.add_argument("--use_depth_hints", action="store_true",

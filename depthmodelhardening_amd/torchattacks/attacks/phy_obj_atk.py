@@ -55,6 +55,12 @@ class Phy_obj_atk(Attack):
         # None = the reference's behaviour.
         self.pose_group = None
         self.use_roi = True     # evaluate the cost on windows around the object when the model offers masked_sq_mean
+        # Data-parallel "shared patch" mode: shard = (rank, world, process group or None).  The
+        # reference attacks ONE patch on batch_size scenes per iteration (MD2/trainer.py:300-307, mono_dataset.py:178-184);
+        # with a shard every rank holds scenes rank, rank + world, ... of that batch (``images`` = its own scenes), the pose
+        # draws and the random start come from rank 0, and the patch gradient is summed over the ranks before the sign
+        # step: all ranks end with the same patch -- the patch of the one-process attack on the concatenated scenes.
+        self.shard = None
         conf = {'path': f'{object_dataset_root}/training/calib/003086.txt'}
         self.phy_trans_adv = PhysicalTrans(self.obj_img.clone(), self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
@@ -84,7 +90,14 @@ class Phy_obj_atk(Attack):
         In eval mode the first object position / angle of the returned scenes is fixed (7 m, 0 deg).
         """
         images = images.detach().to(self.device)
-        if images.size()[0] != 1 and images.size()[0] != batch_size:
+        mine, share = None, 1.0
+        if self.shard is not None:
+            import torch.distributed as dist
+            rank, world, group = self.shard
+            mine = list(range(rank, batch_size, world))         # this rank's scenes of the global batch
+            share = len(mine) / float(batch_size)               # its part of the global mean of the cost
+        n_local = batch_size if mine is None else len(mine)
+        if images.size()[0] != 1 and images.size()[0] != n_local:
             raise RuntimeError('Batch size doesn\'t match!')
         scene_imgs = images  # a single scene is broadcast inside the kernel (no torch.cat copy)
 
@@ -93,7 +106,10 @@ class Phy_obj_atk(Attack):
             noise = self.random_start_noise
             if noise is None:
                 noise = torch.empty_like(obj_img_adv).uniform_(-self.eps, self.eps)
-            obj_img_adv = torch.clamp(obj_img_adv + noise.to(self.device), min=0, max=1).detach()
+            noise = noise.to(self.device)
+            if mine is not None:
+                dist.broadcast(noise, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            obj_img_adv = torch.clamp(obj_img_adv + noise, min=0, max=1).detach()
 
         # every (z0, alpha) draw of the attack, in the reference's order: one project() per step
         # (physicalTrans.py:150,155), then the two explicit draws for the returned scenes (:108-109)
@@ -103,6 +119,14 @@ class Phy_obj_atk(Attack):
         if eval:
             z0_sample[0] = 7
             alpha_sample[0] = 0
+        if mine is not None:        # rank 0's draws for the whole batch; every rank keeps the poses of its own scenes
+            box = [draws + [(z0_sample, alpha_sample)]]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            allp = [([z[i] for i in mine], [a[i] for i in mine]) for z, a in box[0]]
+            draws, (z0_sample, alpha_sample) = allp[:-1], allp[-1]
+            if n_local == 0:        # more ranks than scenes: this rank only takes part in the exchange
+                return self._shard_without_scenes(obj_img_adv, dist, group)
+            batch_size = n_local
         coeffs = self._coeffs(draws + [(z0_sample, alpha_sample)])
         l_pad, t_pad = pt.l_pad, pt.t_pad
         mask = self.obj_mask.to(self.device)
@@ -128,7 +152,11 @@ class Phy_obj_atk(Attack):
             else:
                 adv_depth = self.model(adv_scenes)
                 cost = -ops.masked_sq_mean(adv_depth, obj_masks_out)  # -MSE(adv_depth * mask, 0)
+            if mine is not None:
+                cost = cost * share     # the local mean's part of the mean over the global batch
             grad = torch.autograd.grad(cost, obj_img_adv, retain_graph=False, create_graph=False)[0]
+            if mine is not None:        # 0.94 MB: the one exchange of the shared-patch attack, before the sign
+                dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
             obj_img_adv = ops.pgd_linf_step(obj_img_adv, self.obj_img, grad, self.alpha, self.eps)
 
         self.phy_trans_adv.reset_img(obj_img_adv, self.obj_mask)
@@ -137,3 +165,14 @@ class Phy_obj_atk(Attack):
                                                       self.scene_size)
             ben_scenes, _ = ops.eot_paste(scene_imgs, self.obj_img, mask, coeffs[-1], l_pad, t_pad, self.scene_size)
         return adv_scenes, ben_scenes, obj_masks_out, obj_img_adv
+
+    def _shard_without_scenes(self, obj_img_adv, dist, group):
+        """A rank whose share of the attack batch is empty (world > batch_size): it contributes a zero gradient to every
+        step's sum and follows the patch."""
+        for _ in range(self.steps):
+            grad = torch.zeros_like(obj_img_adv)
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+            obj_img_adv = ops.pgd_linf_step(obj_img_adv, self.obj_img, grad, self.alpha, self.eps)
+        self.phy_trans_adv.reset_img(obj_img_adv, self.obj_mask)
+        empty = obj_img_adv.new_zeros((0, 3) + tuple(self.scene_size))
+        return empty, empty.clone(), obj_img_adv.new_zeros((0, 1) + tuple(self.scene_size)), obj_img_adv

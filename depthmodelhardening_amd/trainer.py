@@ -148,7 +148,11 @@ class Trainer:
                             mask_wt=self.opt.atk_mask_wt, l0_thresh=self.opt.atk_l0_thresh)
             self.dataset.set_adv_train(self.models["DepthModelWrapper"], obj_tensor, mask_tensor, args)
             self.adv_args = args
-            self.dataset.update_adv_obj(self.dataset.next_scenes(args["batch_size"]))   # trainer.py:231-233
+            if getattr(self.opt, "shared_patch", False) and self.world_size > 1:
+                if self.opt.norm_type != "l_inf":
+                    raise RuntimeError("--shared_patch is implemented for --norm_type l_inf (the sign step's gradient sum)")
+                self.dataset.depth_atk.shard = (self.rank, self.world_size, None)
+            self.update_adv_obj()   # trainer.py:231-233
 
         # The reference builds SSIM() and per-scale BackprojectDepth / Project3D modules here (MD2/trainer.py:240-254);
         # the fused loss derives the pixel grid on chip, so those ~170 MB of device buffers (B=32) are not allocated.
@@ -180,6 +184,15 @@ class Trainer:
             if self.opt.max_steps and self.step >= self.opt.max_steps:
                 break
 
+    def update_adv_obj(self):
+        """dataset.update_adv_obj on this iteration's attack scenes (MD2/trainer.py:300-307): --atk_batch_size scenes per
+        rank, or with --shared_patch this rank's share of the job's --atk_batch_size scenes."""
+        n = self.adv_args["batch_size"]
+        shard = getattr(self.dataset.depth_atk, "shard", None)
+        if shard is not None:
+            n = len(range(shard[0], n, shard[1]))
+        self.dataset.update_adv_obj(self.dataset.next_scenes(n))
+
     def train_step(self):
         """One iteration of run_epoch's loop body (MD2/trainer.py:297-315): attack -> forward -> loss ->
         backward -> gradient all-reduce -> Adam.  Returns the losses dict."""
@@ -188,12 +201,12 @@ class Trainer:
             # the previous iteration left its all-reduce in flight: enqueue this iteration's attack first
             # (it reads weights one optimiser step old), then apply the averaged gradients
             if self.opt.adv_train:
-                self.dataset.update_adv_obj(self.dataset.next_scenes(self.adv_args["batch_size"]))
+                self.update_adv_obj()
             self._apply_pending_update()
         else:
             self._apply_pending_update()
             if self.opt.adv_train:
-                self.dataset.update_adv_obj(self.dataset.next_scenes(self.adv_args["batch_size"]))
+                self.update_adv_obj()
         inputs = self.dataset.next_batch(self.opt.batch_size)
         outputs, losses = self.process_batch(inputs)
         self.bucket.zero()                       # model_optimizer.zero_grad()
@@ -209,7 +222,9 @@ class Trainer:
         makes MIOpen compile its kernels into the per-user cache (minutes on a fresh box).  bench.py lets rank 0 do
         that alone before the other ranks start, so that N ranks do not build the same kernels concurrently."""
         if self.opt.adv_train:
-            self.dataset.update_adv_obj(self.dataset.next_scenes(self.adv_args["batch_size"]))
+            shard, self.dataset.depth_atk.shard = getattr(self.dataset.depth_atk, "shard", None), None   # no collectives here
+            self.update_adv_obj()
+            self.dataset.depth_atk.shard = shard
         inputs = self.dataset.next_batch(self.opt.batch_size)
         _, losses = self.process_batch(inputs)
         self.bucket.zero()

@@ -69,7 +69,7 @@ def _pool_seeds(B, H, W, seed):
 def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
     N, ops, loss_ref, _, synth, _ = _mods()
     B, H, W, seed0 = shape
-    pool = GradPool()
+    pool = GradPool(count_floor=2.0 / (H * W) if variant == "dh" else 0.0)
     for seed in _pool_seeds(B, H, W, seed0):
         inputs, disps = synth.make_loss_case(B, H, W, seed)
         noise = None

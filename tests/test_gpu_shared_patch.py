@@ -1,0 +1,123 @@
+"""SURVEY.md section 8e "shared patch": the reference attacks ONE patch per iteration (MD2/trainer.py:300-307,
+mono_dataset.py:178-184).  With --shared_patch the attack's scenes are sharded over the ranks and the 0.94 MB patch gradient
+is summed over them before every sign step (Phy_obj_atk.shard): every rank ends with the same patch, and that patch is the
+one a single process gets from the attack on the concatenated scenes.
+
+Two ranks on ONE MI355X over gloo (RCCL needs one GPU per rank; the driver runs the real multi-GPU bench), the HIP kernels on
+both: there is no CPU path to run this on."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+STEPS, SCENES = 3, 12
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _setup(dev):
+    from oracle import synth
+    from tests.test_roi import _unet
+    model = _unet(dev, seed=2)
+    obj, pmask = synth.make_object()
+    scenes = synth.kitti_like(SCENES, 3, 375, 1242, torch.Generator().manual_seed(8)).to(dev)
+    noise = (torch.rand(obj.shape, generator=torch.Generator().manual_seed(9)) * 2 - 1) * 0.1
+    return model, obj.to(dev), pmask.to(dev), scenes, noise
+
+
+def _attack(model, obj, pmask):
+    from depthmodelhardening_amd.torchattacks import Phy_obj_atk
+    return Phy_obj_atk(model, obj, pmask, eps=0.1, alpha=0.02, steps=STEPS, dist_range=list(np.arange(5, 10, 0.2)))
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", DMH_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from depthmodelhardening_amd.ddp import init_distributed
+    _, _, dev = init_distributed("cuda")
+    model, obj, pmask, scenes, noise = _setup(dev)
+    atk = _attack(model, obj, pmask)
+    atk.shard = (rank, world, None)
+    # rank 0's start noise and pose draws are the job's: give rank 1 different ones to show that they are not used
+    atk.random_start_noise = noise if rank == 0 else torch.zeros_like(noise)
+    random.seed(13 if rank == 0 else 999)
+    mine = scenes[rank::world].contiguous()
+    adv, ben, m, patch = atk(mine, SCENES)
+    torch.cuda.synchronize()
+    ret[rank] = (patch.cpu(), tuple(adv.shape), float(m.sum()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_attack_equals_the_one_process_attack_on_all_scenes():
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    (p0, shape0, m0), (p1, shape1, m1) = ret[0], ret[1]
+    assert torch.equal(p0, p1), "the ranks must end with ONE patch"
+    assert shape0 == shape1 == (SCENES // 2, 3, 320, 1024) and m0 > 0 and m1 > 0
+    # the one-process attack on the twelve scenes, same start noise, same draws
+    dev = torch.device("cuda")
+    model, obj, pmask, scenes, noise = _setup(dev)
+    atk = _attack(model, obj, pmask)
+    atk.random_start_noise = noise
+    random.seed(13)
+    _, _, _, patch = atk(scenes, SCENES)
+    patch = patch.cpu()
+    assert float((patch - obj.cpu()).abs().max()) <= 0.1 + 1e-6 and not torch.equal(patch, obj.cpu())
+    agree = (patch == p0).float().mean().item()
+    print("patch texels identical, 2 ranks x 6 scenes vs 1 process x 12 scenes: %.5f" % agree)
+    # the sum of two partial gradients rounds differently from the one-process sum over twelve scenes: a sign() step on a
+    # ~0 gradient may flip a texel by 2 alpha
+    assert agree > 0.999
+    assert float((patch - p0).abs().max()) <= 2 * 0.02 * STEPS + 1e-6
+
+
+def _trainer_worker(rank, world, port, tmp, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", DMH_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from depthmodelhardening_amd.ddp import init_distributed
+    from depthmodelhardening_amd.options import MonodepthOptions
+    from depthmodelhardening_amd.trainer import Trainer
+    r, w, dev = init_distributed("cuda")
+    torch.manual_seed(100 + rank)
+    random.seed(100 + rank)
+    argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "64", "--width", "192",
+            "--batch_size", "2", "--weights_init", "scratch", "--log_dir", os.path.join(tmp, "r%d" % rank),
+            "--model_name", "t", "--synthetic_len", "8", "--adv_train", "--atk_steps", "2", "--atk_batch_size", "3",
+            "--shared_patch", "--sync_attack"]
+    tr = Trainer(MonodepthOptions().parse(argv), rank=r, world_size=w, device=dev)
+    tr.set_train()
+    patches = [tr.dataset.obj_img_adv.detach().cpu().clone()]
+    for _ in range(2):
+        tr.train_step()
+        patches.append(tr.dataset.obj_img_adv.detach().cpu().clone())
+    torch.cuda.synchronize()
+    ret[rank] = (patches, tr.dataset.depth_atk.shard[:2])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_shared_patch_keeps_one_patch_across_the_ranks(tmp_path):
+    """--shared_patch through the Trainer: three attack scenes over two ranks (2 + 1), every iteration's patch identical on
+    both ranks and changing from iteration to iteration."""
+    ret = mp.Manager().dict()
+    mp.spawn(_trainer_worker, args=(2, _free_port(), str(tmp_path), ret), nprocs=2, join=True)
+    (pa, sa), (pb, sb) = ret[0], ret[1]
+    assert sa == (0, 2) and sb == (1, 2)
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    assert not torch.equal(pa[0], pa[1]) and not torch.equal(pa[1], pa[2])

@@ -906,15 +906,17 @@ def test_config5_physical_hardening_full_size():
     assert float((w1 - w2).abs().max()) <= 2.0e-4, float((w1 - w2).abs().max())
 
 
-@pytest.mark.parametrize("cfg", [3, 4])
-def test_configs_3_and_4_step_full_size(tmp_path, cfg):
-    """BASELINE configs 3 and 4 at their workloads (what `bench.py --config N` times), one train_step each on the ResNet-18
-    U-Net at 320x1024: config 3 = L0/Adam attack (10 steps, 12 scenes) + supervised_adv, batch 32; config 4 = DepthHints loss
-    variant + 20-step PGD + SimSiam contrastive term, batch 64.  All loss terms present and finite, the attack moved the
-    object inside its constraint, every trained parameter moved, and the losses of the iteration are bitwise reproducible."""
+@pytest.mark.parametrize("cfg", [2, 3, 4])
+def test_configs_2_3_and_4_step_full_size(tmp_path, cfg):
+    """BASELINE configs 2, 3 and 4 at their workloads (what `bench.py --config N` times), one train_step each on the
+    ResNet-18 U-Net at 320x1024: config 2 (the headline) = 10-step PGD-L_inf on 12 scenes, batch 32; config 3 = L0/Adam
+    attack (10 steps, 12 scenes) + supervised_adv, batch 32; config 4 = DepthHints loss variant + 20-step PGD + SimSiam
+    contrastive term, batch 64.  All loss terms present and finite, the attack moved the object inside its constraint, every
+    trained parameter moved, and the losses of the iteration are bitwise reproducible."""
     from depthmodelhardening_amd.options import MonodepthOptions
     from depthmodelhardening_amd.trainer import Trainer
-    extra = {3: ["--batch_size", "32", "--atk_steps", "10", "--norm_type", "l_0", "--supervised_adv"],
+    extra = {2: ["--batch_size", "32", "--atk_steps", "10", "--norm_type", "l_inf"],
+             3: ["--batch_size", "32", "--atk_steps", "10", "--norm_type", "l_0", "--supervised_adv"],
              4: ["--batch_size", "64", "--atk_steps", "20", "--norm_type", "l_inf", "--loss_variant", "dh",
                  "--contrastive_learning"]}[cfg]
     argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "320", "--width", "1024",
@@ -935,10 +937,13 @@ def test_configs_3_and_4_step_full_size(tmp_path, cfg):
         return tr, obj0, w0, {k: v.detach().clone() for k, v in losses.items() if torch.is_tensor(v) and v.dim() == 0}
     tr, obj0, w0, losses = run()
     want = {"loss", "loss/0", "loss/1", "loss/2", "loss/3"}
-    want |= {"sup_loss"} if cfg == 3 else {"contras_loss", "reproj_loss/0"}
+    want |= {2: set(), 3: {"sup_loss"}, 4: {"contras_loss", "reproj_loss/0"}}[cfg]
     assert want <= set(losses), sorted(losses)
     assert all(torch.isfinite(v) for v in losses.values()) and float(losses["loss"]) > 0
-    assert tr.opt.batch_size == (32 if cfg == 3 else 64) and tr.adv_args["step"] == (10 if cfg == 3 else 20)
+    assert tr.opt.batch_size == (64 if cfg == 4 else 32) and tr.adv_args["step"] == (20 if cfg == 4 else 10)
+    if cfg == 2:        # the L_inf attack keeps the object inside its eps ball around the benign object
+        eps = tr.adv_args["epsilon"]
+        assert float((tr.dataset.obj_img_adv - tr.dataset.obj_img_ben.to(tr.dataset.obj_img_adv.device)).abs().max()) <= eps + 1e-6
     moved = [n for n, p in tr.models["encoder"].named_parameters() if n in w0 and not torch.equal(p.detach(), w0[n])]
     assert len(moved) >= len([n for n in w0 if not n.startswith("encoder.fc")]) - 2, len(moved)
     assert not torch.equal(tr.dataset.obj_img_adv, obj0)                     # the iteration's attack produced a new object

@@ -64,11 +64,24 @@ class GradPool(object):
         #bad(got)           <= 1.5 * #bad(ref32) + 1e-3 * numel        (bad: |err| > 1e-4 * (max|g64| + |g64|))
 
     i.e. HIP may not be further from exact arithmetic than 1.5x the reference's own fp32 conditioning noise.  No
-    additive slack beyond 1e-6 / 1e-3: a gradient that is a few per cent wrong fails."""
+    additive slack beyond 1e-6 / 1e-3: a gradient that is a few per cent wrong fails.
 
-    def __init__(self, scales=4):
+    And the absolute gate of north_star (1e-4 relative) where the reference is well conditioned: on the elements where the
+    fp32 reference itself is within 1e-4 * (max|g64| + |g64|) of fp64 (no floor() / argmin flip in its neighbourhood), HIP
+    must be too, for all but 1e-3 of them (its own, independent flips) -- per scale, for every case that goes through a pool:
+
+        #{ |got - g64| > tol  and  |ref32 - g64| <= tol }  <=  1e-3 * #{ |ref32 - g64| <= tol }  +  #{ |ref32 - g64| > tol }
+
+    ``count_floor``: the DepthHints normalisation divides a masked sum by the mask's pixel count (DH/trainer.py:700-708), so
+    ONE argmin flip anywhere rescales every gradient element of that scale by 1/count -- 2.6e-4 on a 48 x 80 image, more
+    than the 1e-4 gate.  Pools of that variant pass count_floor = 2 / (pixels per image): HIP's element-wise bound for the
+    gate is widened by two such flips (the same allowance the dh loss scalar has); 1.6e-5 at 192 x 640."""
+
+    def __init__(self, scales=4, count_floor=0.0):
+        self.count_floor = float(count_floor)
         z = lambda: np.zeros(scales)   # noqa: E731
         self.num_h, self.num_r, self.den, self.bad_h, self.bad_r, self.cnt = z(), z(), z(), z(), z(), z()
+        self.ok_r, self.bad_h_on_ok = z(), z()
 
     def add(self, s, got, ref32, g64):
         got, ref32, g64 = (t.detach().double().cpu() for t in (got, ref32, g64))
@@ -78,8 +91,11 @@ class GradPool(object):
         self.num_r[s] += float((ref32 - g64).pow(2).sum())
         self.den[s] += float(g64.pow(2).sum())
         tol = 1e-4 * g64.abs().max().item() + 1e-4 * g64.abs()
-        self.bad_h[s] += float(((got - g64).abs() > tol).sum())
-        self.bad_r[s] += float(((ref32 - g64).abs() > tol).sum())
+        bad_h, ok_r = (got - g64).abs() > tol, (ref32 - g64).abs() <= tol
+        self.bad_h[s] += float(bad_h.sum())
+        self.bad_r[s] += float((~ok_r).sum())
+        self.ok_r[s] += float(ok_r.sum())
+        self.bad_h_on_ok[s] += float((((got - g64).abs() > tol + self.count_floor * g64.abs()) & ok_r).sum())
         self.cnt[s] += g64.numel()
 
     def check(self, name=""):
@@ -93,3 +109,10 @@ class GradPool(object):
                 name, s, e_h, e_r)
             assert self.bad_h[s] <= 1.5 * self.bad_r[s] + 1e-3 * self.cnt[s], (name, s, self.bad_h[s], self.bad_r[s],
                                                                              self.cnt[s])
+            print("%s scale %d: well-conditioned elements %d of %d, HIP beyond 1e-4 on them: %d" % (
+                name, s, self.ok_r[s], self.cnt[s], self.bad_h_on_ok[s]))
+            # HIP's flips are independent of the reference's: it may have as many of its own, on other elements, as the
+            # reference has (on 48 x 80 images a flipped pixel is 1 % of a coarse scale's texels in ANY fp32 implementation)
+            assert self.bad_h_on_ok[s] <= max(1e-3 * self.ok_r[s], 1.0) + self.bad_r[s], (
+                "%s scale %d: HIP beyond 1e-4 on %d of the %d elements where the fp32 reference is within 1e-4 of fp64" % (
+                    name, s, self.bad_h_on_ok[s], self.ok_r[s]))
