@@ -276,6 +276,9 @@ def parse(argv=None):
     ap.add_argument("--height", type=int, default=320)
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--atk_steps", type=int, default=10)
+    ap.add_argument("--atk_scenes", type=int, default=12, help="attack scenes per iteration (--atk_batch_size; reference: 12)")
+    ap.add_argument("--shared_patch", action="store_true",
+                    help="ONE patch for the job: the --atk_scenes scenes are sharded over the ranks, the patch gradient summed")
     ap.add_argument("--norm_type", type=str, default="l_inf", choices=["l_inf", "l_0"])
     ap.add_argument("--sync_attack", action="store_true")
     # the other BASELINE.json configs (parity/regression cases, not the headline line)
@@ -385,6 +388,9 @@ def run_rank(a):
                 "--log_dir", os.path.join("/tmp", "dmh_bench_%d" % rank), "--synthetic_len", "1000000"]
         if a.sync_attack:
             argv.append("--sync_attack")
+        if a.shared_patch:
+            argv.append("--shared_patch")
+        argv += ["--atk_batch_size", str(a.atk_scenes)]
         if a.supervised_adv:
             argv.append("--supervised_adv")
         if a.contrastive_learning:
@@ -393,9 +399,10 @@ def run_rank(a):
         opts = MonodepthOptions().parse(argv)
         job = Trainer(opts, rank=rank, world_size=world, device=device)
         job.set_train()
-        workload = ("Monodepth2 ResNet18 %dx%d, %d-step %s attack on 12 scenes, train batch %d/GPU, stereo "
+        workload = ("Monodepth2 ResNet18 %dx%d, %d-step %s attack on %d scenes%s, train batch %d/GPU, stereo "
                     "photometric+SSIM+smoothness loss (%s)%s%s, Adam" % (
-                        a.width, a.height, a.atk_steps, "PGD-L_inf" if a.norm_type == "l_inf" else "L0/Adam",
+                        a.width, a.height, a.atk_steps, "PGD-L_inf" if a.norm_type == "l_inf" else "L0/Adam", a.atk_scenes,
+                        " (ONE patch: scenes sharded over the ranks)" if a.shared_patch and world > 1 else "",
                         a.batch_size, a.loss_variant, " + supervised_adv" if a.supervised_adv else "",
                         " + contrastive" if a.contrastive_learning else ""))
 
@@ -561,6 +568,8 @@ def run_rank(a):
                 note("roofline.step unavailable: %r" % (e,))
         steps_txt = "%d-step %s" % (a.atk_steps, "PGD" if a.norm_type == "l_inf" else "L0")
         metric = "adv-train images/sec @%dx%d, %s, bs%d" % (a.width, a.height, steps_txt, a.batch_size)
+        if a.atk_scenes != 12 or a.shared_patch:
+            metric += ", %d attack scenes%s" % (a.atk_scenes, " (shared patch)" if a.shared_patch else "")
         if a.harness != "trainer":
             metric = "physical_adv_training images/sec @%dx%d, %s patch attack, bs%d" % (a.width, a.height, steps_txt, a.batch_size)
         out = {"metric": metric, "value": round(a.batch_size * world * a.steps / elapsed, 3),
@@ -570,6 +579,7 @@ def run_rank(a):
                "config": {"workload": workload, "baseline_config": BASELINE_CONFIGS[a.config][0], "config_index": a.config,
                           "global_batch": a.batch_size * world, "per_gpu_batch": a.batch_size, "parallelism": "dp%d" % world,
                           "attack_overlap": bool(world > 1 and not a.sync_attack and a.harness == "trainer"),
+                          "attack_scenes": a.atk_scenes, "shared_patch": bool(a.shared_patch),
                           "final_loss": round(loss_val, 6)},
                "roofline": roof}
         if other_mode is not None:

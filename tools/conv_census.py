@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
-"""Which 3x3 convolution shapes of one adversarial-training step take the K10 Winograd kernel and which fall through to
-MIOpen: python3 tools/conv_census.py  (counts per (B, C_in, C_out, H_out, W_out) and the dispatch decision)."""
+"""Which convolution shapes of one adversarial-training step take the hand-written kernels and which fall through to MIOpen:
+
+    python3 tools/conv_census.py [--batch_size 32] [--atk_batch_size 12] [--json out.json]
+
+(counts per (B, C_in, C_out, H_out, W_out) and the K10 dispatch decision; every torch.conv2d / aten.convolution_backward that
+still reaches the library).  --batch_size 4 is the per-rank workload of the strong-scaling point (global batch 32 on 8 GPUs),
+--atk_batch_size 2 its --shared_patch attack share."""
+import argparse
 import collections
+import json
 import os
 import sys
 
@@ -10,6 +17,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from depthmodelhardening_amd import ops  # noqa: E402
 
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch_size", type=int, default=32)
+ap.add_argument("--atk_batch_size", type=int, default=12)
+ap.add_argument("--json", type=str, default=None)
+cli = ap.parse_args()
 census = collections.Counter()
 real_ok = ops._wino_ok
 
@@ -32,13 +44,30 @@ def counting_conv2d(x, w, b=None, stride=1, padding=0, *a, **k):
 
 torch.conv2d = counting_conv2d
 torch.nn.functional.conv2d = counting_conv2d
+backward_lib = collections.Counter()
+real_cb = torch.ops.aten.convolution_backward
+
+
+class _CountingBackward(object):
+    """aten.convolution_backward calls (what the autograd Functions of ops.py still hand to MIOpen)."""
+
+    def __call__(self, g, x, w, bias_sizes, stride, padding, dilation, transposed, output_padding, groups, mask):
+        backward_lib[(tuple(x.shape), tuple(w.shape), str(list(stride)), str(list(padding)), str(list(mask)))] += 1
+        return real_cb(g, x, w, bias_sizes, stride, padding, dilation, transposed, output_padding, groups, mask)
+
+    def __getattr__(self, name):
+        return getattr(real_cb, name)
+
+
+torch.ops.aten.convolution_backward = _CountingBackward()
 
 from depthmodelhardening_amd.options import MonodepthOptions  # noqa: E402
 from depthmodelhardening_amd.trainer import Trainer  # noqa: E402
 
 argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "320", "--width", "1024", "--batch_size",
-        "32", "--learning_rate", "1e-5", "--adv_train", "--norm_type", "l_inf", "--atk_steps", "10", "--weights_init",
-        "scratch", "--model_name", "census", "--log_dir", "/tmp/dmh_census", "--synthetic_len", "1000000"]
+        str(cli.batch_size), "--atk_batch_size", str(cli.atk_batch_size), "--learning_rate", "1e-5", "--adv_train", "--norm_type",
+        "l_inf", "--atk_steps", "10", "--weights_init", "scratch", "--model_name", "census", "--log_dir", "/tmp/dmh_census",
+        "--synthetic_len", "1000000"]
 torch.backends.cudnn.benchmark = False
 job = Trainer(MonodepthOptions().parse(argv), rank=0, world_size=1, device=torch.device("cuda"))
 job.set_train()
@@ -53,3 +82,14 @@ for k, n in sorted(census.items()):
 print("torch.conv2d calls (forward fall-through and non-3x3), one step:")
 for k, n in sorted(fallback.items()):
     print("  x%s w%s stride %s pad %s  x%d" % (k + (n,)))
+print("aten.convolution_backward calls (library weight / data gradients), one step:")
+for k, n in sorted(backward_lib.items()):
+    print("  x%s w%s stride %s pad %s mask %s  x%d" % (k + (n,)))
+if cli.json:
+    json.dump({"batch_size": cli.batch_size, "atk_batch_size": cli.atk_batch_size,
+               "k10_dispatch": [{"B": k[0], "C_in": k[1], "C_out": k[2], "H_out": k[3], "W_out": k[4], "split_ok": k[5],
+                                 "takes_K10": k[6], "calls": n} for k, n in sorted(census.items())],
+               "library_forward": [{"x": k[0], "w": k[1], "stride": k[2], "pad": k[3], "calls": n}
+                                   for k, n in sorted(fallback.items())],
+               "library_backward": [{"x": k[0], "w": k[1], "stride": k[2], "pad": k[3], "mask_x_w_b": k[4], "calls": n}
+                                    for k, n in sorted(backward_lib.items())]}, open(cli.json, "w"), indent=1)
