@@ -81,6 +81,11 @@ _SIGNATURES = {
     "dmh_sq_mean_partials_size": (C.c_int64, [C.c_int64]),
     "dmh_masked_sq_mean_fwd": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, _fp]),
     "dmh_masked_sq_mean_bwd": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, _fp]),
+    "dmh_ssim_map": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
+    "dmh_ssim_map_bwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "dmh_edge_smooth_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "dmh_edge_smooth": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [_fp, _fp, _fp]),
+    "dmh_edge_smooth_bwd": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [_fp, _fp, _fp]),
     "dmh_depth_errors_partials_size": (C.c_int64, [C.c_int64]),
     "dmh_masked_depth_errors": (C.c_int, [_fp, _fp, _fp, C.c_int64] + [C.c_float] * 5 + [_fp, _fp, _fp]),
     "dmh_dec_up_cat_pad_fwd": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp, _fp]),

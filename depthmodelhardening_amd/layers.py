@@ -85,7 +85,13 @@ class Project3D(nn.Module):
 
 
 def get_smooth_loss(disp, img):
-    """Edge-aware first-order smoothness of a (normalised) disparity image."""
+    """Edge-aware first-order smoothness of a (normalised) disparity image (MD2/layers.py:207-220).  fp32 CUDA tensors go
+    through the registered kernel ``torch.ops.dmh.smooth_loss`` (one pass forward, a four-neighbour gather backward; the
+    gradient flows to ``disp`` -- ``img`` is data); anything else takes the reference's formula below."""
+    if (disp.is_cuda and disp.dtype == torch.float32 and img.dtype == torch.float32 and disp.dim() == 4 and disp.shape[1] == 1
+            and img.dim() == 4 and disp.shape[2] >= 2 and disp.shape[3] >= 2 and not img.requires_grad):
+        from . import library  # noqa: F401  (registers torch.ops.dmh.*)
+        return torch.ops.dmh.smooth_loss(disp, img)
     gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
     gdy = torch.abs(disp[:, :, :-1, :] - disp[:, :, 1:, :])
     gix = torch.mean(torch.abs(img[:, :, :, :-1] - img[:, :, :, 1:]), 1, keepdim=True)
@@ -104,6 +110,11 @@ class SSIM(nn.Module):
         self.C2 = 0.03 ** 2
 
     def forward(self, x, y):
+        if x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.dim() == 4 and x.shape == y.shape \
+                and x.shape[2] >= 2 and x.shape[3] >= 2:
+            # the registered kernel (torch.ops.dmh.ssim_map: window sums forward, coefficient-field gathers backward)
+            from . import library  # noqa: F401
+            return torch.ops.dmh.ssim_map(x, y)
         x, y = self.refl(x), self.refl(y)
         mu_x, mu_y = self.pool(x), self.pool(y)
         sigma_x = self.pool(x ** 2) - mu_x ** 2

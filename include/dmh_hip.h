@@ -227,6 +227,22 @@ int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, cons
                            void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Stand-alone forms of the two loss layers of MD2/layers.py (Trainer.compute_losses runs the fused K1 + K2 instead; these
+ * serve callers of the reference surface `SSIM()(x, y)` / `get_smooth_loss(disp, img)`):
+ *   ssim_map   : out[planes,H,W] = clamp((1 - SSIM(x, y)) / 2, 0, 1), 3x3 means over the ReflectionPad2d(1) planes
+ *                (MD2/layers.py:223-253).  bwd: g_x / g_y (either may be NULL); workspace: 5 * planes * H * W floats.
+ *   edge_smooth: out = mean(|d_x disp| exp(-mean_c |d_x img|)) + mean(|d_y disp| exp(-mean_c |d_y img|)) for disp[B,1,H,W],
+ *                img[B,C,H,W] (MD2/layers.py:207-220).  bwd: g_disp = gscale[0] * d out / d disp.
+ * ---------------------------------------------------------------------------------- */
+int dmh_ssim_map(const float* x, const float* y, int planes, int H, int W, float* out, void* stream);
+int dmh_ssim_map_bwd(const float* x, const float* y, const float* g_out, int planes, int H, int W, float* workspace, float* g_x,
+                     float* g_y, void* stream);
+int64_t dmh_edge_smooth_partials_size(int B, int H, int W);
+int dmh_edge_smooth(const float* disp, const float* img, int B, int C, int H, int W, float* partials, float* out, void* stream);
+int dmh_edge_smooth_bwd(const float* disp, const float* img, int B, int C, int H, int W, const float* gscale, float* g_disp,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K8  attack-evaluation metrics of Trainer.val -> evaluate_attacks (MD2/evaluate_depth.py:57-99,193-197):
  *     depth = clamp(5.4 / (min_disp + (max_disp-min_disp)*|disp|), 1e-3, 80) for both disparities, then the
  *     (mask-weighted) abs_err, abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 -> out8.  mask may be NULL.
