@@ -65,7 +65,18 @@ def measured_traffic(B, H, W):
         for key in ("photo_fwd", "photo_bwd"):
             if key + "_kernel" in r["Kernel"]:
                 out[key] = (float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
+                if r.get("SQ_INSTS_VALU"):
+                    out[key + "_valu_insts"] = float(r["SQ_INSTS_VALU"])
     return out
+
+
+def valu_roof(insts, measured_ms):
+    """The vector-issue roof of a VALU-bound kernel: SQ_INSTS_VALU wave-instructions at the chip's rate of one wave64
+    instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: `v_fma_f32` 2 cyc on a SIMD-32 once >= 2 waves are resident; ONE
+    wave alone issues every 4), 1024 SIMDs, 2.4 GHz."""
+    floor_ms = insts * 2.0 / 1024.0 / 2.4e9 * 1e3
+    return {"bound": "valu", "SQ_INSTS_VALU": insts, "cycles_per_wave_instruction": 2, "floor_ms": round(floor_ms, 4),
+            "frac": round(floor_ms / measured_ms, 4) if measured_ms else None}
 
 
 def k1_bytes(B, H, W, scales=4):
@@ -517,8 +528,11 @@ def run_rank(a):
                             "K3 EOT paste (the hot-path kernel of this harness): SURVEY 8d bytes per launch, averaged over the "
                             "launches of the timed region",
                     "avg_ms": round(kms[dom], 4), "algorithmic_bytes": nbytes,
+                    "valu_roof": valu_roof(meas[dom + "_valu_insts"], kms[dom]) if meas.get(dom + "_valu_insts") else None,
                     "others": {names[k][0]: {"avg_ms": round(v, 4), "GB/s": round(names[k][1] / (v * 1e-3) / 1e9, 1),
-                                             "algorithmic_bytes": names[k][1], "traffic": meas.get(k)}
+                                             "algorithmic_bytes": names[k][1], "traffic": meas.get(k),
+                                             "valu_roof": valu_roof(meas[k + "_valu_insts"], v) if meas.get(k + "_valu_insts")
+                                             else None}
                                for k, v in kms.items() if k != dom}}
             # streaming kernels of the decoder glue: shapes vary per launch, so total bytes / total time
             for k, (cnt, ms, nb, fl) in sorted(kbytes.items()):
@@ -538,8 +552,9 @@ def run_rank(a):
                         ent.update({"bound": "hbm", "GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
                                     "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
                         if k == "stem_conv_bwd":
-                            ent["note"] = ("vector-ALU gather (147 FMAs per gradient channel and pixel block, filter in SGPRs): "
-                                           "bound by VALU issue, not by the HBM roof it is listed against")
+                            ent["bound"] = "valu"       # 147 FMAs per gradient channel and 2x2 pixel block on the vector ALU
+                            ent["note"] = ("vector-ALU gather (filter in SGPRs): bound by VALU issue; the GB/s figure is its "
+                                           "algorithmic traffic, not its roof")
                     roof["others"][k + "_kernel"] = ent
         # whole-step compute fraction: U-Net FLOPs per image measured with torch.utils.flop_counter, times the
         # U-Net passes counted in the instrumented step (direct-convolution FLOPs: the Winograd kernels issue 2.25x fewer)

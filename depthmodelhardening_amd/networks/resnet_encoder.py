@@ -235,6 +235,7 @@ class ResnetEncoder(nn.Module):
         self.encoder = ResNet(block, layers, num_input_images)
         self.roi_backward = True    # forward(x, roi=...) may run the head's backward on the attack's windows (ops.encoder_head_eval)
         self.roi_incremental = os.environ.get("DMH_ROI_INCREMENTAL", "1") != "0"     # ... and, given the clean frames, its forward
+        self.roi_incremental_layer2 = os.environ.get("DMH_ROI_LAYER2", "1") != "0"   # ... and layer2's forward and backward
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
@@ -287,6 +288,18 @@ class ResnetEncoder(nn.Module):
             return None
         return [(b.conv1.weight, aff[b.bn1], b.conv2.weight, aff[b.bn2]) for b in l1]
 
+    def _layer2_blocks(self, aff):
+        """layer2 as the ``layer2`` argument of ops.encoder_head_incremental, or None when it is not the ResNet-18 pair (a
+        down-sampling BasicBlock with the standard 3x3/2 + 1x1/2 entry, then a plain stride-1 BasicBlock)."""
+        l2 = self.encoder.layer2
+        if len(l2) != 2 or not all(isinstance(b, BasicBlock) for b in l2):
+            return None
+        a, b = l2
+        if not (a._is_down_pair() and _plain3x3(a.conv2) and b.downsample is None and _plain3x3(b.conv1) and _plain3x3(b.conv2)):
+            return None
+        return ((a.conv1.weight, aff[a.bn1], a.downsample[0].weight, aff[a.downsample[1]], a.conv2.weight, aff[a.bn2]),
+                (b.conv1.weight, aff[b.bn1], b.conv2.weight, aff[b.bn2]))
+
     def _forward_fused_eval(self, input_image, roi=None, clean=None):
         e = self.encoder
         aff = e.eval_affine()
@@ -300,13 +313,20 @@ class ResnetEncoder(nn.Module):
                 if (clean is not None and self.roi_incremental and ops.weights_frozen() and roi[0].head_incremental_ok
                         and clean.shape == input_image.shape and clean.is_cuda and clean.dtype == torch.float32):
                     # forward AND backward of the head on one window per scene, on top of the clean frames' feature 1
-                    cache = ops.frozen_memo(("clean_head", id(self), clean.data_ptr(), clean._version),
-                                            lambda: ops.clean_head(clean, c.weight, aff[e.bn1], blocks))
-                    f0, y = ops.encoder_head_incremental(input_image, roi[0], roi[1], cache, c.weight, aff[e.bn1], blocks)
+                    l2 = self._layer2_blocks(aff) if self.roi_incremental_layer2 else None
+                    if l2 is not None and not (roi[0].layer2_incremental_ok and ops.layer2_incremental_ok(input_image, l2)):
+                        l2 = None
+                    cache = ops.frozen_memo(("clean_head", id(self), clean.data_ptr(), clean._version, l2 is not None),
+                                            lambda: ops.clean_head(clean, c.weight, aff[e.bn1], blocks, l2))
+                    outs = ops.encoder_head_incremental(input_image, roi[0], roi[1], cache, c.weight, aff[e.bn1], blocks, l2)
+                    if l2 is not None:      # conv1 ... layer2 on windows: the whole-frame layers start at layer3
+                        feats, layers = [outs[0], outs[1], outs[2]], layers[2:]
+                    f0, y = outs[0], outs[-1]
                 else:
                     # the attack's encoder head: one node, backward on the plan's windows (K19)
                     f0, y = ops.encoder_head_eval(input_image, roi[0], roi[1], c.weight, aff[e.bn1], blocks)
-                feats, layers = [f0, y], layers[1:]
+                if feats is None:
+                    feats, layers = [f0, y], layers[1:]
         if feats is None:
             z = self._stem(input_image)
             if z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:

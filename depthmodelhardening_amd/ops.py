@@ -1829,17 +1829,25 @@ class CleanHead(object):
     network, into which each attack step writes the cells the pasted object changes ("f1s") and puts the clean values back
     before the next step."""
 
-    def __init__(self, f1):
+    def __init__(self, f1, f2=None):
         self.pristine, self.work = f1, f1.clone()
         self.dirty = None           # (origin table [B,2], (rows, cols)) of the window written by the last step
+        self.pristine2, self.work2 = f2, (None if f2 is None else f2.clone())     # the same for feature 2 (layer2's output)
+        self.dirty2 = None
+
+    @staticmethod
+    def _put_back(pristine, work, dirty):
+        org, (h, w) = dirty
+        B, Cc, H, W = work.shape
+        N.check(N.lib().dmh_roi_paste(N.ptr(pristine), None, H, W, N.ptr(org), B, Cc, H, W, h, w, N.ptr(work), N.stream()))
 
     def restore(self):
         if self.dirty is not None:
-            org, (h, w) = self.dirty
-            B, Cc, H, W = self.work.shape
-            N.check(N.lib().dmh_roi_paste(N.ptr(self.pristine), None, H, W, N.ptr(org), B, Cc, H, W, h, w, N.ptr(self.work),
-                                          N.stream()))
+            self._put_back(self.pristine, self.work, self.dirty)
             self.dirty = None
+        if self.dirty2 is not None:
+            self._put_back(self.pristine2, self.work2, self.dirty2)
+            self.dirty2 = None
 
 
 class _EncHeadInc(torch.autograd.Function):
@@ -1853,7 +1861,9 @@ class _EncHeadInc(torch.autograd.Function):
     stem's adjoint and K12's window form -- d / d image inside the plan's image window "d", zero elsewhere."""
 
     @staticmethod
-    def forward(ctx, x, plan, tab, clean, w_stem, s0, b0, w1a, s1a, b1a, w2a, s2a, b2a, w1b, s1b, b1b, w2b, s2b, b2b):
+    def forward(ctx, x, plan, tab, clean, w_stem, s0, b0, w1a, s1a, b1a, w2a, s2a, b2a, w1b, s1b, b1b, w2b, s2b, b2b, *l2):
+        """``l2`` (optional, 15 tensors): layer2 = a down-sampling block (w3, s1, b1, wd, sd, bd, w2, s2, b2) and a stride-1
+        block (w1, s1, b1, w2, s2, b2) -- evaluated on the plan's "h3" window and returned as a third output."""
         lib = N.lib()
         B, _, H, W = x.shape
         dev = x.device
@@ -1891,14 +1901,48 @@ class _EncHeadInc(torch.autograd.Function):
                                                              H // 4, W // 4, hs_, ws_, N.ptr(clean.work), st),
                        8 * B * 64 * hs_ * ws_))
         clean.dirty = (org["f1s"], (hs_, ws_))
-        ctx.save_for_backward(f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b)
-        ctx.plan, ctx.img = plan, (H, W)
+        saved = [f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b]
+        ctx.plan, ctx.img, ctx.l2 = plan, (H, W), bool(l2)
         ctx.set_materialize_grads(False)
-        return f0, clean.work.detach()      # a fresh alias per step: the cached tensor itself never enters an autograd graph
+        if not l2:
+            ctx.save_for_backward(*saved)
+            return f0, clean.work.detach()  # a fresh alias per step: the cached tensor itself never enters an autograd graph
+        # ---- layer2 on the "h3" window of the 1/8 map: its input is the "h3in" window of feature 1 as just assembled
+        w3, sc1, sh1, wd, scd, shd, w2, sc2, sh2, v1, t1, u1, v2, t2, u2 = l2
+        h3, w3_ = plan.size["h3"]
+        x2 = torch.empty((B, 64, 2 * h3, 2 * w3_), device=dev, dtype=torch.float32)
+        N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(N.ptr(clean.work), None, None, N.ptr(org["h3in"]), B, 64, H // 4,
+                                                           W // 4, 2 * h3, 2 * w3_, 0, N.ptr(x2), st), 8 * x2.numel()))
+        w3s = frozen_memo(("down_w3s", w3.data_ptr(), w3._version, sc1.data_ptr()), lambda: _c(w3 * sc1.view(-1, 1, 1, 1)))
+        wds = frozen_memo(("down_wds", wd.data_ptr(), wd._version, scd.data_ptr()), lambda: _c(wd * scd.view(-1, 1, 1, 1)))
+        Co = w3.shape[0]
+        q1 = torch.empty((B, Co, h3, w3_), device=dev, dtype=torch.float32)
+        idt = torch.empty_like(q1)
+        N.check(_timed("down_conv_fwd", lambda: lib.dmh_down_conv_fwd_act(
+            N.ptr(x2), N.ptr(w3s), N.ptr(wds), N.ptr(sh1), N.ptr(shd), 1, B, 64, Co, 2 * h3, 2 * w3_, N.ptr(q1), N.ptr(idt), st),
+            4 * (x2.numel() + 2 * q1.numel()), 20 * 64 * q1.numel()))
+
+        def conv_act2(inp, w, sc, sh, res):
+            y = torch.empty_like(inp)
+            N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+                N.ptr(inp), N.ptr(_wino_filter(w, False, sc)), N.ptr(sh), N.ptr(res), 1, B, Co, Co, h3, w3_, 1, N.ptr(y), st),
+                4 * (2 + (res is not None)) * inp.numel(), 18 * Co * inp.numel()))
+            return y
+
+        y2a = conv_act2(q1, w2, sc2, sh2, idt)
+        q2 = conv_act2(y2a, v1, t1, u1, None)
+        f2c = conv_act2(q2, v2, t2, u2, y2a)
+        hf, wf = plan.size["f2s"]
+        N.check(_timed("roi_paste", lambda: lib.dmh_roi_paste(N.ptr(f2c), N.ptr(org["h3"]), h3, w3_, N.ptr(org["f2s"]), B, Co,
+                                                             H // 8, W // 8, hf, wf, N.ptr(clean.work2), st), 8 * B * Co * hf * wf))
+        clean.dirty2 = (org["f2s"], (hf, wf))
+        ctx.save_for_backward(*saved, q1, y2a, q2, f2c, w3, sc1, wd, scd, w2, sc2, v1, t1, v2, t2)
+        return f0, clean.work.detach(), clean.work2.detach()
 
     @staticmethod
-    def backward(ctx, g_f0, g_f1):
-        f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b = ctx.saved_tensors
+    def backward(ctx, g_f0, g_f1, g_f2=None):
+        sv = ctx.saved_tensors
+        f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b = sv[:17]
         plan, (H, W) = ctx.plan, ctx.img
         lib = N.lib()
         dev = f0.device
@@ -1908,6 +1952,44 @@ class _EncHeadInc(torch.autograd.Function):
         hl, wl = plan.size["hl"]
         hz, wz = 2 * hl, 2 * wl
         g_pool = None
+        f1_frame, f1_org = (H // 4, W // 4), org["hl"]          # where feature 1's gradient lives: the whole 1/4 map ...
+        if ctx.l2 and g_f2 is not None:
+            # ---- layer2's backward on "h3": feature 1's gradient comes out as the "h3in" window (which holds "hl")
+            q1, y2a, q2, f2c, w3, sc1, wd, scd, w2, sc2, v1, t1, v2, t2 = sv[17:]
+            h3, w3_ = plan.size["h3"]
+            Co = w3.shape[0]
+
+            def conv_bwd2(g, w, sc, res, flag):
+                y = torch.empty_like(g)
+                N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+                    N.ptr(g), N.ptr(_wino_filter(w, True, sc)), None, N.ptr(res), flag, B, Co, Co, h3, w3_, 1, N.ptr(y), st),
+                    4 * 3 * g.numel(), 18 * Co * g.numel()))
+                return y
+
+            gb = torch.empty_like(f2c)                                     # g * [f2 > 0] on the window
+            N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(N.ptr(_c(g_f2)), N.ptr(f2c), None, N.ptr(org["h3"]), B, Co, H // 8,
+                                                               W // 8, h3, w3_, 1, N.ptr(gb), st), 12 * gb.numel()))
+            g1b = conv_bwd2(gb, v2, t2, q2, 2)
+            g_y2a = conv_bwd2(g1b, v1, t1, gb, 0)
+            g2 = torch.empty_like(g_y2a)                                   # * [y2a > 0]: bn2's output and the shortcut's
+            N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(None, N.ptr(y2a), N.ptr(g_y2a), N.ptr(org["h3"]), B, Co, H // 8,
+                                                               W // 8, h3, w3_, 1, N.ptr(g2), st), 12 * g2.numel()))
+            g1 = conv_bwd2(g2, w2, sc2, q1, 2)
+            gskip = None
+            if g_f1 is not None:            # the decoder's skip gradient, on the same window: added in K15's epilogue
+                gskip = torch.empty((B, 64, 2 * h3, 2 * w3_), device=dev, dtype=torch.float32)
+                N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(N.ptr(_c(g_f1)), None, None, N.ptr(org["h3in"]), B, 64, H // 4,
+                                                                   W // 4, 2 * h3, 2 * w3_, 0, N.ptr(gskip), st),
+                               8 * gskip.numel()))
+            w3ts = frozen_memo(("down_w3ts", w3.data_ptr(), w3._version, sc1.data_ptr()),
+                               lambda: _c((w3 * sc1.view(-1, 1, 1, 1)).transpose(0, 1)))
+            wdts = frozen_memo(("down_wdts", wd.data_ptr(), wd._version, scd.data_ptr()),
+                               lambda: _c((wd * scd.view(-1, 1, 1, 1)).reshape(Co, 64).t()))
+            g_f1 = torch.empty((B, 64, 2 * h3, 2 * w3_), device=dev, dtype=torch.float32)
+            N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data_acc(
+                N.ptr(g1), N.ptr(g2), N.ptr(w3ts), N.ptr(wdts), N.ptr(gskip), B, 64, Co, 2 * h3, 2 * w3_, N.ptr(g_f1), st),
+                4 * (g_f1.numel() * (1 if gskip is None else 2) + 2 * g1.numel()), 20 * 64 * g1.numel()))
+            f1_frame, f1_org = (2 * h3, 2 * w3_), org["hl_rel"]             # ... or that window, "hl" at its relative origin
         if g_f1 is not None:
             def conv_bwd(g, w, s, res, flag):
                 y = torch.empty_like(g)
@@ -1918,8 +2000,8 @@ class _EncHeadInc(torch.autograd.Function):
 
             g_f1 = _c(g_f1)
             g2b = torch.empty_like(f1c)                                     # g * [y_b > 0] on the window
-            N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(N.ptr(g_f1), N.ptr(f1c), None, N.ptr(org["hl"]), B, 64, H // 4,
-                                                               W // 4, hl, wl, 1, N.ptr(g2b), st), 12 * g2b.numel()))
+            N.check(_timed("roi_crop", lambda: lib.dmh_roi_crop(N.ptr(g_f1), N.ptr(f1c), None, N.ptr(f1_org), B, 64, f1_frame[0],
+                                                               f1_frame[1], hl, wl, 1, N.ptr(g2b), st), 12 * g2b.numel()))
             g1b = conv_bwd(g2b, w2b, s2b, o1b, 2)                           # ... * [out1_b > 0]
             g_ya = conv_bwd(g1b, w1b, s1b, g2b, 0)                          # + the identity branch
             g2a = torch.empty_like(g_ya)                                    # * [y_a > 0]
@@ -1927,8 +2009,9 @@ class _EncHeadInc(torch.autograd.Function):
                                                                W // 4, hl, wl, 1, N.ptr(g2a), st), 12 * g2a.numel()))
             g1a = conv_bwd(g2a, w2a, s2a, o1a, 2)
             g_pool = conv_bwd(g1a, w1a, s1a, g2a, 0)
+        n_in = 19 + (15 if ctx.l2 else 0)
         if g_pool is None and g_f0 is None:
-            return (None,) * 19
+            return (None,) * n_in
         g_z = torch.empty_like(f0)
         N.check(_timed("stem_bwd", lambda: lib.dmh_stem_bn_relu_pool_bwd(
             N.ptr(f0), N.ptr(arg), N.ptr(None if g_f0 is None else _c(g_f0)), N.ptr(g_pool), N.ptr(s0), B, 64, hz, wz, N.ptr(g_z),
@@ -1940,24 +2023,44 @@ class _EncHeadInc(torch.autograd.Function):
         N.check(_timed("stem_conv_bwd_win", lambda: lib.dmh_conv7x7s2_bwd_data_win(
             N.ptr(g_z), N.ptr(w_s), N.ptr(org["d"]), N.ptr(org["hz"]), B, 64, 3, H, W, hd, wd, hz, wz, N.ptr(g_x), st),
             4 * (g_z.numel() + B * 3 * hd * wd)))
-        return (g_x,) + (None,) * 18
+        return (g_x,) + (None,) * (n_in - 1)
 
 
-def clean_head(x_clean, conv1_weight, aff0, blocks):
-    """CleanHead of the clean frames ``x_clean`` [B,3,H,W]: feature 1 through the whole-frame head, no gradient."""
+def clean_head(x_clean, conv1_weight, aff0, blocks, layer2=None):
+    """CleanHead of the clean frames ``x_clean`` [B,3,H,W]: feature 1 (and, with ``layer2`` = (down block, block) as in
+    encoder_head_incremental, feature 2) through the whole-frame kernels, no gradient."""
     with torch.no_grad():
         z = stem_conv_norm(x_clean, conv1_weight, 0.45, 0.225)
         _, y = stem_bn_relu_pool(z, aff0[0], aff0[1])
         for w1, a1, w2, a2 in blocks:
             o = conv3x3_bn_act(y, w1, a1[0], a1[1], None, True, 1)
             y = conv3x3_bn_act(o, w2, a2[0], a2[1], y, True, 1)
-    return CleanHead(y)
+        f2 = None
+        if layer2 is not None:
+            (w3, a1, wd, ad, w2, a2), (v1, c1, v2, c2) = layer2
+            f2 = down_block_eval(y, w3, a1[0], a1[1], wd, ad[0], ad[1], w2, a2[0], a2[1])
+            o = conv3x3_bn_act(f2, v1, c1[0], c1[1], None, True, 1)
+            f2 = conv3x3_bn_act(o, v2, c2[0], c2[1], f2, True, 1)
+    return CleanHead(y, f2)
 
 
-def encoder_head_incremental(x, plan, tab, clean, conv1_weight, aff0, blocks):
-    """(feature 0 on its "hz" window, feature 1) of the ResNet-18 encoder for an attack step whose image ``x`` differs from
-    the clean frames behind ``clean`` (ops.clean_head) inside the plan's boxes only -- see _EncHeadInc.  Marks the plan:
-    head_windowed (feature 0's gradient is read inside the window) and f0_compact (feature 0 IS the window)."""
+def layer2_incremental_ok(x, layer2):
+    """layer2 = a 64 -> 128 down-sampling block + a stride-1 block whose kernels (K15, K10) take the whole-frame shape."""
+    if layer2 is None:
+        return False
+    (w3, _, wd, _, w2, _), (v1, _, v2, _) = layer2
+    B, _, H, W = x.shape
+    probe = x.new_empty((B, 64, H // 4, W // 4))
+    return (tuple(w3.shape) == (128, 64, 3, 3) and tuple(wd.shape) == (128, 64, 1, 1) and down_convs_ok(probe, w3, wd)
+            and all(tuple(w.shape) == (128, 128, 3, 3) for w in (w2, v1, v2)) and DOWN_NODE_ENABLED
+            and _wino_ok(B, 128, 128, H // 8, W // 8, allow_split=False))
+
+
+def encoder_head_incremental(x, plan, tab, clean, conv1_weight, aff0, blocks, layer2=None):
+    """(feature 0 on its "hz" window, feature 1[, feature 2]) of the ResNet-18 encoder for an attack step whose image ``x``
+    differs from the clean frames behind ``clean`` (ops.clean_head) inside the plan's boxes only -- see _EncHeadInc.  Marks the
+    plan: head_windowed (feature 0's gradient is read inside the window) and f0_compact (feature 0 IS the window).  ``layer2``:
+    ((w3, aff1, wd, aff_d, w2, aff2), (w1, aff1, w2, aff2)) -- then layer2 runs on the plan's "h3" window as well."""
     ws = [(b[0], b[2]) for b in blocks]
     if not encoder_head_ok(x, conv1_weight, ws) or not plan.head_incremental_ok:
         raise RuntimeError("encoder_head_incremental: needs ops.frozen_weights(), the ResNet-18 head and a plan whose \"hz\" "
@@ -1969,6 +2072,13 @@ def encoder_head_incremental(x, plan, tab, clean, conv1_weight, aff0, blocks):
     args = [d(conv1_weight), d(aff0[0]), d(aff0[1])]
     for w1, a1, w2, a2 in blocks:
         args += [w1.detach(), d(a1[0]), d(a1[1]), w2.detach(), d(a2[0]), d(a2[1])]
+    if layer2 is not None:
+        if not (layer2_incremental_ok(x, layer2) and plan.layer2_incremental_ok and clean.work2 is not None):
+            raise RuntimeError("encoder_head_incremental: layer2 given, but its shapes / the plan's \"h3\" window / the clean "
+                               "feature 2 do not allow the incremental form")
+        (w3, a1, wd, ad, w2, a2), (v1, c1, v2, c2) = layer2
+        args += [w3.detach(), d(a1[0]), d(a1[1]), wd.detach(), d(ad[0]), d(ad[1]), w2.detach(), d(a2[0]), d(a2[1]),
+                 v1.detach(), d(c1[0]), d(c1[1]), v2.detach(), d(c2[0]), d(c2[1])]
     plan.head_windowed = plan.f0_compact = True
     return _EncHeadInc.apply(_c(x), plan, _c(tab), clean, *args)
 

@@ -35,10 +35,15 @@ MAX_DEPTH = 4
 # Incremental forward of the encoder head (ops.encoder_head_incremental): the pasted object changes the image inside the
 # box only, so conv1 ... layer1 are recomputed on "hl" (1/4 map; "hz" = the same window on the 1/2 map, twice the size) and
 # the part of feature 1 that really changes, "f1s", is written into the cached feature of the clean scenes
-REGIONS = ("r_f0", "r_f1", "r_f2", "r_f3", "r_y20", "r_y30", "r_y40", "gz", "l1", "hl", "hz", "f1s")
+# ... and layer2 on "h3" (1/8 map; "h3in" = the same window on the 1/4 map, its input), writing "f2s" into the cached
+# feature 2; "hl_rel" = the origin of "hl" inside "h3in" (layer2's backward hands layer1's its input gradient as that window)
+REGIONS = ("r_f0", "r_f1", "r_f2", "r_f3", "r_y20", "r_y30", "r_y40", "gz", "l1", "hl", "hz", "f1s", "h3", "h3in", "f2s",
+           "hl_rel")
 LEVEL.update({"r_f0": 1, "r_f1": 2, "r_f2": 3, "r_f3": 4, "r_y20": 3, "r_y30": 4, "r_y40": 5, "gz": 1, "l1": 2, "hl": 2,
-              "hz": 1, "f1s": 2})
+              "hz": 1, "f1s": 2, "h3": 3, "h3in": 2, "f2s": 3, "hl_rel": 2})
 _HEAD_RING = 9      # max-pool (1) + layer1 forward (4) + what layer1's backward needs around its own target (4)
+_L2_FWD_RING = 5    # layer2 forward on a compact window: the stride-2 entry + three convolutions spoil 4 rings (top / left)
+_L2_BWD_RING = 8    # ... and its backward three more before the stride-2 adjoint reads it
 TABLE = WINDOWS + REGIONS
 _L1_RING = 4                                # layer1 = two BasicBlocks = four 3x3 convolutions: each spoils one ring
 
@@ -141,6 +146,34 @@ class RoiPlan(object):
                   (np.maximum(bx[0] - _HEAD_RING, 0), np.minimum(bx[1] + _HEAD_RING, W >> 2)))
         hl, ol = self.size["hl"], self.org["hl"]
         self.size["hz"], self.org["hz"] = (2 * hl[0], 2 * hl[1]), (2 * ol).astype(np.int32)
+        # ---- layer2 on a compact window of the 1/8 map.  Forward: the changed cells of feature 1 ("f1s") reach output cell i
+        # of the stride-2 entry (rows 2i-1 .. 2i+1) and three more convolutions; backward: layer1's backward reads feature
+        # 1's gradient on all of "hl", which the stride-2 adjoint forms from the cells above it
+        f1o, (f1h, f1w) = self.org["f1s"].astype(np.int64), self.size["f1s"]
+        hlo, (hlh, hlw) = self.org["hl"].astype(np.int64), self.size["hl"]
+        p3y = f1o[:, 0] >> 1, np.minimum(((f1o[:, 0] + f1h) >> 1) + 1, H >> 3)
+        p3x = f1o[:, 1] >> 1, np.minimum(((f1o[:, 1] + f1w) >> 1) + 1, W >> 3)
+        fs = ()
+        for lo, hi, frame in ((np.maximum(p3y[0] - 3, 0), np.minimum(p3y[1] + 3, H >> 3), H >> 3),
+                              (np.maximum(p3x[0] - 3, 0), np.minimum(p3x[1] + 3, W >> 3), W >> 3)):
+            size = int((hi - lo).max())
+            fs += (size, np.minimum(lo, frame - size))
+        self.size["f2s"] = (fs[0], fs[2])
+        self.org["f2s"] = np.stack([fs[1], fs[3]], 1).astype(np.int32)
+        f2o = self.org["f2s"].astype(np.int64)
+        q3y = hlo[:, 0] >> 1, np.minimum(((hlo[:, 0] + hlh) >> 1) + 1, H >> 3)
+        q3x = hlo[:, 1] >> 1, np.minimum(((hlo[:, 1] + hlw) >> 1) + 1, W >> 3)
+        cy = (np.maximum(np.minimum(f2o[:, 0] - _L2_FWD_RING, q3y[0] - _L2_BWD_RING), 0),
+              np.minimum(np.maximum(f2o[:, 0] + fs[0] + _L2_FWD_RING, q3y[1] + _L2_BWD_RING), H >> 3))
+        cx = (np.maximum(np.minimum(f2o[:, 1] - _L2_FWD_RING, q3x[0] - _L2_BWD_RING), 0),
+              np.minimum(np.maximum(f2o[:, 1] + fs[2] + _L2_FWD_RING, q3x[1] + _L2_BWD_RING), W >> 3))
+        self._put("h3", cy, cx)
+        h3, o3 = self.size["h3"], self.org["h3"]
+        self.size["h3in"], self.org["h3in"] = (2 * h3[0], 2 * h3[1]), (2 * o3).astype(np.int32)
+        self.size["hl_rel"], self.org["hl_rel"] = (hlh, hlw), (hlo - 2 * o3.astype(np.int64)).astype(np.int32)
+        rel = self.org["hl_rel"].astype(np.int64)
+        self.layer2_incremental_ok = bool((rel >= 0).all() and (rel[:, 0] + hlh <= 2 * h3[0]).all()
+                                          and (rel[:, 1] + hlw <= 2 * h3[1]).all() and (rel % 2 == 0).all())
         # the tail reads feature 0 inside "r_f0" and the head's backward reads conv1's gradient inside "gz": both lie in "hz"
         for nm in ("r_f0", "gz"):
             (hh, ww), oo = self.size[nm], self.org[nm]

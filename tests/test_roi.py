@@ -82,7 +82,20 @@ def test_plan_covers_every_read_for_all_training_poses():
             z0_, zn = plan.org["hz"][:, ax].astype(int), plan.size["hz"][ax]
             assert (z0_ == 2 * h0).all() and zn == 2 * hn
             assert (z0_ <= s0).all() and (z0_ + zn >= s0 + sn).all() and (z0_ <= f0_).all() and (z0_ + zn >= f0_ + fn).all()
-        assert plan.head_incremental_ok
+        assert plan.head_incremental_ok and plan.layer2_incremental_ok
+        # layer2 on "h3": the cells written into feature 2 ("f2s") lie inside it minus the rings its stages spoil (stride-2
+        # entry + three convolutions: 4 top / left, 3 bottom / right); the cells whose gradient the stride-2 adjoint reads to
+        # cover "hl" lie 7 rings inside; "h3in" = 2 x "h3" holds "hl" at the even origin "hl_rel"
+        for ax, (f8, f4) in enumerate(((H >> 3, H >> 2), (W >> 3, W >> 2))):
+            c0, cn = plan.org["h3"][:, ax].astype(int), plan.size["h3"][ax]
+            w0, wn = plan.org["f2s"][:, ax].astype(int), plan.size["f2s"][ax]
+            assert (((w0 - c0) >= 4) | (c0 == 0)).all() and ((((c0 + cn) - (w0 + wn)) >= 3) | (c0 + cn == f8)).all()
+            l0, ln = plan.org["hl"][:, ax].astype(int), plan.size["hl"][ax]
+            q0, q1 = l0 >> 1, np.minimum(((l0 + ln) >> 1) + 1, f8)
+            assert (((q0 - c0) >= 7) | (c0 == 0)).all() and ((((c0 + cn) - q1) >= 7) | (c0 + cn == f8)).all()
+            r0 = plan.org["hl_rel"][:, ax].astype(int)
+            assert (r0 == l0 - 2 * c0).all() and (r0 >= 0).all() and (r0 + ln <= 2 * cn).all() and (r0 % 2 == 0).all()
+            assert (plan.org["h3in"][:, ax] == 2 * c0).all() and plan.size["h3in"][ax] == 2 * cn
     # the windows are a small part of the frame even for the nearest object
     near = RoiPlan(pt.mask_boxes([5.0], [0], (H, W)), H, W)
     assert near.area_fraction()["z01"] < 0.25 and near.area_fraction()["l1"] < 0.35
@@ -367,7 +380,12 @@ def test_incremental_encoder_head_equals_the_full_one():
             tab = to_device_async(plan.table(), dev)
             x0, m = ops.eot_paste(scenes, obj, pmask, to_device_async(pt.coeffs_for(z0, al), dev), pt.l_pad, pt.t_pad, (H, W))
             assert float(((x0 - clean) * (m == 0)).abs().max()) == 0.0       # the premise: equal outside the mask
-            g_f1 = torch.randn(B, 64, H // 4, W // 4, generator=g).to(dev)
+            g_f1 = torch.zeros(B, 64, H // 4, W // 4)           # the decoder's skip gradient: lives inside "r_f1"
+            (rh, rw), ro = plan.size["r_f1"], plan.org["r_f1"]
+            for b in range(B):
+                g_f1[b, :, ro[b, 0]:ro[b, 0] + rh, ro[b, 1]:ro[b, 1] + rw] = torch.randn(64, rh, rw, generator=g)
+            g_f1 = g_f1.to(dev)
+            g_f2 = torch.randn(B, 128, H // 8, W // 8, generator=g).to(dev)      # dense: it comes down from layer3
             hz, oz = plan.size["hz"], plan.org["hz"]
             g_f0c = torch.randn(B, 64, hz[0], hz[1], generator=g).to(dev)
             g_f0 = torch.zeros(B, 64, H // 2, W // 2, device=dev)
@@ -376,7 +394,7 @@ def test_incremental_encoder_head_equals_the_full_one():
             # whole-frame reference (the plain nodes)
             x = x0.clone().requires_grad_(True)
             ref = enc(x)
-            (gx_ref,) = torch.autograd.grad([ref[0], ref[1]], x, [g_f0, g_f1])
+            (gx_ref,) = torch.autograd.grad([ref[0], ref[1], ref[2]], x, [g_f0, g_f1, g_f2])
             # incremental
             x = x0.clone().requires_grad_(True)
             feats = enc(x, roi=(plan, tab), clean=clean)
@@ -386,7 +404,7 @@ def test_incremental_encoder_head_equals_the_full_one():
                 assert torch.equal(feats[0][b], ref[0][b, :, oz[b, 0]:oz[b, 0] + hz[0], oz[b, 1]:oz[b, 1] + hz[1]])
             for k in (2, 3, 4):
                 assert torch.equal(feats[k], ref[k])
-            (gx,) = torch.autograd.grad([feats[0], feats[1]], x, [g_f0c, g_f1])
+            (gx,) = torch.autograd.grad([feats[0], feats[1], feats[2]], x, [g_f0c, g_f1, g_f2])
             (hd, wd), od = plan.size["d"], plan.org["d"]
             inside = torch.zeros(B, 1, H, W, device=dev)
             for b in range(B):
@@ -396,10 +414,11 @@ def test_incremental_encoder_head_equals_the_full_one():
             print("incremental encoder head vs full, inside the image window: max err / max |g| = %.3g" % err)
             assert err <= 1e-6
             del plan_full
-        cache = ops.frozen_memo(("clean_head", id(enc), clean.data_ptr(), clean._version), lambda: None)
+        cache = ops.frozen_memo(("clean_head", id(enc), clean.data_ptr(), clean._version, True), lambda: None)
         assert cache is not None and cache.dirty is not None and not torch.equal(cache.work, cache.pristine)
+        assert cache.dirty2 is not None and not torch.equal(cache.work2, cache.pristine2)
         cache.restore()
-        assert torch.equal(cache.work, cache.pristine)
+        assert torch.equal(cache.work, cache.pristine) and torch.equal(cache.work2, cache.pristine2)
         # the check bites: frames that differ from the clean ones outside the box give a different feature 1
         x_bad = x0.clone()
         x_bad[:, :, :8, :8] += 0.25
