@@ -28,15 +28,17 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header(tmp_path):
     from depthmodelhardening_amd import _native
     src = tmp_path / "sz.c"
-    src.write_text('#include "dmh_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include "dmh_hip.h"\n#include <stdio.h>\n#include <stddef.h>\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(dmh_photo_args),sizeof(dmh_smooth_args),sizeof(dmh_paste_args),'
-                   'offsetof(dmh_photo_args,seed),offsetof(dmh_paste_args,mode));return 0;}\n')
+                   'offsetof(dmh_photo_args,seed),offsetof(dmh_paste_args,mode),sizeof(dmh_roi_glue_args),'
+                   'offsetof(dmh_roi_glue_args,B),offsetof(dmh_roi_glue_args,elu));return 0;}\n')
     exe = tmp_path / "sz"
     assert os.system("gcc -I%s %s -o %s" % (os.path.join(REPO, "include"), src, exe)) == 0
     out = os.popen(str(exe)).read().split()
     assert [int(v) for v in out] == [ctypes.sizeof(_native.PhotoArgs), ctypes.sizeof(_native.SmoothArgs),
                                      ctypes.sizeof(_native.PasteArgs), _native.PhotoArgs.seed.offset,
-                                     _native.PasteArgs.mode.offset]
+                                     _native.PasteArgs.mode.offset, ctypes.sizeof(_native.RoiGlueArgs),
+                                     _native.RoiGlueArgs.B.offset, _native.RoiGlueArgs.elu.offset]
 
 
 def test_host_side_argument_checks_without_gpu():
@@ -78,3 +80,31 @@ def test_convolution_entry_points_reject_bad_shapes_without_gpu():
     assert lib.dmh_bn_stats_partials_size(0, 8, 100) == -1
     assert lib.dmh_stem_bn_relu_pool_fwd(one, one, one, 1, 2, 3, 4, one, one, one, None) != 0
     assert b"even" in lib.dmh_last_error()
+
+
+def test_window_entry_points_reject_bad_shapes_without_gpu():
+    """K19 (windowed glue / cost / encoder-head passes) and the stand-alone layers kernels: host-side argument checks and
+    size helpers, no launch."""
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    one = ctypes.c_void_p(16)
+    a = N.RoiGlueArgs()
+    assert lib.dmh_roi_glue_fwd(ctypes.byref(a), one, None) != 0 and b"null pointer" in lib.dmh_last_error()
+    a.y, a.dst_org = one, one
+    a.B, a.C1, a.C2, a.sh, a.sw, a.hc, a.wc, a.H, a.W = 2, 8, 0, 10, 10, 6, 5, 16, 16      # odd window width
+    assert lib.dmh_roi_glue_fwd(ctypes.byref(a), one, None) != 0 and b"even width" in lib.dmh_last_error()
+    a.wc = 20                                                                            # window wider than its frame
+    assert lib.dmh_roi_glue_bwd(ctypes.byref(a), one, one, None, None, 0, 0, None, 0, 0, None) != 0
+    a.wc, a.y_org = 6, one                                                               # a region needs a whole-frame y
+    assert lib.dmh_roi_glue_bwd(ctypes.byref(a), one, one, None, one, 4, 4, None, 0, 0, None) != 0
+    assert b"whole-frame y" in lib.dmh_last_error()
+    assert lib.dmh_roi_cost_partials_size(12, 174, 208) == 12 * 36
+    assert lib.dmh_roi_cost_fwd(one, one, one, 2, 40, 40, 32, 64, one, one, one, None) != 0        # window taller than the frame
+    assert lib.dmh_roi_crop(one, None, None, one, 2, 8, 16, 16, 6, 5, 0, one, None) != 0           # odd width
+    assert lib.dmh_roi_crop(one, None, one, one, 2, 8, 16, 16, 6, 6, 0, one, None) != 0            # both src and g
+    assert lib.dmh_roi_paste(one, one, 4, 4, one, 2, 8, 16, 16, 6, 6, one, None) != 0              # source smaller than the window
+    assert lib.dmh_stem_bn_relu_pool_bwd_win(one, one, None, one, one, one, one, 2, 8, 16, 16, 6, 5, 4, 4, one, None) != 0
+    assert lib.dmh_conv7x7s2_bwd_data_win(one, one, one, one, 2, 64, 3, 32, 64, 12, 15, 8, 10, one, None) != 0   # odd window
+    assert lib.dmh_stem_conv_norm_fwd_win(one, one, one, 2, 32, 64, 20, 10, 0.45, 0.225, one, None) != 0        # taller than H/2
+    assert lib.dmh_ssim_map(one, one, 6, 1, 8, one, None) != 0 and lib.dmh_edge_smooth_partials_size(2, 32, 96) == 2 * 2 * 3
+    assert lib.dmh_edge_smooth(one, one, 2, 3, 1, 8, one, one, None) != 0
