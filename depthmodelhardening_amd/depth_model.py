@@ -30,6 +30,8 @@ class DepthModelWrapper(torch.nn.Module):
         head's forward does too."""
         from . import ops
         roi_dec = plan is not None and hasattr(self.decoder, "roi_ok")
+        if plan is not None:        # what THIS call's encoder does with the plan (a plan may be used for more than one call)
+            plan.head_windowed = plan.f0_compact = False
         if roi_dec and getattr(self.encoder, "roi_backward", False):
             feats = self.encoder(input_image, roi=(plan, tab), clean=clean)
         else:

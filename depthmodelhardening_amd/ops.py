@@ -1829,7 +1829,9 @@ class CleanHead(object):
     network, into which each attack step writes the cells the pasted object changes ("f1s") and puts the clean values back
     before the next step."""
 
-    def __init__(self, f1, f2=None):
+    def __init__(self, f1, f2=None, frames=None):
+        self.frames = frames        # the clean frames themselves: kept alive, so that their address cannot name other data
+        self.generation = 0         # bumped by every step that writes into `work`: a backward of an older step must not run
         self.pristine, self.work = f1, f1.clone()
         self.dirty = None           # (origin table [B,2], (rows, cols)) of the window written by the last step
         self.pristine2, self.work2 = f2, (None if f2 is None else f2.clone())     # the same for feature 2 (layer2's output)
@@ -1896,6 +1898,8 @@ class _EncHeadInc(torch.autograd.Function):
         f1c = conv_act(o1b, w2b, s2b, b2b, ya)
         # feature 1 = the clean scenes' feature with the changed cells written in (the clean values return before the next step)
         clean.restore()
+        clean.generation += 1
+        ctx.clean, ctx.generation = clean, clean.generation
         hs_, ws_ = plan.size["f1s"]
         N.check(_timed("roi_paste", lambda: lib.dmh_roi_paste(N.ptr(f1c), N.ptr(org["hl"]), hl, wl, N.ptr(org["f1s"]), B, 64,
                                                              H // 4, W // 4, hs_, ws_, N.ptr(clean.work), st),
@@ -1941,6 +1945,9 @@ class _EncHeadInc(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_f0, g_f1, g_f2=None):
+        if ctx.clean.generation != ctx.generation:
+            raise RuntimeError("encoder_head_incremental: a later forward has re-written the cached clean features this graph's "
+                               "feature 1 / 2 alias; run each step's backward before the next step's forward")
         sv = ctx.saved_tensors
         f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b = sv[:17]
         plan, (H, W) = ctx.plan, ctx.img
@@ -2041,7 +2048,7 @@ def clean_head(x_clean, conv1_weight, aff0, blocks, layer2=None):
             f2 = down_block_eval(y, w3, a1[0], a1[1], wd, ad[0], ad[1], w2, a2[0], a2[1])
             o = conv3x3_bn_act(f2, v1, c1[0], c1[1], None, True, 1)
             f2 = conv3x3_bn_act(o, v2, c2[0], c2[1], f2, True, 1)
-    return CleanHead(y, f2)
+    return CleanHead(y, f2, x_clean)
 
 
 def layer2_incremental_ok(x, layer2):

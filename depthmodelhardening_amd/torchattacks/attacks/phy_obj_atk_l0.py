@@ -45,7 +45,9 @@ class Phy_obj_atk_l0(Attack):
         self.phy_trans_ben = PhysicalTrans(self.obj_img, self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
         self.use_roi = True     # evaluate the adversarial cost on windows around the object when the model offers it
+        self.shard = None       # (rank, world, group): data-parallel shared-patch mode, see Phy_obj_atk.shard
         self.trace = None  # set to a list to record (l0, mask_weight, adv_cost, mask_cost) per iteration
+        self.grad_trace = None  # set to a list to record the two pattern gradients Adam is handed, per iteration (tests)
 
     def cal_l0(self):
         """Number of pixels whose thresholded pattern is non-zero (:43-52), as a device tensor."""
@@ -63,7 +65,19 @@ class Phy_obj_atk_l0(Attack):
             images = F.interpolate(images, size=[ori_H, ori_W], mode="bilinear", align_corners=False)
             print("image size inconsistent in l0 attack")
         images = images.detach().to(self.device)
-        if img_B != 1 and img_B != batch_size:
+        # data-parallel "shared patch" mode (see Phy_obj_atk.shard): this rank holds scenes rank, rank + world, ... of the
+        # batch; rank 0's initial patterns and pose draws are the job's; the two pattern gradients are summed over the ranks
+        mine, share, world, group, src = None, 1.0, 1, None, 0
+        if self.shard is not None:
+            import torch.distributed as dist
+            rank, world, group = self.shard
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            mine = list(range(rank, batch_size, world))
+            if not mine:
+                raise RuntimeError("Phy_obj_atk_l0.shard: more ranks than attack scenes is not supported")
+            share = len(mine) / float(batch_size)
+        n_local = batch_size if mine is None else len(mine)
+        if img_B != 1 and img_B != n_local:
             raise RuntimeError('Batch size doesn\'t match!')
         scene_imgs = images
 
@@ -73,6 +87,8 @@ class Phy_obj_atk_l0(Attack):
             init_pattern = np.random.random(self.obj_img.size()) * self.clip_max
             init_pattern = np.clip(init_pattern, 0.0, self.clip_max) / self.clip_max
             t = torch.Tensor(init_pattern).to(self.device)
+            if mine is not None:
+                dist.broadcast(t, src=src, group=group)
             t.requires_grad = True
             pats.append(t)
         self.pattern_pos_tensor, self.pattern_neg_tensor = pats
@@ -88,6 +104,14 @@ class Phy_obj_atk_l0(Attack):
         for _ in range(max_iter):
             draws.append(pt.draw_samples(batch_size))
             rng_states.append(random.getstate())
+        final_draw = None
+        if mine is not None:        # the job's draws are rank 0's (the final pose draw included); keep the own scenes' poses
+            fin = (sample(pt.dist_range, batch_size), sample(pt.angle_range, batch_size))
+            box = [draws + [fin]]
+            dist.broadcast_object_list(box, src=src, group=group)
+            allp = [([z[i] for i in mine], [a[i] for i in mine]) for z, a in box[0]]
+            draws, final_draw = allp[:-1], allp[-1]
+            batch_size = n_local
         coeffs_host = np.stack([pt.coeffs_for(z0, al) for z0, al in draws], 0)
         coeffs = to_device_async(coeffs_host, self.device)
         l_pad, t_pad = pt.l_pad, pt.t_pad
@@ -125,23 +149,34 @@ class Phy_obj_atk_l0(Attack):
                 adv_cost = ops.masked_sq_mean(adv_depth, adv_obj_mask)
             mask_cost = ops.l0_mask_cost(self.pattern_pos_tensor, self.pattern_neg_tensor)
             total_cost = adv_cost + mw * mask_cost
+            if mine is not None:    # this rank's part of the job's cost: the sum over the ranks below is the one-process gradient
+                total_cost = adv_cost * share + mw * mask_cost * (1.0 / world)
             # same update as zero_grad(); total_cost.backward(); step() (:136-138), but only the two
             # pattern tensors get gradients: the reference's backward() also fills (and later discards)
             # weight gradients of the attacked model -- a third of the conv backward work
             g_pos, g_neg = torch.autograd.grad(total_cost, [self.pattern_pos_tensor, self.pattern_neg_tensor])
+            if mine is not None:
+                dist.all_reduce(g_pos, op=dist.ReduceOp.SUM, group=group)
+                dist.all_reduce(g_neg, op=dist.ReduceOp.SUM, group=group)
+            if self.grad_trace is not None:
+                self.grad_trace.append((g_pos.detach().clone(), g_neg.detach().clone()))
             self.pattern_pos_tensor.grad, self.pattern_neg_tensor.grad = g_pos, g_neg
             optimizer.step()
             ran += 1
             if self.trace is not None:
                 self.trace.append((int(l0_norm), float(mw), float(adv_cost), float(mask_cost)))
-        random.setstate(rng_states[ran])
+        if mine is None:
+            random.setstate(rng_states[ran])
 
         with torch.no_grad():
             obj_img_adv, _ = ops.l0_compose(self.obj_img, self.pattern_pos_tensor.detach(),
                                             self.pattern_neg_tensor.detach(), self.l0_clip, finalize=True)
         self.phy_trans_adv.reset_img(obj_img_adv, self.obj_mask)
-        z0_sample = sample(pt.dist_range, batch_size)
-        alpha_sample = sample(pt.angle_range, batch_size)
+        if final_draw is not None:
+            z0_sample, alpha_sample = final_draw
+        else:
+            z0_sample = sample(pt.dist_range, batch_size)
+            alpha_sample = sample(pt.angle_range, batch_size)
         if eval:
             z0_sample[0] = 6.1
             alpha_sample[0] = 0

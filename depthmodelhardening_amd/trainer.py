@@ -149,8 +149,6 @@ class Trainer:
             self.dataset.set_adv_train(self.models["DepthModelWrapper"], obj_tensor, mask_tensor, args)
             self.adv_args = args
             if getattr(self.opt, "shared_patch", False) and self.world_size > 1:
-                if self.opt.norm_type != "l_inf":
-                    raise RuntimeError("--shared_patch is implemented for --norm_type l_inf (the sign step's gradient sum)")
                 self.dataset.depth_atk.shard = (self.rank, self.world_size, None)
             self.update_adv_obj()   # trainer.py:231-233
 

@@ -419,6 +419,12 @@ def test_incremental_encoder_head_equals_the_full_one():
         assert cache.dirty2 is not None and not torch.equal(cache.work2, cache.pristine2)
         cache.restore()
         assert torch.equal(cache.work, cache.pristine) and torch.equal(cache.work2, cache.pristine2)
+        # two steps' graphs cannot be alive across each other's forward: the cached features are re-written in place
+        xa = x0.clone().requires_grad_(True)
+        fa = enc(xa, roi=(plan, tab), clean=clean)
+        enc(x0.clone().requires_grad_(True), roi=(plan, tab), clean=clean)
+        with pytest.raises(RuntimeError, match="later forward"):
+            torch.autograd.grad(fa[1].sum(), xa)
         # the check bites: frames that differ from the clean ones outside the box give a different feature 1
         x_bad = x0.clone()
         x_bad[:, :, :8, :8] += 0.25
