@@ -48,16 +48,16 @@ TABLE = WINDOWS + REGIONS
 _L1_RING = 4                                # layer1 = two BasicBlocks = four 3x3 convolutions: each spoils one ring
 
 
-def _size_for(need, frame, level, axis):
+def _size_for(need, frame):
     """Common window size along one axis: the smallest even size >= need + 1 (origins are rounded down to even).  Rounding up
     to whole Winograd regions (4 x 16 tiles = 8 x 32 pixels) was tried: the slack of one level is the need of the next, and
     three levels up the windows had grown by half; a ragged last region costs less."""
     return min(-(-(need + 1) // 2) * 2, frame)
 
 
-def _fit(lo, hi, frame, level, axis):
+def _fit(lo, hi, frame):
     """One axis: a common size and per-scene even origins with origin <= lo, origin + size >= hi, inside [0, frame]."""
-    size = _size_for(int((hi - lo).max()), frame, level, axis)
+    size = _size_for(int((hi - lo).max()), frame)
     if size >= frame:
         return frame, np.zeros_like(lo)
     org = np.minimum(lo, frame - size) & ~1
@@ -183,9 +183,8 @@ class RoiPlan(object):
 
     def _put(self, name, ry, rx):
         lvl = LEVEL[name]
-        align_lvl = 0 if name.startswith("r_") or name == "gz" else lvl      # plain rectangles: no tile alignment wanted
-        hc, oy = _fit(ry[0], ry[1], self.H >> lvl, align_lvl, 0)
-        wc, ox = _fit(rx[0], rx[1], self.W >> lvl, align_lvl, 1)
+        hc, oy = _fit(ry[0], ry[1], self.H >> lvl)
+        wc, ox = _fit(rx[0], rx[1], self.W >> lvl)
         self.size[name] = (int(hc), int(wc))
         self.org[name] = np.stack([oy, ox], 1).astype(np.int32)
 
