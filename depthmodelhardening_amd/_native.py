@@ -125,6 +125,10 @@ _SIGNATURES = {
     "dmh_conv3x3_small": (C.c_int, [_fp] * 3 + [C.c_int] * 7 + [_fp, _fp]),
     "dmh_conv3x3_head": (C.c_int, [_fp] * 3 + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_conv3x3_head_bwd_data": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [_fp, _fp]),
+    "dmh_down_wrw_workspace_size": (C.c_int64, [C.c_int] * 5),
+    "dmh_down_wrw": (C.c_int, [_fp] * 3 + [C.c_int] * 5 + [_fp] * 4),
+    "dmh_stem_wrw_workspace_size": (C.c_int64, [C.c_int] * 3),
+    "dmh_stem_wrw": (C.c_int, [_fp, _fp] + [C.c_int] * 3 + [C.c_float, C.c_float, _fp, _fp, _fp]),
     "dmh_conv3x3_head_wrw_partials_size": (C.c_int64, [C.c_int] * 5),
     "dmh_conv3x3_head_wrw": (C.c_int, [_fp, _fp] + [C.c_int] * 5 + [_fp] * 4),
     "dmh_conv3x3_small_wrw_partials_size": (C.c_int64, [C.c_int]),

@@ -18,7 +18,7 @@ LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libdmh_hip.so")
 OBJ_DIR = os.path.join(HERE, "build")
 
-SOURCES = ["runtime.hip", "photo_loss.hip", "warp_view.hip", "smooth_loss.hip", "eot_paste.hip", "attack_ops.hip", "decoder_glue.hip", "roi_glue.hip", "roi_encoder.hip", "encoder_glue.hip", "wino_conv.hip", "wino32_conv.hip", "wino_wrw.hip", "small_conv.hip", "small_wrw.hip", "stem_conv_bwd.hip", "stem_conv_fwd.hip", "down_conv.hip", "head_conv.hip", "layers_ops.hip"]
+SOURCES = ["runtime.hip", "photo_loss.hip", "warp_view.hip", "smooth_loss.hip", "eot_paste.hip", "attack_ops.hip", "decoder_glue.hip", "roi_glue.hip", "roi_encoder.hip", "encoder_glue.hip", "wino_conv.hip", "wino32_conv.hip", "wino_wrw.hip", "small_conv.hip", "small_wrw.hip", "stem_conv_bwd.hip", "stem_conv_fwd.hip", "down_conv.hip", "down_wrw.hip", "stem_wrw.hip", "head_conv.hip", "layers_ops.hip"]
 # -fno-slp-vectorize: hipcc's SLP pass packs adjacent fp32 ops into v_pk_*_f32 and pays for it with register-pair
 # shuffles (v_mov): on the fused loss kernel that was +30 % VALU instructions and +50 VGPRs (2 -> 4 waves/SIMD without it)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",

@@ -1170,6 +1170,23 @@ def conv3x3(x, weight, bias=None, padding=1):
     return _Conv3x3.apply(_c(x), weight, bias, int(padding))
 
 
+def _stem_wrw(x, g, weight, mean, std):
+    """K21: dW of the 7x7/2 first convolution on (x - mean) / std, fixed-order sums on the fp32 MFMA; None when the shape is
+    not the kernel's (3 -> 64 channels, even H, W a multiple of 8): the caller then takes ATen's."""
+    B, Cin, H, W = x.shape
+    if not WINO_ENABLED or tuple(weight.shape) != (64, 3, 7, 7) or Cin != 3 or x.numel() * 4 > 0xFFFFFF00:
+        return None
+    lib = N.lib()
+    n = lib.dmh_stem_wrw_workspace_size(B, H, W)
+    if n < 0:
+        return None
+    ws = torch.empty(n, device=x.device, dtype=torch.float32)
+    g_w = torch.empty_like(weight, memory_format=torch.contiguous_format)
+    N.check(_timed("stem_wrw", lambda: lib.dmh_stem_wrw(N.ptr(x), N.ptr(g), B, H, W, mean, std, N.ptr(ws), N.ptr(g_w),
+                                                        N.stream()), 4 * (x.numel() + g.numel()), 2 * 147 * g.numel()))
+    return g_w
+
+
 class _StemConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
@@ -1192,14 +1209,16 @@ class _StemConv(torch.autograd.Function):
             N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(_c(weight.detach())), B, K,
                                                                               Cin, H, W, N.ptr(g_x), N.stream()), nb))
         if need_w:
-            g_w = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
-                                                      [False, True, False])[1]
+            g_w = _stem_wrw(x, g, weight, 0.0, 1.0)
+            if g_w is None:
+                g_w = torch.ops.aten.convolution_backward(g, x, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                          [False, True, False])[1]
         return g_x, g_w
 
 
 def stem_conv(x, weight):
     """nn.Conv2d(Cin, K, 7, stride=2, padding=3, bias=False) -- the encoder's first convolution
-    (MD2/networks/resnet_encoder.py:88).  Forward and the weight gradient are MIOpen; the gradient w.r.t. the image (what
+    (MD2/networks/resnet_encoder.py:88).  Forward is MIOpen, the weight gradient K21 (3 -> 64 channels; MIOpen otherwise); the gradient w.r.t. the image (what
     every attack step back-propagates to the patch) is the K12 gather kernel."""
     B, Cin, H, W = x.shape
     if (not x.is_cuda or not WINO_ENABLED or weight.shape[1:] != (Cin, 7, 7) or Cin > 4 or weight.shape[0] % 8 or H % 2
@@ -1210,7 +1229,7 @@ def stem_conv(x, weight):
 
 class _StemConvNorm(torch.autograd.Function):
     """K14 forward (normalisation + 7x7/2 convolution on the fp32 MFMA); backward: image gradient by K12 (scaled by 1/std),
-    weight gradient by MIOpen on the re-normalised image (train pass only)."""
+    weight gradient by K21 (train pass only; ATen on the re-normalised image for widths that are not multiples of 8)."""
 
     @staticmethod
     def forward(ctx, x, weight, mean, std):
@@ -1244,9 +1263,11 @@ class _StemConvNorm(torch.autograd.Function):
             N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(w_s), B, 64, Cin, H, W,
                                                                               N.ptr(g_x), N.stream()), nb))
         if ctx.needs_input_grad[1] and not ctx.params_const:
-            xn = (x - mean) / std
-            g_w = torch.ops.aten.convolution_backward(g, xn, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
-                                                      [False, True, False])[1]
+            g_w = _stem_wrw(x, g, weight, mean, std)
+            if g_w is None:
+                xn = (x - mean) / std
+                g_w = torch.ops.aten.convolution_backward(g, xn, weight, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1,
+                                                          [False, True, False])[1]
         return g_x, g_w, None, None
 
 
@@ -1264,7 +1285,8 @@ def stem_conv_norm(x, weight, mean=0.45, std=0.225):
 
 class _DownConvs(torch.autograd.Function):
     """K15: conv3x3 stride 2 and the 1x1 stride-2 shortcut convolution of a down-sampling BasicBlock, one launch; backward:
-    both input gradients in one launch (no separate accumulation pass), weight gradients by MIOpen (train pass only)."""
+    both input gradients in one launch (no separate accumulation pass), both weight gradients in one K20 launch (train pass
+    only; ATen for input widths that are not multiples of 8)."""
 
     @staticmethod
     def forward(ctx, x, w3, wd):
@@ -1298,7 +1320,17 @@ class _DownConvs(torch.autograd.Function):
             N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data(
                 N.ptr(g3), N.ptr(gd), N.ptr(w3t), N.ptr(wdt), B, Cin, Cout, H, W, N.ptr(g_x), N.stream()),
                 nb, 20 * Cin * g3.numel()))
-        if not ctx.params_const:
+        if not ctx.params_const and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            n = lib.dmh_down_wrw_workspace_size(B, Cin, Cout, H, W) if x.numel() * 4 <= 0xFFFFFF00 else -1
+            if n >= 0 and ctx.needs_input_grad[1]:
+                ws = torch.empty(n, device=x.device, dtype=torch.float32)
+                g_w3 = torch.empty_like(w3, memory_format=torch.contiguous_format)
+                with_d = bool(ctx.needs_input_grad[2])
+                g_wd = torch.empty_like(wd, memory_format=torch.contiguous_format) if with_d else None
+                N.check(_timed("down_wrw", lambda: lib.dmh_down_wrw(
+                    N.ptr(x), N.ptr(g3), N.ptr(gd) if with_d else None, B, Cin, Cout, H, W, N.ptr(ws), N.ptr(g_w3),
+                    N.ptr(g_wd) if with_d else None, N.stream()), 4 * (x.numel() + 2 * g3.numel()), 20 * Cin * g3.numel()))
+                return g_x, g_w3, g_wd
             if ctx.needs_input_grad[1]:
                 g_w3 = torch.ops.aten.convolution_backward(g3, x, w3, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
                                                            [False, True, False])[1]

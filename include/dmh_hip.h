@@ -227,6 +227,25 @@ int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, cons
                            void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K20 weight gradients of the pair of convolutions that opens a down-sampling ResNet block (K15's train-pass counterpart):
+ *     dw3[K][C][3][3] of nn.Conv2d(C, K, 3, stride 2, padding 1) and dwd[K][C][1][1] of nn.Conv2d(C, K, 1, stride 2) on the
+ *     same x[B,C,H,W], from g3 / gd [B,K,H/2,W/2] (gd and dwd may be NULL: the 3x3 filter only).  Pixel axis on the fp32 MFMA,
+ *     one partial block set per workgroup, fixed-order reduction: no atomics, bitwise reproducible (MIOpen's kernels for these
+ *     shapes accumulate with float atomics).  C and K multiples of 64, H even, W a multiple of 8.
+ *     workspace: dmh_down_wrw_workspace_size(B, C, K, H, W) floats (-1: shape not supported).
+ * K21 weight gradient of the encoder's first convolution on the normalised image, nn.Conv2d(3, 64, 7, stride 2, padding 3)
+ *     applied to (x - mean) / std (MD2/networks/resnet_encoder.py:89-90): dw[64][3][7][7] from x[B,3,H,W] and g[B,64,H/2,W/2];
+ *     the normalisation is applied while the image tile is staged (zero in the padding), as in K14.  Same reduction scheme.
+ *     H even, W a multiple of 8.  workspace: dmh_stem_wrw_workspace_size(B, H, W) floats.
+ * ---------------------------------------------------------------------------------- */
+int64_t dmh_down_wrw_workspace_size(int B, int C, int K, int H, int W);
+int dmh_down_wrw(const float* x, const float* g3, const float* gd, int B, int C, int K, int H, int W, float* workspace, float* dw3,
+                 float* dwd, void* stream);
+int64_t dmh_stem_wrw_workspace_size(int B, int H, int W);
+int dmh_stem_wrw(const float* x, const float* g, int B, int H, int W, float mean, float std, float* workspace, float* dw,
+                 void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Stand-alone forms of the two loss layers of MD2/layers.py (Trainer.compute_losses runs the fused K1 + K2 instead; these
  * serve callers of the reference surface `SSIM()(x, y)` / `get_smooth_loss(disp, img)`):
  *   ssim_map   : out[planes,H,W] = clamp((1 - SSIM(x, y)) / 2, 0, 1), 3x3 means over the ReflectionPad2d(1) planes

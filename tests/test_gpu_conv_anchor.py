@@ -123,3 +123,79 @@ def test_strided_block_entry_vs_fp64(shape):
     lib = (torch.ops.aten.convolution_backward(g3, x, w3, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False])[0] +
            torch.ops.aten.convolution_backward(gd, x, wd, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [True, False, False])[0])
     _bound("K15 %d->%d backward-data" % (C, K), _rel(gx, gx64), _rel(lib, gx64), chain=10 * K // 4)
+
+
+def _wrw_chain(pixels, parts):
+    """Accumulation structure of K20 / K21: ``parts`` partial sums (one per workgroup or wave) of pixels / parts products each,
+    added in order: two chains, the random-walk estimate of each added in quadrature."""
+    return pixels / parts + parts
+
+
+# batch 32: the train pass's shapes
+@pytest.mark.parametrize("shape", [(32, 64, 128, 80, 256), (32, 128, 256, 40, 128), (32, 256, 512, 20, 64), (3, 64, 64, 6, 24)],
+                         ids=["layer2.0", "layer3.0", "layer4.0", "ragged"])
+def test_strided_block_entry_weight_gradients_vs_fp64(shape):
+    """K20: both weight gradients of a down-sampling block's entry (3x3 stride 2 and the 1x1 stride-2 shortcut) in one launch,
+    against float64 and MIOpen, and bit for bit the same on a second run (no atomics)."""
+    from depthmodelhardening_amd import ops
+    B, C, K, H, W = shape
+    g0 = torch.Generator().manual_seed(31)
+    x = torch.randn(B, C, H, W, generator=g0).cuda()
+    w3 = (torch.randn(K, C, 3, 3, generator=g0) * (2.0 / (9 * C)) ** 0.5).cuda().requires_grad_(True)
+    wd = (torch.randn(K, C, 1, 1, generator=g0) * (2.0 / C) ** 0.5).cuda().requires_grad_(True)
+    y3, yd = ops.down_convs(x, w3, wd)
+    px = y3.shape[2] * y3.shape[3]
+    g3 = (torch.randn(y3.shape, generator=g0) / px ** 0.5).cuda()
+    gd = (torch.randn(yd.shape, generator=g0) / px ** 0.5).cuda()
+    lib = __import__("depthmodelhardening_amd._native", fromlist=["x"]).lib()
+    assert lib.dmh_down_wrw_workspace_size(B, C, K, H, W) > 0, "the shape must take K20, not the ATen fallback"
+    gw3, gwd = torch.autograd.grad([y3, yd], [w3, wd], [g3, gd], retain_graph=True)
+    gw3_2, gwd_2 = torch.autograd.grad([y3, yd], [w3, wd], [g3, gd])
+    assert torch.equal(gw3, gw3_2) and torch.equal(gwd, gwd_2), "fixed-order sums: a second run must agree bit for bit"
+    gw3_64 = torch.zeros(K, C, 3, 3, dtype=torch.float64, device="cuda")
+    gwd_64 = torch.zeros(K, C, 1, 1, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        gw3_64 += torch.nn.grad.conv2d_weight(x[b:b + 1].double(), (K, C, 3, 3), g3[b:b + 1].double(), 2, 1)
+        gwd_64 += torch.nn.grad.conv2d_weight(x[b:b + 1].double(), (K, C, 1, 1), gd[b:b + 1].double(), 2, 0)
+    l3 = torch.ops.aten.convolution_backward(g3, x, w3, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    ld = torch.ops.aten.convolution_backward(gd, x, wd, None, [2, 2], [0, 0], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    parts = min(512 // ((K // 64) * (C // 64)), B * (H // 2) * ((W // 2 + 31) // 32))
+    chain = _wrw_chain(B * px, parts)
+    _bound("K20 %d->%d 3x3/2 weight gradient" % (C, K), _rel(gw3, gw3_64), _rel(l3, gw3_64), chain=chain)
+    _bound("K20 %d->%d 1x1/2 weight gradient" % (C, K), _rel(gwd, gwd_64), _rel(ld, gwd_64), chain=chain)
+    # the 3x3 filter alone (a caller that holds the shortcut constant)
+    y3, yd = ops.down_convs(x, w3, wd.detach())
+    (only3,) = torch.autograd.grad([y3, yd], [w3], [g3, gd])
+    assert torch.equal(only3, gw3)
+
+
+@pytest.mark.parametrize("shape", [(8, 320, 1024), (2, 64, 192), (3, 38, 72)], ids=["kitti", "small", "ragged"])
+def test_stem_weight_gradient_vs_fp64(shape):
+    """K21: dW of conv1((x - 0.45) / 0.225) -- 3 -> 64 channels, 7x7, stride 2 -- against float64 and MIOpen on the normalised
+    image, twice bit for bit; and the un-normalised form (stem_conv) through the same kernel."""
+    from depthmodelhardening_amd import ops
+    B, H, W = shape
+    g0 = torch.Generator().manual_seed(41)
+    x = torch.rand(B, 3, H, W, generator=g0).cuda()
+    w = (torch.randn(64, 3, 7, 7, generator=g0) * (2.0 / 147) ** 0.5).cuda().requires_grad_(True)
+    y = ops.stem_conv_norm(x, w, 0.45, 0.225)
+    px = y.shape[2] * y.shape[3]
+    g = (torch.randn(y.shape, generator=g0) / px ** 0.5).cuda()
+    lib = __import__("depthmodelhardening_amd._native", fromlist=["x"]).lib()
+    assert lib.dmh_stem_wrw_workspace_size(B, H, W) > 0
+    (gw,) = torch.autograd.grad(y, w, g, retain_graph=True)
+    (gw2,) = torch.autograd.grad(y, w, g)
+    assert torch.equal(gw, gw2), "fixed-order sums: a second run must agree bit for bit"
+    xn = (x - 0.45) / 0.225
+    gw64 = torch.zeros(64, 3, 7, 7, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        gw64 += torch.nn.grad.conv2d_weight(((x[b:b + 1].double() - 0.45) / 0.225), (64, 3, 7, 7), g[b:b + 1].double(), 2, 3)
+    glib = torch.ops.aten.convolution_backward(g, xn, w, None, [2, 2], [3, 3], [1, 1], False, [0, 0], 1, [False, True, False])[1]
+    tiles = B * ((H // 2 + 3) // 4) * ((W // 2 + 31) // 32)
+    _bound("K21 stem weight gradient %dx%dx%d" % shape, _rel(gw, gw64), _rel(glib, gw64),
+           chain=_wrw_chain(B * px, 4 * min(tiles, 512)))
+    # stem_conv: the caller normalised the image itself (mean 0, std 1 inside the kernel)
+    xr = xn.clone().requires_grad_(True)
+    y2 = ops.stem_conv(xr, w)
+    (gw3,) = torch.autograd.grad(y2, w, g)
+    assert _rel(gw3, gw64) <= 2 * _rel(gw, gw64) + 1e-7

@@ -158,7 +158,8 @@ if bs and bt:
     def family(n):
         for key, fam in (("roi_", "K19 window glue / cost / crop / paste"), ("stem_bwd_win", "K19 window glue / cost / crop / paste"),
                          ("zero_fill", "K10 wino_conv (+ filter transforms)"), ("ssim_", "layers surface"), ("edge_smooth", "layers surface"),
-                         ("wino32", "K17 wino32_conv"), ("wino_wrw", "K18 wino_wrw"), ("wino_", "K10 wino_conv (+ filter transforms)"),
+                         ("wino32", "K17 wino32_conv"), ("wino_wrw", "K18 wino_wrw"), ("down_wrw", "K20 / K21 strided + stem weight gradients"),
+                         ("stem_wrw", "K20 / K21 strided + stem weight gradients"), ("wino_", "K10 wino_conv (+ filter transforms)"),
                          ("small_conv", "K11 small_conv"), ("small_wrw", "K16 small_wrw"), ("head_wrw", "K13 head weight gradient"),
                          ("down_conv", "K15 down_conv"), ("elu_pad", "K7 decoder glue"), ("up_cat_pad", "K7 decoder glue"),
                          ("bn_", "K9 encoder glue / BatchNorm"), ("channel_sum", "K9 encoder glue / BatchNorm"),
