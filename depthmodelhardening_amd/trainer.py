@@ -27,7 +27,7 @@ from .contrastive import SimSiam
 from .datasets import SyntheticKITTIDataset, make_object
 from .ddp import GradBucket, average_buffers, broadcast_parameters
 from .depth_model import DepthModelWrapper, import_depth_model
-from .layers import SSIM
+from .layers import SSIM, get_smooth_loss
 from .my_utils import ori_H, ori_W
 
 
@@ -77,15 +77,19 @@ class Trainer:
             raise NotImplementedError("pose networks (monocular frames -1/+1) are outside the hot-path scope; "
                                       "train with --frame_ids 0 --use_stereo as the paper's command does "
                                       "(reference README.md:87-91)")
-        for flag in ("predictive_mask", "gt_depth"):
-            if getattr(self.opt, flag):
-                raise NotImplementedError("--%s is not supported by the fused photometric kernel" % flag)
+        if self.opt.gt_depth:
+            raise NotImplementedError("--gt_depth is not supported by the fused photometric kernel")
         # --avg_reprojection (MD2/trainer.py:593,617-621,636-639) replaces the min over the source frames by their mean;
-        # with the one (stereo) source frame this trainer supports the two are the same number, so the flag is accepted
-        if self.opt.avg_reprojection and len(self.opt.frame_ids) > 2:
-            raise NotImplementedError("--avg_reprojection over several source frames is not in the fused kernel")
+        # with the one (stereo) source frame of this trainer the two are the same number and the fused kernel serves it;
+        # over several source frames compute_losses takes the composed path (_losses_composed)
         if self.opt.v1_multiscale and (self.opt.loss_variant != "md2" or self.opt.use_depth_hints):
             raise NotImplementedError("--v1_multiscale is Monodepth2's option (MD2/trainer.py:478-483,593-596)")
+        if self.opt.predictive_mask:
+            assert self.opt.disable_automasking, \
+                "When using predictive_mask, please disable automasking with --disable_automasking"    # MD2/trainer.py:123-125
+            if self.opt.loss_variant != "md2" or self.opt.v1_multiscale:
+                raise NotImplementedError("--predictive_mask is served at the frame's resolution by Monodepth2's loss "
+                                          "(MD2/trainer.py:623-635)")
         if self.opt.use_depth_hints and (self.opt.loss_variant != "dh" or self.opt.disable_automasking):
             raise RuntimeError("--use_depth_hints is the DepthHints trainer's option: use --loss_variant dh with "
                                "auto-masking (DH/trainer.py:71-75,557-590)")
@@ -101,6 +105,12 @@ class Trainer:
         self.parameters_to_train += list(self.models["encoder"].parameters())
         self.parameters_to_train += list(self.models["depth"].parameters())
         self.models["DepthModelWrapper"] = DepthModelWrapper(self.models["encoder"], self.models["depth"]).to(self.device)
+        if self.opt.predictive_mask:
+            # "the same architecture as our depth decoder", one mask per source frame (MD2/trainer.py:127-133)
+            self.models["predictive_mask"] = networks.DepthDecoder(self.models["encoder"].num_ch_enc, self.opt.scales,
+                                                                   num_output_channels=len(self.opt.frame_ids) - 1)
+            self.models["predictive_mask"].to(self.device)
+            self.parameters_to_train += list(self.models["predictive_mask"].parameters())
 
         if self.opt.adv_train and self.opt.supervised_adv:
             self.gt_model = import_depth_model((1024, 320)).to(self.device)   # frozen teacher, trainer.py:93-95
@@ -281,6 +291,8 @@ class Trainer:
         outputs["middle_features_aug"] = features
         if self.opt.contrastive_learning:
             outputs["middle_features_ben"] = self.models["encoder"](inputs["color_ben", 0, 0])
+        if self.opt.predictive_mask:
+            outputs["predictive_mask"] = self.models["predictive_mask"](features)       # MD2/trainer.py:362-363
         self.generate_images_pred(inputs, outputs)
         losses = self.compute_losses(inputs, outputs)
         return outputs, losses
@@ -341,6 +353,8 @@ class Trainer:
         frames = self.opt.frame_ids[1:]
         if self.opt.v1_multiscale:
             return self._losses_v1_multiscale(inputs, outputs, losses, total_loss, frames)
+        if self.opt.predictive_mask or (self.opt.avg_reprojection and len(frames) > 1):
+            return self._losses_composed(inputs, outputs, losses, total_loss, frames)
         out = ops.photometric_smooth_loss(
             inputs[("color", 0, 0)], [inputs[("color", f, 0)] for f in frames],
             [self._frame_T(inputs, outputs, f) for f in frames], inputs[("K", 0)], inputs[("inv_K", 0)],
@@ -379,6 +393,58 @@ class Trainer:
                 else:
                     outputs[key] = selection()
         total_loss = total_loss + out.fin[N.FIN_LOSS]
+        losses["loss"] = total_loss
+        return losses
+
+    def _losses_composed(self, inputs, outputs, losses, total_loss, frames):
+        """The option branches of the per-scale body that the fused kernel does not carry (MD2/trainer.py:589-668):
+        --predictive_mask (:623-635, with --disable_automasking) and --avg_reprojection over several source frames (:617-621,
+        :637-640).  Neither is on the paper's command line; they are composed from the stand-alone operators -- the warp
+        kernel (``ops.warp_view``, differentiable in the disparity), ``torch.ops.dmh.ssim_map`` behind
+        ``compute_reprojection_loss``, ``torch.ops.dmh.smooth_loss`` behind ``get_smooth_loss`` -- and element-wise torch in
+        the reference's order; per-pixel maps are materialised, as in the reference."""
+        target = inputs[("color", 0, 0)]
+        H, W = target.shape[-2:]
+        automask = not self.opt.disable_automasking
+        per_scale = []
+        for scale in self.opt.scales:
+            loss = 0
+            disp = outputs[("disp", scale)]
+            reproj = []
+            for f in frames:
+                key = ("color", f, scale)
+                pred = outputs[key] if key in outputs else ops.warp_view(
+                    inputs[("color", f, 0)], disp, inputs[("K", 0)], inputs[("inv_K", 0)], self._frame_T(inputs, outputs, f),
+                    H, W, self.opt.min_depth, self.opt.max_depth)[2]
+                reproj.append(self.compute_reprojection_loss(pred, target))
+            reproj = torch.cat(reproj, 1)
+            if automask:
+                ident = torch.cat([self.compute_reprojection_loss(inputs[("color", f, 0)], target) for f in frames], 1)
+                if self.opt.avg_reprojection:
+                    ident = ident.mean(1, keepdim=True)
+            elif self.opt.predictive_mask:
+                mask = F.interpolate(outputs["predictive_mask"][("disp", scale)], [H, W], mode="bilinear", align_corners=False)
+                reproj = reproj * mask
+                loss = loss + 0.2 * F.binary_cross_entropy(mask, torch.ones_like(mask))     # pushes the mask to 1
+            if self.opt.avg_reprojection:
+                reproj = reproj.mean(1, keepdim=True)
+            if automask:
+                ident = ident + torch.randn(ident.shape, device=ident.device) * 0.00001     # breaks ties
+                combined = torch.cat((ident, reproj), dim=1)
+            else:
+                combined = reproj
+            if combined.shape[1] == 1:
+                to_optimise = combined
+            else:
+                to_optimise, idxs = torch.min(combined, dim=1)
+            if automask:
+                outputs["identity_selection/{}".format(scale)] = (idxs > ident.shape[1] - 1).float()
+            loss = loss + to_optimise.mean()
+            norm_disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
+            loss = loss + self.opt.disparity_smoothness * get_smooth_loss(norm_disp, inputs[("color", 0, scale)]) / (2 ** scale)
+            losses["loss/{}".format(scale)] = loss
+            per_scale.append(loss)
+        total_loss = total_loss + sum(per_scale) / self.num_scales
         losses["loss"] = total_loss
         return losses
 

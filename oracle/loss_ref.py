@@ -200,6 +200,57 @@ def compute_losses(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), noi
     return losses, maps
 
 
+def compute_losses_options(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), noise=None, smooth_wt=SMOOTH_WT,
+                           automask=True, avg_reprojection=False, predictive_mask=None, no_ssim=False):
+    """The option branches of Monodepth2's per-scale body, trainer.py:589-668 (non-v1_multiscale), that compute_losses above
+    leaves out: --disable_automasking (:608 skipped), --avg_reprojection (:617-621, :637-640: the MEAN over the source frames
+    replaces the per-frame candidates), --predictive_mask (:623-635: requires automasking off, trainer.py:123-125;
+    ``predictive_mask`` = {scale: mask [B, F, H/2^s, W/2^s] in (0,1)} as the second decoder returns it, up-sampled to the
+    frame, multiplies the reprojection losses, and 0.2 * BCE(mask, 1) is added to the scale's loss).
+    ``noise``: {scale: tensor shaped like the identity loss}, already scaled (trainer.py:642-645); None -> zeros.
+    Needs outputs[("color", f, s)] (generate_images_pred).  Returns (losses dict, per-scale to_optimise maps)."""
+    losses, maps = {}, {}
+    total = 0
+    H, W = inputs[("color", 0, 0)].shape[-2:]
+    for scale in scales:
+        loss = 0
+        disp = outputs[("disp", scale)]
+        color = inputs[("color", 0, scale)]
+        target = inputs[("color", 0, 0)]
+        reproj = torch.cat([compute_reprojection_loss(outputs[("color", f, scale)], target, no_ssim)
+                            for f in frame_ids[1:]], 1)
+        ident = None
+        if automask:
+            ident = torch.cat([compute_reprojection_loss(inputs[("color", f, 0)], target, no_ssim) for f in frame_ids[1:]], 1)
+            if avg_reprojection:
+                ident = ident.mean(1, keepdim=True)
+        elif predictive_mask is not None:
+            mask = F.interpolate(predictive_mask[scale], [H, W], mode="bilinear", align_corners=False)
+            reproj = reproj * mask
+            loss = loss + 0.2 * F.binary_cross_entropy(mask, torch.ones_like(mask))
+        if avg_reprojection:
+            reproj = reproj.mean(1, keepdim=True)
+        if automask:
+            if noise is not None:
+                ident = ident + noise[scale]
+            combined = torch.cat((ident, reproj), dim=1)
+        else:
+            combined = reproj
+        if combined.shape[1] == 1:
+            to_opt = combined
+        else:
+            to_opt, idxs = torch.min(combined, dim=1)
+        if automask:
+            outputs["identity_selection/{}".format(scale)] = (idxs > ident.shape[1] - 1).float()
+        loss = loss + to_opt.mean()
+        maps[scale] = to_opt
+        loss = loss + smooth_wt * normalised_smooth_loss(disp, color) / (2 ** scale)
+        total = total + loss
+        losses["loss/{}".format(scale)] = loss
+    losses["loss"] = total / len(scales)
+    return losses, maps
+
+
 def v1_multiscale_losses(inputs, disps, noise=None, smooth_wt=SMOOTH_WT):
     """--v1_multiscale (trainer.py:478-483,593-596): every scale is warped, compared and smoothed at its own resolution
     with the intrinsics of that scale; loss = mean_s(loss_s), loss_s = mean(min(identity, reprojection)) + wt *

@@ -261,6 +261,60 @@ def gold_v1_multiscale(trainer_mod, layers):
     save("loss_md2_v1ms", **keep)
 
 
+def gold_options(trainer_mod, layers):
+    """The option branches of MD2's per-scale loss body (trainer.py:608-658): --predictive_mask (with --disable_automasking,
+    one and two source frames) and --avg_reprojection over two source frames (auto-masking on, recorded tie-break noise)."""
+    from oracle.synth import options_case
+    B, H, W, seed = 2, 32, 96, 33
+    for name, frames, kw in (("pmask", ["s"], dict(disable_automasking=True, predictive_mask=True)),
+                             ("pmask2", [-1, "s"], dict(disable_automasking=True, predictive_mask=True)),
+                             ("avg2", [-1, 1], dict(avg_reprojection=True)),
+                             ("avg2_noauto", [-1, 1], dict(avg_reprojection=True, disable_automasking=True))):
+        inputs, disps, poses, masks = options_case(B, H, W, seed, frames)
+        self, T = _fake_trainer(trainer_mod, layers, B, H, W, "md2")
+        self.opt.frame_ids = [0] + frames
+        for k, v in kw.items():
+            setattr(self.opt, k, v)
+        outputs, leaves, mleaves = {}, [], []
+        for f, P in poses.items():
+            outputs[("cam_T_cam", 0, f)] = P
+        for s, d in enumerate(disps):
+            d = d.clone().requires_grad_(True)
+            leaves.append(d)
+            outputs[("disp", s)] = d
+        if self.opt.predictive_mask:
+            outputs["predictive_mask"] = {}
+            for s, m in enumerate(masks):
+                m = m.clone().requires_grad_(True)
+                mleaves.append(m)
+                outputs["predictive_mask"][("disp", s)] = m
+        g = torch.Generator().manual_seed(seed + 100)
+        queue = [torch.randn(B, 1, H, W, generator=g) for _ in range(4)]       # avg: one identity channel
+        real_randn = torch.randn
+
+        def fake_randn(*shape, **k2):
+            shp = shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape
+            t = queue.pop(0)
+            assert tuple(t.shape) == tuple(shp), (t.shape, shp)
+            return t
+        torch.randn = fake_randn
+        try:
+            T.generate_images_pred(self, inputs, outputs)
+            losses = T.compute_losses(self, inputs, outputs)
+        finally:
+            torch.randn = real_randn
+        losses["loss"].backward()
+        keep = {"shape": np.array([B, H, W, seed]), "loss": losses["loss"]}
+        for s in range(4):
+            keep["loss_%d" % s] = losses["loss/%d" % s]
+            keep["grad_disp_%d" % s] = leaves[s].grad
+            if mleaves:
+                keep["grad_mask_%d" % s] = mleaves[s].grad
+            if "identity_selection/%d" % s in outputs:
+                keep["identity_selection_%d" % s] = np.packbits(outputs["identity_selection/%d" % s].numpy().astype(np.uint8))
+        save("loss_md2_opt_%s" % name, **keep)
+
+
 def gold_depth_hints(trainer_mod, layers):
     """DepthHints with --use_depth_hints (depth-hints/trainer.py:510-525,629-636,700-725): hint warp, three-way argmin,
     proxy log-L1 supervision; synthetic hints with holes (oracle.synth.make_depth_hint)."""
@@ -463,6 +517,10 @@ def gold_prep_adv_data(mono_dataset, PhysicalTrans, calib_path):
 
 
 def main():
+    only = set(sys.argv[1:])        # e.g. `python oracle/make_goldens.py options`: just that group (default: everything)
+
+    def want(name):
+        return not only or name in only
     install_shims()
     tmp = tempfile.mkdtemp(prefix="kitti_obj_")
     os.makedirs(os.path.join(tmp, "training", "calib"))
@@ -475,21 +533,31 @@ def main():
     import my_utils
     my_utils.object_dataset_root = tmp  # bound at import by the attack modules (phy_obj_atk.py:7,53-54)
     import layers
-    gold_layers(layers)
+    if want("layers"):
+        gold_layers(layers)
     import trainer as md2_trainer
-    gold_losses(md2_trainer, layers, "md2")
-    gold_v1_multiscale(md2_trainer, layers)
+    if want("losses"):
+        gold_losses(md2_trainer, layers, "md2")
+    if want("v1ms"):
+        gold_v1_multiscale(md2_trainer, layers)
+    if want("options"):
+        gold_options(md2_trainer, layers)
     import physicalTrans
-    gold_geometry(physicalTrans.PhysicalTrans, calib)
+    if want("geometry"):
+        gold_geometry(physicalTrans.PhysicalTrans, calib)
     import torchattacks as ta
-    gold_attacks(ta)
+    if want("attacks"):
+        gold_attacks(ta)
     import contrastive
-    gold_simsiam(contrastive)
-    gold_sup_loss(md2_trainer, layers)
+    if want("addons"):
+        gold_simsiam(contrastive)
+        gold_sup_loss(md2_trainer, layers)
     import evaluate_depth
-    gold_compute_errors(evaluate_depth, layers)
+    if want("errors"):
+        gold_compute_errors(evaluate_depth, layers)
     import datasets.mono_dataset as mono_dataset
-    gold_prep_adv_data(mono_dataset, physicalTrans.PhysicalTrans, calib)
+    if want("prep"):
+        gold_prep_adv_data(mono_dataset, physicalTrans.PhysicalTrans, calib)
 
     # DepthHints variant: same module names, so import it in a scrubbed namespace
     for m in ["trainer", "layers", "datasets", "networks", "utils", "kitti_utils", "options", "evaluate_depth",
@@ -498,8 +566,10 @@ def main():
     sys.path[0] = DH
     import layers as dh_layers
     import trainer as dh_trainer
-    gold_losses(dh_trainer, dh_layers, "dh")
-    gold_depth_hints(dh_trainer, dh_layers)
+    if want("losses"):
+        gold_losses(dh_trainer, dh_layers, "dh")
+    if want("hints"):
+        gold_depth_hints(dh_trainer, dh_layers)
 
 
 if __name__ == "__main__":

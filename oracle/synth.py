@@ -121,3 +121,35 @@ class TinyDepthNet(nn.Module):
         x = F.elu(self.bn(self.c1((x - 0.45) / 0.225)))
         x = F.elu(self.c2(x))
         return torch.sigmoid(self.c3(x))
+
+
+def general_pose(B, seed):
+    """A small rigid motion per sample (rotation about all three axes + translation), float64 -> float32."""
+    g = torch.Generator().manual_seed(seed)
+    ang = (torch.rand(B, 3, generator=g, dtype=torch.float64) - 0.5) * 0.02
+    T = torch.eye(4, dtype=torch.float64).repeat(B, 1, 1)
+    for b in range(B):
+        ax, ay, az = [float(v) for v in ang[b]]
+        Rx = torch.tensor([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]], dtype=torch.float64)
+        Ry = torch.tensor([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]], dtype=torch.float64)
+        Rz = torch.tensor([[np.cos(az), -np.sin(az), 0], [np.sin(az), np.cos(az), 0], [0, 0, 1]], dtype=torch.float64)
+        T[b, :3, :3] = Rz @ Ry @ Rx
+    T[:, :3, 3] = (torch.rand(B, 3, generator=g, dtype=torch.float64) - 0.5) * 0.06
+    return T.float()
+
+
+def options_case(B, H, W, seed, frames):
+    """Inputs of the option-branch goldens: make_loss_case + (for monocular source frames -1 / +1) a shifted, noised copy of
+    the target as that frame and a general pose for it; predictive masks = smooth fields in (0.05, 0.95), one channel per
+    source frame, at the four scales."""
+    inputs, disps = make_loss_case(B, H, W, seed)
+    g = torch.Generator().manual_seed(seed + 7)
+    poses = {}
+    for f in frames:
+        if f == "s":
+            continue
+        inputs[("color", f, 0)] = (0.8 * torch.roll(inputs[("color", 0, 0)], -2 * f, 3) + 0.2 * kitti_like(B, 3, H, W, g)).contiguous()
+        poses[f] = general_pose(B, seed + 11 + f)
+    masks = [torch.cat([smooth_field(B, H >> s, W >> s, g, 0.05, 0.95, k=max(3, 9 // 2 ** s) | 1) for _ in frames], 1).contiguous()
+             for s in range(4)]
+    return inputs, disps, poses, masks
