@@ -108,6 +108,29 @@ class GradBucket(object):
         self.check_attached()
         self.flat.zero_()
 
+    def release(self):
+        """Before ``backward()``: detach every ``.grad`` so that autograd hands each parameter the gradient tensor its producer
+        wrote (AccumulateGrad keeps it as it is) instead of adding it into the zeroed view -- one element-wise add kernel per
+        parameter otherwise (93 launches, 1.0 ms of a config-2 step).  ``collect()`` puts the bucket back together."""
+        for p in self.params:
+            p.grad = None
+
+    def collect(self):
+        """After ``backward()`` that followed ``release()``: copy the gradients into their slices of the flat buffer (one
+        multi-tensor copy; parameters that received none read as zero) and re-point every ``.grad`` at its slice."""
+        views = [self.flat[off:off + p.numel()].view_as(p) for p, off in zip(self.params, self._offsets)]
+        grads, dsts = [], []
+        for p, v in zip(self.params, views):
+            if p.grad is not None:
+                grads.append(p.grad if p.grad.is_contiguous() else p.grad.contiguous())
+                dsts.append(v)
+        if len(grads) < len(views):
+            self.flat.zero_()
+        if grads:
+            torch._foreach_copy_(dsts, grads)
+        for p, v in zip(self.params, views):
+            p.grad = v
+
     def start_all_reduce(self):
         """Enqueue sum-all-reduce + 1/N of the bucket; returns immediately."""
         if self.world <= 1 and not self.force:

@@ -110,8 +110,9 @@ class HardeningJob(object):
             disp_gt = self.model_ori(ben_image)
         pre_disp = self.model_rob(adv_image)
         loss = ops.masked_sq_mean(disp_gt - pre_disp, None)         # MSELoss(disp_gt, pre_disp)
-        self.bucket.zero()                                          # optimizer.zero_grad()
+        self.bucket.release()                                       # optimizer.zero_grad()
         loss.backward()
+        self.bucket.collect()
         return loss
 
     def train_step(self):

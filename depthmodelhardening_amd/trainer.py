@@ -217,8 +217,9 @@ class Trainer:
                 self.update_adv_obj()
         inputs = self.dataset.next_batch(self.opt.batch_size)
         outputs, losses = self.process_batch(inputs)
-        self.bucket.zero()                       # model_optimizer.zero_grad()
+        self.bucket.release()                    # model_optimizer.zero_grad()
         losses["loss"].backward()
+        self.bucket.collect()
         self.bucket.start_all_reduce()
         self._pending = True
         if not overlap:

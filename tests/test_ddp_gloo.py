@@ -132,3 +132,27 @@ def _buffers_worker(rank, world, port, ret):
     ret[rank] = bn.running_mean.clone()
     dist.barrier()
     dist.destroy_process_group()
+
+
+def test_release_collect_equals_in_place_accumulation():
+    """GradBucket.release() / collect() (autograd keeps each gradient tensor, one multi-tensor copy gathers them) leaves the
+    flat bucket bit for bit what accumulation into the zeroed views leaves, re-attaches every .grad, and zero-fills the slices
+    of parameters that got no gradient."""
+    from depthmodelhardening_amd.ddp import GradBucket
+    m = _model()
+    extra = torch.nn.Parameter(torch.ones(5))               # in the bucket, never used: no gradient
+    b = GradBucket(list(m.parameters()) + [extra], 1)
+    x = torch.rand(2, 3, 8, 8)
+    b.zero()
+    (m(x) ** 2).mean().backward()
+    want = b.flat.clone()
+    b.flat.fill_(7.0)                                       # stale contents must not survive
+    b.release()
+    assert all(p.grad is None for p in b.params)
+    (m(x) ** 2).mean().backward()
+    b.collect()
+    assert torch.equal(b.flat, want) and float(extra.grad.abs().sum()) == 0.0
+    b.check_attached()
+    b.zero()                                                # the in-place path still works afterwards
+    (m(x) ** 2).mean().backward()
+    assert torch.equal(b.flat, want)
