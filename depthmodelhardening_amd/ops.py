@@ -829,7 +829,7 @@ def stem_bn_relu_pool(x, scale, shift):
 # channels (tools/wino_bench.py, profiles/); everything else is the ATen/MIOpen convolution.
 # ---------------------------------------------------------------------------------------------------------------
 WINO_ENABLED = os.environ.get("DMH_WINO", "1") != "0"
-WRW_ENABLED = os.environ.get("DMH_WRW", "1") != "0"     # K18 (weight gradients); 0: MIOpen (A/B switch)
+WRW_ENABLED = os.environ.get("DMH_WRW", "1") != "0"     # K18 / K20 / K21 (weight gradients); 0: MIOpen (A/B switch)
 _wino_frozen = 0
 _wino_cache = {}
 
@@ -1174,7 +1174,7 @@ def _stem_wrw(x, g, weight, mean, std):
     """K21: dW of the 7x7/2 first convolution on (x - mean) / std, fixed-order sums on the fp32 MFMA; None when the shape is
     not the kernel's (3 -> 64 channels, even H, W a multiple of 8): the caller then takes ATen's."""
     B, Cin, H, W = x.shape
-    if not WINO_ENABLED or tuple(weight.shape) != (64, 3, 7, 7) or Cin != 3 or x.numel() * 4 > 0xFFFFFF00:
+    if not WINO_ENABLED or not WRW_ENABLED or tuple(weight.shape) != (64, 3, 7, 7) or Cin != 3 or x.numel() * 4 > 0xFFFFFF00:
         return None
     lib = N.lib()
     n = lib.dmh_stem_wrw_workspace_size(B, H, W)
@@ -1321,7 +1321,7 @@ class _DownConvs(torch.autograd.Function):
                 N.ptr(g3), N.ptr(gd), N.ptr(w3t), N.ptr(wdt), B, Cin, Cout, H, W, N.ptr(g_x), N.stream()),
                 nb, 20 * Cin * g3.numel()))
         if not ctx.params_const and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-            n = lib.dmh_down_wrw_workspace_size(B, Cin, Cout, H, W) if x.numel() * 4 <= 0xFFFFFF00 else -1
+            n = lib.dmh_down_wrw_workspace_size(B, Cin, Cout, H, W) if (WRW_ENABLED and x.numel() * 4 <= 0xFFFFFF00) else -1
             if n >= 0 and ctx.needs_input_grad[1]:
                 ws = torch.empty(n, device=x.device, dtype=torch.float32)
                 g_w3 = torch.empty_like(w3, memory_format=torch.contiguous_format)
