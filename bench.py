@@ -463,12 +463,17 @@ def run_rank(a):
     kbytes = ops.profile_bytes()
     hot = ("photo_",) if a.harness == "trainer" else ("paste_",)      # the kernels of the roofline entry carry events
     ops.enable_profile(True, only=hot)
+    atk = getattr(getattr(job, "dataset", None), "depth_atk", None) or getattr(job, "depth_atk", None)
+    it0 = (getattr(atk, "total_iterations", 0), getattr(atk, "total_calls", 0))
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = job.train_step()
     job._apply_pending_update()
     sync()
     elapsed = time.perf_counter() - t0
+    it1 = (getattr(atk, "total_iterations", 0), getattr(atk, "total_calls", 0))
+    # the L0 attack runs atk_steps ... 2 atk_steps iterations by its patch's L0 ratio: the timed region's mean per attack
+    atk_iters = round((it1[0] - it0[0]) / float(it1[1] - it0[1]), 2) if it1[1] > it0[1] else None
     note("timed region done: %.3fs for %d steps" % (elapsed, a.steps))
     kms = {k: v for k, v in ops.profile_ms().items() if k.startswith(hot)}
     kb_timed = ops.profile_bytes()
@@ -597,6 +602,8 @@ def run_rank(a):
                           "attack_scenes": a.atk_scenes, "shared_patch": bool(a.shared_patch),
                           "final_loss": round(loss_val, 6)},
                "roofline": roof}
+        if atk_iters is not None:
+            out["config"]["attack_iterations_per_step"] = atk_iters
         if other_mode is not None:
             out["config"]["other_order"] = other_mode
         if world == 1 and not a.no_cpu_baseline:

@@ -167,6 +167,10 @@ class Phy_obj_atk_l0(Attack):
                 self.trace.append((int(l0_norm), float(mw), float(adv_cost), float(mask_cost)))
         if mine is None:
             random.setstate(rng_states[ran])
+        # the loop runs ``steps`` ... 2 ``steps`` iterations, by the patch's L0 ratio (:105-109): callers that time the attack
+        # (bench.py) report how many it ran
+        self.total_iterations = getattr(self, "total_iterations", 0) + ran
+        self.total_calls = getattr(self, "total_calls", 0) + 1
 
         with torch.no_grad():
             obj_img_adv, _ = ops.l0_compose(self.obj_img, self.pattern_pos_tensor.detach(),
