@@ -19,7 +19,7 @@ namespace {
 constexpr int NT = 256;
 constexpr int BY = 8, BX = 32;              // 2x2 blocks per workgroup: 16 x 64 image pixels
 constexpr int KC = 8;                       // gradient channels per LDS stage
-constexpr int RH = BY + 3, RW = BX + 3;     // g_y region: rows Y0-1 .. Y0+BY+1, cols X0-1 .. X0+BX+1
+constexpr int RW = BX + 3;                  // g_y region: rows Y0-1 .. Y0+BY+1 (BY + 3 of them), cols X0-1 .. X0+BX+1
 
 // Window form (K19, the attack's patch gradient: only the image gradient under the pasted object is read): the workgroups
 // cover the wh x ww block window (2x2-pixel blocks = pixels of g_y's frame) at the per-sample, even image-pixel origin win_org, and
@@ -32,12 +32,19 @@ struct StemWin {
     int sh, sw;             // plane size of g_y
 };
 
-template <int CIN>
+// KS = 4 (the window form: a twelfth of the pixels, ~500 workgroups of a 64-channel serial loop -- latency-bound at 93 us): the
+// workgroup covers BY / 4 rows of blocks and each of its four waves takes a quarter of the gradient channels of every LDS
+// stage; the four partial sums meet in LDS and are added in wave order (fixed: no atomics).
+template <int CIN, int KS>
 __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ w,
                                                            int K, int Ho, int Wo, int gx, int gyb, const StemWin sw_,
                                                            float* __restrict__ gxo) {
+    constexpr int BY = ::BY / KS, RH = BY + 3;      // rows of blocks per workgroup, g_y rows staged for them
+    constexpr int NG = NT / KS;                     // threads per channel group (one wave when KS = 4)
     __shared__ float tile[KC * RH * RW];
+    __shared__ float red[KS > 1 ? (KS - 1) * NG * 4 * CIN : 1];
     const int tid = threadIdx.x;
+    const int grp = __builtin_amdgcn_readfirstlane(tid / NG), lt = tid - grp * NG;
     int bid = blockIdx.x;
     const int bxi = bid % gx;  bid /= gx;
     const int byi = bid % gyb;
@@ -46,7 +53,7 @@ __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restri
     const int gy0 = sw_.gy_org ? sw_.gy_org[2 * b] : 0, gx0 = sw_.gy_org ? sw_.gy_org[2 * b + 1] : 0;
     const int Y0 = wy0 + byi * BY, X0 = wx0 + bxi * BX;
     const int Yend = wy0 + sw_.wh, Xend = wx0 + sw_.ww;
-    const int ty = tid / BX, tx = tid - ty * BX;
+    const int ty = lt / BX, tx = lt - ty * BX;
     const size_t HWo = (size_t)sw_.sh * sw_.sw;
     const float* gb = gy + (size_t)b * K * HWo;
 
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restri
         }
         __syncthreads();
 #pragma unroll 1
-        for (int kk = 0; kk < KC; ++kk) {
+        for (int kk = grp * (KC / KS); kk < (grp + 1) * (KC / KS); ++kk) {
             const float* tp = tile + kk * (RH * RW) + ty * RW + tx;
             const float* wk = w + (size_t)(k0 + kk) * CIN * 49;          // uniform: scalar loads
             float g[4][4];
@@ -106,6 +113,28 @@ __global__ __launch_bounds__(NT) void stem_conv_bwd_kernel(const float* __restri
                     }
         }
     }
+    if (KS > 1) {       // partial sums of waves 1 .. KS-1 to LDS, added by wave 0 in wave order
+        if (grp > 0) {
+            float* rp = red + ((grp - 1) * NG + lt) * 4 * CIN;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) rp[(py * 2 + px) * CIN + c] = acc[py][px][c];
+        }
+        __syncthreads();
+        if (grp > 0) return;
+        for (int g2 = 0; g2 < KS - 1; ++g2) {
+            const float* rp = red + (g2 * NG + lt) * 4 * CIN;
+#pragma unroll
+            for (int py = 0; py < 2; ++py)
+#pragma unroll
+                for (int px = 0; px < 2; ++px)
+#pragma unroll
+                    for (int c = 0; c < CIN; ++c) acc[py][px][c] += rp[(py * 2 + px) * CIN + c];
+        }
+    }
     const int Y = Y0 + ty, X = X0 + tx;
     if (Y < Yend && X < Xend) {
         const int H = 2 * Ho, W = 2 * Wo;
@@ -125,12 +154,22 @@ extern "C" {
 static int launch_stem_bwd(const float* g_y, const float* w, int B, int K, int Cin, int H, int W, const StemWin& sw_,
                            float* g_x, void* stream, const char* fn) {
     const int Ho = H / 2, Wo = W / 2;
-    const int gx = (sw_.ww + BX - 1) / BX, gyb = (sw_.wh + BY - 1) / BY;
+    // few workgroups (a window): four channel groups per workgroup, a quarter of the rows
+    const int gx = (sw_.ww + BX - 1) / BX;
+    const bool split = (long long)B * gx * ((sw_.wh + BY - 1) / BY) < 2048;
+    const int by = split ? BY / 4 : BY, gyb = (sw_.wh + by - 1) / by;
     const long long blocks = (long long)B * gx * gyb;
     if (blocks >= (1ll << 31)) return fail(DMH_EINVAL, "%s: grid too large", fn);
     hipStream_t st = (hipStream_t)stream;
-#define DMH_LAUNCH(CIN) \
-    hipLaunchKernelGGL(stem_conv_bwd_kernel<CIN>, dim3((unsigned)blocks), dim3(NT), 0, st, g_y, w, K, Ho, Wo, gx, gyb, sw_, g_x)
+#define DMH_LAUNCH(CIN)                                                                                                          \
+    do {                                                                                                                         \
+        if (split)                                                                                                               \
+            hipLaunchKernelGGL((stem_conv_bwd_kernel<CIN, 4>), dim3((unsigned)blocks), dim3(NT), 0, st, g_y, w, K, Ho, Wo, gx,   \
+                               gyb, sw_, g_x);                                                                                   \
+        else                                                                                                                     \
+            hipLaunchKernelGGL((stem_conv_bwd_kernel<CIN, 1>), dim3((unsigned)blocks), dim3(NT), 0, st, g_y, w, K, Ho, Wo, gx,   \
+                               gyb, sw_, g_x);                                                                                   \
+    } while (0)
     if (Cin == 1) DMH_LAUNCH(1);
     else if (Cin == 2) DMH_LAUNCH(2);
     else if (Cin == 3) DMH_LAUNCH(3);
