@@ -108,3 +108,24 @@ def test_window_entry_points_reject_bad_shapes_without_gpu():
     assert lib.dmh_stem_conv_norm_fwd_win(one, one, one, 2, 32, 64, 20, 10, 0.45, 0.225, one, None) != 0        # taller than H/2
     assert lib.dmh_ssim_map(one, one, 6, 1, 8, one, None) != 0 and lib.dmh_edge_smooth_partials_size(2, 32, 96) == 2 * 2 * 3
     assert lib.dmh_edge_smooth(one, one, 2, 3, 1, 8, one, one, None) != 0
+
+
+def test_strided_and_stem_weight_gradient_entry_points_without_gpu():
+    """K20 / K21: workspace sizes (-1 for shapes the kernels do not take) and host-side argument checks, no launch."""
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    one = ctypes.c_void_p(16)
+    # layer2.0 at batch 32: 2 channel-block pairs x 256 pixel slices x 10 taps x 64 x 64
+    assert lib.dmh_down_wrw_workspace_size(32, 64, 128, 80, 256) == 2 * 256 * 10 * 64 * 64
+    assert lib.dmh_down_wrw_workspace_size(3, 64, 64, 6, 24) == 9 * 10 * 64 * 64            # nine row tiles: nine slices
+    for bad in ((32, 48, 128, 80, 256), (32, 64, 96, 80, 256), (32, 64, 128, 81, 256), (32, 64, 128, 80, 100), (0, 64, 64, 8, 8)):
+        assert lib.dmh_down_wrw_workspace_size(*bad) == -1, bad
+    assert lib.dmh_down_wrw(one, None, None, 2, 64, 64, 8, 16, one, one, None, None) != 0 and b"null pointer" in lib.dmh_last_error()
+    assert lib.dmh_down_wrw(one, one, one, 2, 64, 64, 8, 16, one, one, None, None) != 0            # gd without dwd
+    assert lib.dmh_down_wrw(one, one, None, 2, 64, 64, 8, 12, one, one, None, None) != 0 and b"multiple of 8" in lib.dmh_last_error()
+    # stem at batch 32, 320 x 1024: 20,480 row tiles -> 512 workgroups x 4 waves x 10 blocks of 32 x 32
+    assert lib.dmh_stem_wrw_workspace_size(32, 320, 1024) == 512 * 4 * 10 * 1024
+    assert lib.dmh_stem_wrw_workspace_size(3, 38, 72) == 30 * 4 * 10 * 1024
+    assert lib.dmh_stem_wrw_workspace_size(2, 37, 72) == -1 and lib.dmh_stem_wrw_workspace_size(2, 38, 76) == -1
+    assert lib.dmh_stem_wrw(one, one, 2, 38, 76, 0.45, 0.225, one, one, None) != 0 and b"multiple of 8" in lib.dmh_last_error()
+    assert lib.dmh_stem_wrw(one, one, 2, 38, 72, 0.45, 0.0, one, one, None) != 0 and b"std" in lib.dmh_last_error()
