@@ -27,39 +27,37 @@ constexpr int NT = 256;
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expf(x) - 1.f; }
 __device__ __forceinline__ float elu_grad(float x) { return x > 0.f ? 1.f : expf(x); }
 
-// Thread block = 64 column pairs x 4 rows, walking FWD_ROWS rows: the column part of the index map (reflection, up-sampling,
-// clamp into the source window) is formed once per thread, the row part once per row -- one thread per output pair with the
-// whole map recomputed per element ran at 2.1 TB/s, bound by its ~60 integer instructions per pair
-constexpr int FWD_ROWS = 16;
-
 __global__ __launch_bounds__(NT) void roi_glue_fwd_kernel(const dmh_roi_glue_args a, float* __restrict__ out) {
     const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
-    const int j = (blockIdx.x * 64 + (threadIdx.x & 63)) * 2;        // PW is even: a pair never straddles two rows
-    if (j >= PW) return;
-    const int plane = blockIdx.z, b = plane / C, c = plane - b * C;
+    const int idx = (blockIdx.x * NT + threadIdx.x) * 2;        // PW is even: a pair never straddles two rows
+    if (idx >= PH * PW) return;
+    const int plane = blockIdx.y, b = plane / C, c = plane - b * C;
+    const int i = idx / PW, j = idx - i * PW;
     const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
+    const int Y = reflect_idx(oy + i - 1, a.H);
     const int X0 = reflect_idx(ox + j - 1, a.W), X1 = reflect_idx(ox + j, a.W);
-    const bool from_y = c < a.C1;
-    const int* sorg = from_y ? a.y_org : a.skip_org;
-    const int sy0 = sorg ? sorg[2 * b] : 0, sx0 = sorg ? sorg[2 * b + 1] : 0;
-    const int sh = from_y ? a.sh : a.kh, sw = from_y ? a.sw : a.kw;
-    const int shift = (from_y && a.up) ? 1 : 0;
-    const int x0 = min(max((X0 >> shift) - sx0, 0), sw - 1), x1 = min(max((X1 >> shift) - sx0, 0), sw - 1);
-    const float* src = from_y ? a.y + (size_t)(b * a.C1 + c) * sh * sw : a.skip + (size_t)(b * a.C2 + (c - a.C1)) * sh * sw;
-    const bool elu = from_y && a.elu;
-    float* op = out + (size_t)plane * PH * PW + j;
-    const int i0 = blockIdx.y * FWD_ROWS + (threadIdx.x >> 6), i1 = min(blockIdx.y * FWD_ROWS + FWD_ROWS, PH);
-    for (int i = i0; i < i1; i += 4) {
-        const int Y = reflect_idx(oy + i - 1, a.H);
-        const int yy = min(max((Y >> shift) - sy0, 0), sh - 1);
-        const float* row = src + (size_t)yy * sw;
-        float v0 = row[x0], v1 = row[x1];
-        if (elu) {
+    float v0, v1;
+    if (c < a.C1) {
+        const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
+        const int yy = min(max((a.up ? Y >> 1 : Y) - sy0, 0), a.sh - 1);
+        const int x0 = min(max((a.up ? X0 >> 1 : X0) - sx0, 0), a.sw - 1);
+        const int x1 = min(max((a.up ? X1 >> 1 : X1) - sx0, 0), a.sw - 1);
+        const float* row = a.y + ((size_t)(b * a.C1 + c) * a.sh + yy) * a.sw;
+        v0 = row[x0];
+        v1 = row[x1];
+        if (a.elu) {
             v0 = elu_f(v0);
             v1 = elu_f(v1);
         }
-        *reinterpret_cast<float2*>(op + (size_t)i * PW) = make_float2(v0, v1);
+    } else {
+        const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
+        const int yy = min(max(Y - ky0, 0), a.kh - 1);
+        const int x0 = min(max(X0 - kx0, 0), a.kw - 1), x1 = min(max(X1 - kx0, 0), a.kw - 1);
+        const float* row = a.skip + ((size_t)(b * a.C2 + (c - a.C1)) * a.kh + yy) * a.kw;
+        v0 = row[x0];
+        v1 = row[x1];
     }
+    *reinterpret_cast<float2*>(out + (size_t)plane * PH * PW + idx) = make_float2(v0, v1);
 }
 
 // sum of the window's padded-gradient entries that read frame position (Y, X): the entry straight above it and, on
@@ -83,6 +81,13 @@ __device__ __forceinline__ float gather_pad(const float* __restrict__ gp, int Y,
     return acc;
 }
 
+// the same sum for an element whose readers cannot involve the frame's border (1 < Y < H - 2, 1 < X < W - 2): the one entry
+// straight above it, if the window holds it
+__device__ __forceinline__ float gather_interior(const float* __restrict__ gp, int Y, int X, int oy, int ox, int PH, int PW) {
+    const int r = Y + 1 - oy, q = X + 1 - ox;
+    return (r >= 0 && r < PH && q >= 0 && q < PW) ? gp[r * PW + q] : 0.f;
+}
+
 // grid.y = B*C1 planes of g_y followed by B*C2 planes of g_skip; one thread per source element of the REGION to write: the
 // whole plane (0 where no window entry reads the element), or -- for a whole-frame source -- a per-sample rectangle that
 // holds everything the window reaches (the caller owns the rest of the plane: pre-zeroed, or never read)
@@ -92,27 +97,18 @@ struct Region {
     int yh, yw, kh, kw;     // rectangle sizes (plane sizes when the table is NULL)
 };
 
-// the same sum for an element whose readers cannot involve the frame's border (1 < Y < H - 2, 1 < X < W - 2): the one entry
-// straight above it, if the window holds it
-__device__ __forceinline__ float gather_interior(const float* __restrict__ gp, int Y, int X, int oy, int ox, int PH, int PW) {
-    const int r = Y + 1 - oy, q = X + 1 - ox;
-    return (r >= 0 && r < PH && q >= 0 && q < PW) ? gp[r * PW + q] : 0.f;
-}
-
-// thread block = 64 columns x 4 rows of the region (no division per element); away from the frame's border -- all but two
-// rows / columns of a frame -- an element's readers are the entries straight above it (above its 2 x 2 children when the
-// source is up-sampled): four loads instead of the general reflection gather
 __global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_args a, const Region rg,
                                                           const float* __restrict__ g_out, float* __restrict__ g_y,
                                                           float* __restrict__ g_skip) {
     const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
-    int xx = blockIdx.x * 64 + (threadIdx.x & 63), yy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int plane = blockIdx.z;
+    const int t = blockIdx.x * NT + threadIdx.x;
+    const int plane = blockIdx.y;
     if (plane < a.B * a.C1) {
-        if (yy >= rg.yh || xx >= rg.yw) return;
+        if (t >= rg.yh * rg.yw) return;
         const int b = plane / a.C1, c = plane - b * a.C1;
         const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
         const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
+        int yy = t / rg.yw, xx = t - yy * rg.yw;
         if (rg.y_org) {
             yy += rg.y_org[2 * b];
             xx += rg.y_org[2 * b + 1];
@@ -123,8 +119,10 @@ __global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_arg
         if (a.up) {
             const int Y0 = 2 * Ys, X0 = 2 * Xs;
             if (Y0 > 1 && Y0 + 1 < a.H - 2 && X0 > 1 && X0 + 1 < a.W - 2) {
+                // away from the frame's border (all but two rows / columns): the readers of the 2 x 2 children are the entries
+                // straight above them -- four loads instead of the general reflection gather
                 const int r = Y0 + 1 - oy, q = X0 + 1 - ox;
-                if (r >= 0 && r + 1 < PH && q >= 0 && q + 1 < PW) {          // both children rows and columns inside the window
+                if (r >= 0 && r + 1 < PH && q >= 0 && q + 1 < PW) {
                     const float* p0 = gp + r * PW + q;
                     acc = p0[0] + p0[1] + p0[PW] + p0[PW + 1];      // (the general path's order of additions)
                 } else if (r + 1 < 0 || r >= PH || q + 1 < 0 || q >= PW) {
@@ -146,10 +144,11 @@ __global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_arg
         const size_t o = ((size_t)plane * a.sh + yy) * a.sw + xx;
         g_y[o] = (a.elu && acc != 0.f) ? acc * elu_grad(a.y[o]) : acc;
     } else {
-        if (yy >= rg.kh || xx >= rg.kw) return;
+        if (t >= rg.kh * rg.kw) return;
         const int q = plane - a.B * a.C1, b = q / a.C2, c = q - b * a.C2;
         const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
         const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
+        int yy = t / rg.kw, xx = t - yy * rg.kw;
         if (rg.skip_org) {
             yy += rg.skip_org[2 * b];
             xx += rg.skip_org[2 * b + 1];
@@ -221,7 +220,7 @@ int check_glue(const dmh_roi_glue_args* a) {
                 "bad sizes");
     DMH_REQUIRE(a->hc >= 2 && a->wc >= 2 && (a->wc & 1) == 0 && a->hc <= a->H && a->wc <= a->W && a->H >= 4 && a->W >= 4,
                 "window must be at least 2 x 2, of even width, inside a frame of at least 4 x 4");
-    DMH_REQUIRE((int64_t)a->B * (a->C1 + a->C2) <= 65535 && (a->hc + 2 + FWD_ROWS - 1) / FWD_ROWS <= 65535, "too many planes / rows");
+    DMH_REQUIRE((int64_t)a->B * (a->C1 + a->C2) <= 65535, "too many planes");
     DMH_REQUIRE((int64_t)a->sh * a->sw < (1 << 30) && (int64_t)a->kh * a->kw < (1 << 30), "source plane too large");
     return DMH_OK;
 }
@@ -233,9 +232,7 @@ extern "C" {
 int dmh_roi_glue_fwd(const dmh_roi_glue_args* a, float* out, void* stream) {
     if (int rc = check_glue(a)) return rc;
     DMH_REQUIRE(out, "null pointer");
-    hipLaunchKernelGGL(roi_glue_fwd_kernel,
-                       dim3((unsigned)((a->wc + 2 + 127) / 128), (unsigned)((a->hc + 2 + FWD_ROWS - 1) / FWD_ROWS),
-                            (unsigned)(a->B * (a->C1 + a->C2))),
+    hipLaunchKernelGGL(roi_glue_fwd_kernel, dim3(blocks_for((int64_t)(a->hc + 2) * (a->wc + 2) / 2), a->B * (a->C1 + a->C2)),
                        dim3(NT), 0, (hipStream_t)stream, *a, out);
     return check_launch("dmh_roi_glue_fwd");
 }
@@ -257,10 +254,9 @@ int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y,
     rg.kw = skip_reg_org ? skip_reg_w : a->kw;
     const bool skip = g_skip && a->C2 > 0;
     const int planes = a->B * a->C1 + (skip ? a->B * a->C2 : 0);
-    const int mh = (skip && rg.kh > rg.yh) ? rg.kh : rg.yh, mw = (skip && rg.kw > rg.yw) ? rg.kw : rg.yw;
-    DMH_REQUIRE((mh + 3) / 4 <= 65535, "region too tall");
-    hipLaunchKernelGGL(roi_glue_bwd_kernel, dim3((unsigned)((mw + 63) / 64), (unsigned)((mh + 3) / 4), (unsigned)planes), dim3(NT), 0,
-                       (hipStream_t)stream, *a, rg, g_out, g_y, g_skip);
+    const int64_t ny = (int64_t)rg.yh * rg.yw, nk = skip ? (int64_t)rg.kh * rg.kw : 0;
+    hipLaunchKernelGGL(roi_glue_bwd_kernel, dim3(blocks_for(ny > nk ? ny : nk), planes), dim3(NT), 0, (hipStream_t)stream, *a,
+                       rg, g_out, g_y, g_skip);
     return check_launch("dmh_roi_glue_bwd");
 }
 

@@ -9,6 +9,11 @@ MODE=${2:-bench}   # the K10 loop below re-sets the positional parameters
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
+if [ "$MODE" = "benchonly" ]; then     # only the whole-step trace (after a change that leaves the per-kernel passes as they are)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_trace -- python3 bench.py --steps 3 --warmup 1 --no_cpu_baseline > $OUT/bench.json 2> $OUT/bench.err
+  tail -1 $OUT/bench.json | cut -c1-200
+  exit 0
+fi
 K1="python3 tools/prof_k1.py"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/k1_trace -- $K1 5 > $OUT/k1_trace.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY --output-format csv -d $OUT/k1_pmc_a -- $K1 2 > $OUT/k1_pmc_a.log 2>&1
