@@ -824,8 +824,8 @@ def stem_bn_relu_pool(x, scale, shift):
 
 
 # ---------------------------------------------------------------------------------------------------------------
-# K10: 3x3 stride-1 convolution, Winograd F(2x2,3x3) on the fp32 matrix cores (forward and backward-data); the weight
-# gradient stays on MIOpen.  Dispatch is by shape: the kernel wins where a launch fills the chip with >= 64 output
+# K10: 3x3 stride-1 convolution, Winograd F(2x2,3x3) on the fp32 matrix cores (forward and backward-data); weight gradients:
+# K13 / K16 / K18 by channel counts.  Dispatch is by shape: the kernel wins where a launch fills the chip with >= 64 output
 # channels (tools/wino_bench.py, profiles/); everything else is the ATen/MIOpen convolution.
 # ---------------------------------------------------------------------------------------------------------------
 WINO_ENABLED = os.environ.get("DMH_WINO", "1") != "0"
@@ -884,6 +884,9 @@ def _wino_filter(weight, backward, scale=None):
     return U
 
 
+_WINO_MIN_ITEMS = int(os.environ.get("DMH_WINO_MIN_ITEMS", "200"))      # work items below which MIOpen is level or ahead (A/B switch)
+
+
 def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     """Shapes the Winograd-MFMA kernel takes: channel counts it tiles without waste and enough 64-channel x 64-tile
     work items to fill the 256 CUs (measured crossover, tools/wino_bench.py)."""
@@ -907,7 +910,7 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     regions *= -(-n_out // 64)
     nch = n_in // 8
     split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
-    return regions * split >= 200
+    return regions * split >= _WINO_MIN_ITEMS
 
 
 def _wrw_ok(x, g, K, Cc):
@@ -1161,8 +1164,9 @@ def conv3x3_bn_act(x, weight, scale, shift, residual=None, relu=True, padding=1)
 def conv3x3(x, weight, bias=None, padding=1):
     """nn.Conv2d(C, K, 3, stride=1, padding=padding) with zero padding 0, 1 or 2 -- the 3x3 convolutions of the ResNet
     encoder (torchvision BasicBlock under MD2/networks/resnet_encoder.py:85-98) and of the depth decoder
-    (MD2/layers.py:127-141 Conv3x3).  Forward and the gradient w.r.t. x run the K10 Winograd-MFMA kernel where the
-    shape fills the chip; the weight/bias gradients and the remaining shapes are ATen/MIOpen."""
+    (MD2/layers.py:127-141 Conv3x3).  Forward and the gradient w.r.t. x run the K10 / K17 / K11 / K13 kernels by shape (K10
+    where >= 64 output channels fill the chip), the weight gradient K13 / K16 / K18 by channel counts (fixed-order sums); the
+    remaining shapes are ATen/MIOpen."""
     if padding not in (0, 1, 2) or weight.shape[2:] != (3, 3):
         raise RuntimeError("conv3x3: 3x3 kernel with padding 0, 1 or 2 expected")
     if not x.is_cuda:
