@@ -70,13 +70,30 @@ def measured_traffic(B, H, W):
     return out
 
 
-def valu_roof(insts, measured_ms):
-    """The vector-issue roof of a VALU-bound kernel: SQ_INSTS_VALU wave-instructions at the chip's rate of one wave64
-    instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: `v_fma_f32` 2 cyc on a SIMD-32 once >= 2 waves are resident; ONE
-    wave alone issues every 4), 1024 SIMDs, 2.4 GHz."""
-    floor_ms = insts * 2.0 / 1024.0 / 2.4e9 * 1e3
-    return {"bound": "valu", "SQ_INSTS_VALU": insts, "cycles_per_wave_instruction": 2, "floor_ms": round(floor_ms, 4),
-            "frac": round(floor_ms / measured_ms, 4) if measured_ms else None}
+# one scalar (non-packed) fp32 vector instruction per SIMD, in cycles of the nominal 2.4 GHz clock, MEASURED on all 256 CUs with
+# tools/micro/valu_rate.hip (profiles/r04_valu_rate.txt): 7.87 / 5.84 / 5.07 / 4.81 / 4.52 / 4.44 at 1 / 2 / 3 / 4 / 6 / 8 waves per
+# SIMD -- the data sheet's 2-cycle rate is approached by packed `v_pk_*_f32` only (4.83 cycles per packed instruction = two
+# operations per lane)
+SCALAR_FP32_ISSUE_CYCLES = {1: 7.87, 2: 5.84, 3: 5.07, 4: 4.81, 6: 4.52, 8: 4.44}
+K1_WAVES_PER_SIMD = {"photo_fwd": 3, "photo_bwd": 2}     # 167 / 214 VGPRs (hipcc -Rpass-analysis=kernel-resource-usage)
+
+
+def valu_roof(insts, measured_ms, waves_per_simd=None):
+    """The vector-issue roof of a VALU-bound kernel: SQ_INSTS_VALU wave-instructions at the chip's peak rate of one wave64
+    instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: 32 lanes per cycle), 1024 SIMDs, 2.4 GHz -- and, beside it, at the
+    rate a stream of scalar fp32 vector instructions was MEASURED to issue at: saturated (8 waves per SIMD), and at the
+    kernel's own occupancy (``waves_per_simd``: 3 for K1 forward at 167 VGPRs, 2 for the backward at 214)."""
+    def floor(cyc):
+        ms = insts * cyc / 1024.0 / 2.4e9 * 1e3
+        return {"cycles_per_wave_instruction": cyc, "floor_ms": round(ms, 4), "frac": round(ms / measured_ms, 4) if measured_ms else None}
+    out = {"bound": "valu", "SQ_INSTS_VALU": insts}
+    out.update(floor(2))
+    out["measured_scalar_fp32_issue"] = dict(floor(SCALAR_FP32_ISSUE_CYCLES[8]), waves_per_simd=8,
+                                             source="tools/micro/valu_rate.hip on all 256 CUs, profiles/r04_valu_rate.txt")
+    if waves_per_simd in SCALAR_FP32_ISSUE_CYCLES:
+        out["measured_scalar_fp32_issue_at_occupancy"] = dict(floor(SCALAR_FP32_ISSUE_CYCLES[waves_per_simd]),
+                                                              waves_per_simd=waves_per_simd)
+    return out
 
 
 def k1_bytes(B, H, W, scales=4):
@@ -533,11 +550,12 @@ def run_rank(a):
                             "K3 EOT paste (the hot-path kernel of this harness): SURVEY 8d bytes per launch, averaged over the "
                             "launches of the timed region",
                     "avg_ms": round(kms[dom], 4), "algorithmic_bytes": nbytes,
-                    "valu_roof": valu_roof(meas[dom + "_valu_insts"], kms[dom]) if meas.get(dom + "_valu_insts") else None,
+                    "valu_roof": valu_roof(meas[dom + "_valu_insts"], kms[dom], K1_WAVES_PER_SIMD.get(dom))
+                    if meas.get(dom + "_valu_insts") else None,
                     "others": {names[k][0]: {"avg_ms": round(v, 4), "GB/s": round(names[k][1] / (v * 1e-3) / 1e9, 1),
                                              "algorithmic_bytes": names[k][1], "traffic": meas.get(k),
-                                             "valu_roof": valu_roof(meas[k + "_valu_insts"], v) if meas.get(k + "_valu_insts")
-                                             else None}
+                                             "valu_roof": valu_roof(meas[k + "_valu_insts"], v, K1_WAVES_PER_SIMD.get(k))
+                                             if meas.get(k + "_valu_insts") else None}
                                for k, v in kms.items() if k != dom}}
             # streaming kernels of the decoder glue: shapes vary per launch, so total bytes / total time
             for k, (cnt, ms, nb, fl) in sorted(kbytes.items()):
