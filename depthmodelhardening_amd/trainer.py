@@ -355,6 +355,9 @@ class Trainer:
         if self.opt.v1_multiscale:
             return self._losses_v1_multiscale(inputs, outputs, losses, total_loss, frames)
         if self.opt.predictive_mask or (self.opt.avg_reprojection and len(frames) > 1):
+            if self.opt.loss_variant != "md2":      # DepthHints forms its masks differently (DH/trainer.py:667-712): not composed here
+                raise NotImplementedError("--predictive_mask / --avg_reprojection over several source frames: Monodepth2's loss "
+                                          "only (--loss_variant md2)")
             return self._losses_composed(inputs, outputs, losses, total_loss, frames)
         out = ops.photometric_smooth_loss(
             inputs[("color", 0, 0)], [inputs[("color", f, 0)] for f in frames],
