@@ -75,6 +75,7 @@ def measured_traffic(B, H, W):
 # SIMD -- the data sheet's 2-cycle rate is approached by packed `v_pk_*_f32` only (4.83 cycles per packed instruction = two
 # operations per lane)
 SCALAR_FP32_ISSUE_CYCLES = {1: 7.87, 2: 5.84, 3: 5.07, 4: 4.81, 6: 4.52, 8: 4.44}
+VALU_F32_SCALAR_TFLOPS = round(1024 * 64 * 2 * 2.4e9 / SCALAR_FP32_ISSUE_CYCLES[8] / 1e12, 1)     # 70.9
 K1_WAVES_PER_SIMD = {"photo_fwd": 3, "photo_bwd": 2}     # 167 / 214 VGPRs (hipcc -Rpass-analysis=kernel-resource-usage)
 
 
@@ -561,7 +562,13 @@ def run_rank(a):
             for k, (cnt, ms, nb, fl) in sorted(kbytes.items()):
                 if not k.startswith("photo_") and k not in names and ms > 0:
                     ent = {"launches_per_step": cnt, "ms_per_step": round(ms, 3)}      # the one instrumented step
-                    if fl > 0 and k.startswith("wino"):    # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe
+                    if k.startswith("stem_conv_bwd"):      # K12 (both forms): 147 FMAs per gradient channel and 2x2 pixel block
+                        tf = fl / (ms * 1e-3) / 1e12        # on the VECTOR ALU with the filter in SGPRs -- not on the MFMA
+                        ent.update({"bound": "valu", "achieved": round(tf, 1), "peak": VALU_F32_SCALAR_TFLOPS, "unit": "TFLOP/s",
+                                    "frac": round(tf / VALU_F32_SCALAR_TFLOPS, 4),
+                                    "note": "peak = the MEASURED issue rate of scalar fp32 FMAs, 4.44 cycles per wave-instruction "
+                                            "and SIMD (profiles/r04_valu_rate.txt); the data sheet's 157.3 TFLOP/s is the packed rate"})
+                    elif fl > 0 and k.startswith("wino"):  # the Winograd-MFMA convolution (K10): bound by the fp32 matrix pipe
                         direct = fl / (ms * 1e-3) / 1e12
                         ent.update({"bound": "mfma", "TFLOP/s_direct_equivalent": round(direct, 1),
                                     "achieved": round(direct / 2.25, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -574,10 +581,6 @@ def run_rank(a):
                     else:
                         ent.update({"bound": "hbm", "GB/s": round(nb / (ms * 1e-3) / 1e9, 1),
                                     "frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)})
-                        if k == "stem_conv_bwd":
-                            ent["bound"] = "valu"       # 147 FMAs per gradient channel and 2x2 pixel block on the vector ALU
-                            ent["note"] = ("vector-ALU gather (filter in SGPRs): bound by VALU issue; the GB/s figure is its "
-                                           "algorithmic traffic, not its roof")
                     roof["others"][k + "_kernel"] = ent
         # whole-step compute fraction: U-Net FLOPs per image measured with torch.utils.flop_counter, times the
         # U-Net passes counted in the instrumented step (direct-convolution FLOPs: the Winograd kernels issue 2.25x fewer)

@@ -1211,7 +1211,8 @@ class _StemConv(torch.autograd.Function):
             g_x = torch.empty_like(x)
             nb = 4 * (g.numel() + g_x.numel())
             N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(_c(weight.detach())), B, K,
-                                                                              Cin, H, W, N.ptr(g_x), N.stream()), nb))
+                                                                              Cin, H, W, N.ptr(g_x), N.stream()), nb,
+                           2 * 49 * Cin * g.numel()))
         if need_w:
             g_w = _stem_wrw(x, g, weight, 0.0, 1.0)
             if g_w is None:
@@ -1265,7 +1266,7 @@ class _StemConvNorm(torch.autograd.Function):
             w_s = frozen_memo(("stem_w_over_std", weight.data_ptr(), weight._version, std),
                               lambda: _c(weight.detach() * (1.0 / std)))
             N.check(_timed("stem_conv_bwd", lambda: lib.dmh_conv7x7s2_bwd_data(N.ptr(g), N.ptr(w_s), B, 64, Cin, H, W,
-                                                                              N.ptr(g_x), N.stream()), nb))
+                                                                              N.ptr(g_x), N.stream()), nb, 2 * 147 * g.numel()))
         if ctx.needs_input_grad[1] and not ctx.params_const:
             g_w = _stem_wrw(x, g, weight, mean, std)
             if g_w is None:
@@ -1824,7 +1825,7 @@ class _EncHeadEval(torch.autograd.Function):
         hd, wd = sz["d"]
         N.check(_timed("stem_conv_bwd_win", lambda: lib.dmh_conv7x7s2_bwd_data_win(
             N.ptr(g_z), N.ptr(w_s), N.ptr(org["d"]), N.ptr(org["gz"]), B, 64, 3, H, W, hd, wd, hs, ws, N.ptr(g_x), st),
-            4 * (g_z.numel() + B * 3 * hd * wd)))
+            4 * (g_z.numel() + B * 3 * hd * wd), 2 * 147 * 64 * B * (hd // 2) * (wd // 2)))
         return (g_x,) + (None,) * 17
 
 
@@ -2065,7 +2066,7 @@ class _EncHeadInc(torch.autograd.Function):
         hd, wd = plan.size["d"]
         N.check(_timed("stem_conv_bwd_win", lambda: lib.dmh_conv7x7s2_bwd_data_win(
             N.ptr(g_z), N.ptr(w_s), N.ptr(org["d"]), N.ptr(org["hz"]), B, 64, 3, H, W, hd, wd, hz, wz, N.ptr(g_x), st),
-            4 * (g_z.numel() + B * 3 * hd * wd)))
+            4 * (g_z.numel() + B * 3 * hd * wd), 2 * 147 * 64 * B * (hd // 2) * (wd // 2)))
         return (g_x,) + (None,) * (n_in - 1)
 
 
