@@ -41,7 +41,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));    // native vector: arrays of it stay in registers
 
 #ifndef DMH_WINO_ABLATE          // tools/wino_ablate.sh: 1 no global loads, 2 no input transform, 4 no LDS staging writes,
-#define DMH_WINO_ABLATE 0        // 16 no MFMAs in the steady-state loop (timing experiments only: results are garbage)
+#define DMH_WINO_ABLATE 0        // 16 no MFMAs in the steady-state loop, 32 no stores in the epilogue, 64 the epilogue's transform + stores twice (timing only)
 #endif
 constexpr int CK = 8;            // input channels per chunk
 constexpr int NT = 256;
@@ -456,6 +456,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
                 for (int v = 0; v < RPF; ++v) res_fetch(v, rq0[v], rq1[v]);
             }
+#pragma unroll 1
+            for (int rep = 0; rep < ((DMH_WINO_ABLATE & 64) ? 2 : 1); ++rep)      // timing experiment: the transform + stores twice
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int ko = kbase + (v & 3) + 8 * (v >> 2);
@@ -489,7 +491,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                             y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
                         }
                     }
-                    if (EPI || a.csplit == 1) {
+                    if ((DMH_WINO_ABLATE & 32) && a.K > 0) {     // timing experiment: everything but the stores
+                        asm volatile("" ::"v"(y00), "v"(y01), "v"(y10), "v"(y11));
+                    } else if (EPI || a.csplit == 1) {
                         *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
                         *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
                     } else {    // two partial sums into zeros: 0 + a + b is the same in either order (deterministic)
