@@ -81,6 +81,8 @@ _SIGNATURES = {
     "dmh_sq_mean_partials_size": (C.c_int64, [C.c_int64]),
     "dmh_masked_sq_mean_fwd": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, _fp]),
     "dmh_masked_sq_mean_bwd": (C.c_int, [_fp, _fp, C.c_int64, _fp, _fp, _fp]),
+    "dmh_gt_depth_mse_fwd": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp, C.c_int, C.c_int64, C.c_float, C.c_float, _fp, _fp, _fp]),
+    "dmh_gt_depth_mse_bwd": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp, C.c_int, C.c_int64, C.c_float, C.c_float, _fp, _fp, _fp]),
     "dmh_ssim_map": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "dmh_ssim_map_bwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "dmh_edge_smooth_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),

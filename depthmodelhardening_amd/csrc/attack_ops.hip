@@ -207,6 +207,63 @@ __global__ __launch_bounds__(NT) void sq_mean_bwd_kernel(const float* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------- K6b
+// --gt_depth supervised term (MD2/trainer.py:551-557): with depth(d) = clamp(5.4 / (min_disp + (max_disp - min_disp) d), 1e-3, 80)
+// (disp_to_depth, layers.py:16-25; 5.4 = the stereo scale factor) the loss is
+//     mean_{b,y,x} ( m objdepth_b + depth(disp_gt) (1 - m)  -  depth(disp) )^2 ,  m = color_objmask[:, 0]
+// one streaming pass over disp, disp_gt and channel 0 of the mask (batch stride mask_bstride floats); two-stage fixed-order sum.
+__device__ __forceinline__ float sup_depth(float d, float min_disp, float range, bool& inside) {
+    const float sd = min_disp + range * d;
+    const float z = (1.f / sd) * 5.4f;
+    inside = z >= 1e-3f && z <= 80.f;       // torch.clamp passes the gradient on the closed interval
+    return fminf(fmaxf(z, 1e-3f), 80.f);
+}
+
+__global__ __launch_bounds__(NT) void gt_depth_fwd_kernel(const float* __restrict__ disp, const float* __restrict__ disp_gt,
+                                                          const float* __restrict__ m, int64_t mask_bstride,
+                                                          const float* __restrict__ objdepth, int B, int64_t HW,
+                                                          float min_disp, float range, float* __restrict__ partials) {
+    __shared__ float s_red[NT / WAVE];
+    float acc = 0.f;
+    const int64_t n = (int64_t)B * HW;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / HW, r = i - b * HW;
+        bool in;
+        const float pred = sup_depth(disp[i], min_disp, range, in);
+        const float pseudo = sup_depth(disp_gt[i], min_disp, range, in);
+        const float mk = m[b * mask_bstride + r];
+        const float gt = mk * objdepth[b] + pseudo * (1.f - mk);
+        const float v = gt - pred;
+        acc += v * v;
+    }
+    const float t = block_sum<NT>(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(NT) void gt_depth_bwd_kernel(const float* __restrict__ disp, const float* __restrict__ disp_gt,
+                                                          const float* __restrict__ m, int64_t mask_bstride,
+                                                          const float* __restrict__ objdepth, int B, int64_t HW,
+                                                          float min_disp, float range, const float* __restrict__ gscale,
+                                                          float* __restrict__ g) {
+    const int64_t n = (int64_t)B * HW;
+    const float up = gscale[0] * 2.f / (float)n;
+    const int64_t stride = (int64_t)gridDim.x * NT;
+    for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < n; i += stride) {
+        const int64_t b = i / HW, r = i - b * HW;
+        bool in, in_gt;
+        const float d = disp[i];
+        const float pred = sup_depth(d, min_disp, range, in);
+        const float pseudo = sup_depth(disp_gt[i], min_disp, range, in_gt);
+        const float mk = m[b * mask_bstride + r];
+        const float gt = mk * objdepth[b] + pseudo * (1.f - mk);
+        // d pred / d disp = -5.4 range / sd^2 inside the clamp, 0 outside
+        const float sd = min_disp + range * d;
+        const float isd = 1.f / sd;
+        g[i] = in ? up * (pred - gt) * (-5.4f * range) * isd * isd : 0.f;
+    }
+}
+
 inline int grid_for(int64_t n) {
     const int64_t b = (n + NT - 1) / NT;
     return (int)(b < 1 ? 1 : (b > 2048 ? 2048 : b));
@@ -289,6 +346,33 @@ int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, cons
     hipLaunchKernelGGL(sq_mean_bwd_kernel, dim3(grid_for(n)), dim3(NT), 0, (hipStream_t)stream, disp, mask, n, gscale,
                        g_disp);
     return check_launch("dmh_masked_sq_mean_bwd");
+}
+
+int dmh_gt_depth_mse_fwd(const float* disp, const float* disp_gt, const float* objmask, int64_t mask_bstride,
+                         const float* objdepth, int B, int64_t HW, float min_depth, float max_depth, float* partials,
+                         float* cost, void* stream) {
+    DMH_REQUIRE(disp && disp_gt && objmask && objdepth && partials && cost, "null pointer");
+    DMH_REQUIRE(B > 0 && HW > 0 && mask_bstride >= HW, "bad sizes (mask batch stride below H*W?)");
+    DMH_REQUIRE(min_depth > 0.f && max_depth > min_depth, "need 0 < min_depth < max_depth");
+    const int64_t n = (int64_t)B * HW;
+    const int nb = red_blocks(n);
+    const float min_disp = (float)(1.0 / (double)max_depth), range = (float)(1.0 / (double)min_depth - 1.0 / (double)max_depth);
+    hipLaunchKernelGGL(gt_depth_fwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, disp, disp_gt, objmask, mask_bstride,
+                       objdepth, B, HW, min_disp, range, partials);
+    hipLaunchKernelGGL(sq_mean_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partials, nb, n, cost);
+    return check_launch("dmh_gt_depth_mse_fwd");
+}
+
+int dmh_gt_depth_mse_bwd(const float* disp, const float* disp_gt, const float* objmask, int64_t mask_bstride,
+                         const float* objdepth, int B, int64_t HW, float min_depth, float max_depth, const float* gscale,
+                         float* g_disp, void* stream) {
+    DMH_REQUIRE(disp && disp_gt && objmask && objdepth && gscale && g_disp, "null pointer");
+    DMH_REQUIRE(B > 0 && HW > 0 && mask_bstride >= HW, "bad sizes (mask batch stride below H*W?)");
+    DMH_REQUIRE(min_depth > 0.f && max_depth > min_depth, "need 0 < min_depth < max_depth");
+    const float min_disp = (float)(1.0 / (double)max_depth), range = (float)(1.0 / (double)min_depth - 1.0 / (double)max_depth);
+    hipLaunchKernelGGL(gt_depth_bwd_kernel, dim3(grid_for((int64_t)B * HW)), dim3(NT), 0, (hipStream_t)stream, disp, disp_gt,
+                       objmask, mask_bstride, objdepth, B, HW, min_disp, range, gscale, g_disp);
+    return check_launch("dmh_gt_depth_mse_bwd");
 }
 
 }  // extern "C"

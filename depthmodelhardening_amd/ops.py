@@ -422,6 +422,56 @@ def masked_sq_mean(disp, mask=None):
     return _MaskedSqMean.apply(_c(disp), None if mask is None else _c(mask))
 
 
+def _gt_depth_operands(disp, disp_gt, objmask, objdepth):
+    """Checked operands of the --gt_depth term: (disp, disp_gt, mask tensor, mask batch stride, objdepth[B], B, HW).
+    ``objmask`` is inputs[("color_objmask",0,0)] ([B,3,H,W] or [B,1,H,W]; channel 0 is read in place through its batch stride),
+    ``objdepth`` inputs[("objdepth",0,0)] (one distance per sample, any shape with B elements)."""
+    disp, disp_gt = _c(disp), _c(disp_gt)
+    if disp.dim() != 4 or disp.shape[1] != 1 or disp_gt.shape != disp.shape:
+        raise RuntimeError("gt_depth_mse: disp and disp_gt must both be [B,1,H,W]")
+    B, _, H, W = disp.shape
+    if objmask.dim() != 4 or objmask.shape[0] != B or tuple(objmask.shape[2:]) != (H, W):
+        raise RuntimeError("gt_depth_mse: color_objmask must be [B,C,H,W] at the disparity's size")
+    if objmask.stride(3) != 1 or objmask.stride(2) != W or objmask.stride(0) < H * W:
+        objmask = objmask[:, :1].contiguous()      # e.g. the dataset's expand(-1, 3, -1, -1) view of a one-channel mask
+    if objmask.dtype != torch.float32 or objmask.device != disp.device:
+        raise RuntimeError("gt_depth_mse: color_objmask must be float32 on the disparity's device")
+    objdepth = _c(objdepth.reshape(-1))
+    if objdepth.numel() != B:
+        raise RuntimeError("gt_depth_mse: objdepth needs one distance per sample")
+    return disp, disp_gt, objmask, int(objmask.stride(0)), objdepth, B, H * W
+
+
+class _GtDepthMse(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, disp, disp_gt, objmask, objdepth, min_depth, max_depth):
+        lib = N.lib()
+        disp, disp_gt, objmask, bstride, objdepth, B, HW = _gt_depth_operands(disp, disp_gt, objmask, objdepth)
+        part = torch.empty(lib.dmh_sq_mean_partials_size(B * HW), device=disp.device, dtype=torch.float32)
+        cost = torch.empty((), device=disp.device, dtype=torch.float32)
+        N.check(lib.dmh_gt_depth_mse_fwd(N.ptr(disp), N.ptr(disp_gt), N.ptr(objmask), bstride, N.ptr(objdepth), B, HW,
+                                         float(min_depth), float(max_depth), N.ptr(part), N.ptr(cost), N.stream()))
+        ctx.save_for_backward(disp, disp_gt, objmask, objdepth)
+        ctx.geo = (bstride, B, HW, float(min_depth), float(max_depth))
+        return cost
+
+    @staticmethod
+    def backward(ctx, g):
+        disp, disp_gt, objmask, objdepth = ctx.saved_tensors
+        bstride, B, HW, min_depth, max_depth = ctx.geo
+        g_disp = torch.empty_like(disp)
+        N.check(N.lib().dmh_gt_depth_mse_bwd(N.ptr(disp), N.ptr(disp_gt), N.ptr(objmask), bstride, N.ptr(objdepth), B, HW,
+                                             min_depth, max_depth, N.ptr(_c(g.to(torch.float32))), N.ptr(g_disp), N.stream()))
+        return g_disp, None, None, None, None, None
+
+
+def gt_depth_mse(disp, disp_gt, objmask, objdepth, min_depth=0.1, max_depth=100.0):
+    """--gt_depth supervised term (MD2/trainer.py:551-557): MSELoss(gt_depth, pred_depth) with
+    pred / pseudo depth = clamp(disp_to_depth(.)[1] * 5.4, 1e-3, 80) and gt_depth = m objdepth + pseudo (1 - m), m = channel 0
+    of color_objmask.  One fused pass forward, one backward (gradient w.r.t. ``disp`` only: disp_gt is the frozen teacher's)."""
+    return _GtDepthMse.apply(disp, disp_gt.detach(), objmask, objdepth, min_depth, max_depth)
+
+
 def pgd_linf_step(x, x0, grad, alpha, eps, out=None):
     """x <- clamp(x0 + clamp(x + alpha*sign(grad) - x0, -eps, eps), 0, 1) (phy_obj_atk.py:98-101)."""
     x, x0, grad = _c(x.detach()), _c(x0), _c(grad)

@@ -77,8 +77,10 @@ class Trainer:
             raise NotImplementedError("pose networks (monocular frames -1/+1) are outside the hot-path scope; "
                                       "train with --frame_ids 0 --use_stereo as the paper's command does "
                                       "(reference README.md:87-91)")
-        if self.opt.gt_depth:
-            raise NotImplementedError("--gt_depth is not supported by the fused photometric kernel")
+        if self.opt.gt_depth and self.opt.adv_train and self.opt.supervised_adv and self.opt.half_no_synthesis:
+            # the reference fails later, with a KeyError on inputs[("color_objmask",0,0)]: --half_no_synthesis samples carry
+            # neither the object mask nor its distance (mono_dataset.py:248-250)
+            raise RuntimeError("--gt_depth needs the object mask and distance of every sample: drop --half_no_synthesis")
         # --avg_reprojection (MD2/trainer.py:593,617-621,636-639) replaces the min over the source frames by their mean;
         # with the one (stereo) source frame of this trainer the two are the same number and the fused kernel serves it;
         # over several source frames compute_losses takes the composed path (_losses_composed)
@@ -338,7 +340,11 @@ class Trainer:
             disp = outputs[("disp", 0)]
             with torch.no_grad():
                 disp_gt = self.gt_model(inputs[("color_ben", 0, 0)])
-            loss_sup = ops.masked_sq_mean(disp_gt - disp, None)     # MSELoss(disp_gt, disp), trainer.py:559
+            if self.opt.gt_depth:       # MD2/trainer.py:551-557: metric depths, the object's known distance under its mask
+                loss_sup = ops.gt_depth_mse(disp, disp_gt, inputs[("color_objmask", 0, 0)], inputs[("objdepth", 0, 0)],
+                                            self.opt.min_depth, self.opt.max_depth)
+            else:
+                loss_sup = ops.masked_sq_mean(disp_gt - disp, None)     # MSELoss(disp_gt, disp), trainer.py:559
             losses["sup_loss"] = loss_sup
             total_loss = total_loss + loss_sup
         if self.opt.adv_train and self.opt.contrastive_learning:

@@ -227,6 +227,21 @@ int dmh_masked_sq_mean_bwd(const float* disp, const float* mask, int64_t n, cons
                            void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * K6b --gt_depth supervised term (MD2/trainer.py:551-557, options.py:227-229): with
+ *     depth(d) = clamp(5.4 / (1/max_depth + (1/min_depth - 1/max_depth) d), 1e-3, 80)   (disp_to_depth, layers.py:16-25)
+ *     cost = mean_{b,hw} ( m objdepth[b] + depth(disp_gt) (1 - m) - depth(disp) )^2 ,   m = objmask[b * mask_bstride + hw]
+ *     disp, disp_gt: [B,1,H,W]; objmask: channel 0 of inputs[("color_objmask",0,0)] ([B,3,H,W]: mask_bstride = 3 H W);
+ *     objdepth: [B] metres.  partials: dmh_sq_mean_partials_size(B*HW) floats; cost: float[1].
+ *     bwd: g_disp = gscale[0] * d cost / d disp (0 where depth(disp) sits on a clamp bound, as torch.clamp does).
+ * ---------------------------------------------------------------------------------- */
+int dmh_gt_depth_mse_fwd(const float* disp, const float* disp_gt, const float* objmask, int64_t mask_bstride,
+                         const float* objdepth, int B, int64_t HW, float min_depth, float max_depth, float* partials,
+                         float* cost, void* stream);
+int dmh_gt_depth_mse_bwd(const float* disp, const float* disp_gt, const float* objmask, int64_t mask_bstride,
+                         const float* objdepth, int B, int64_t HW, float min_depth, float max_depth, const float* gscale,
+                         float* g_disp, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * K20 weight gradients of the pair of convolutions that opens a down-sampling ResNet block (K15's train-pass counterpart):
  *     dw3[K][C][3][3] of nn.Conv2d(C, K, 3, stride 2, padding 1) and dwd[K][C][1][1] of nn.Conv2d(C, K, 1, stride 2) on the
  *     same x[B,C,H,W], from g3 / gd [B,K,H/2,W/2] (gd and dwd may be NULL: the 3x3 filter only).  Pixel axis on the fp32 MFMA,

@@ -3,11 +3,11 @@
 Reference (under /root/reference/DepthNetworks/monodepth2):
   MonoDataset.prep_adv_data     datasets/mono_dataset.py:186-265
   SimSiam.forward               contrastive.py:62-93
-  sup_loss / contras_loss       trainer.py:546-577
+  sup_loss / contras_loss       trainer.py:546-577   (--gt_depth branch :551-557)
 
 Plain PyTorch on tensors (the PIL 8-bit round trip of to_pilimage/to_tensor is not restated; the fixture
 tests/golden/prep_adv_data.npz was produced with identity stand-ins for both).  Test infrastructure only (see
-oracle/__init__.py).  Pinned by tests/golden/{prep_adv_data,simsiam,addon_losses}.npz (oracle/make_goldens.py ran
+oracle/__init__.py).  Pinned by tests/golden/{prep_adv_data,simsiam,addon_losses,addon_gt_depth}.npz (oracle/make_goldens.py ran
 the reference functions themselves).
 """
 import numpy as np
@@ -73,3 +73,17 @@ def addon_losses(gt_model, simsiam, color_ben, disp0, feats_aug, feats_ben, cont
     sup = nn.MSELoss()(disp_gt, disp0)
     con = simsiam(feats_aug, feats_ben) * contras_wt
     return sup, con, sup + con
+
+
+def sup_loss_gt_depth(gt_model, color_ben, disp0, color_objmask, objdepth, min_depth=0.1, max_depth=100.0):
+    """trainer.py:548-557 with --gt_depth: metric depths (disp_to_depth, layers.py:16-25, x 5.4, clamped to [1e-3, 80]); under
+    the pasted object's mask the target is the object's known distance, elsewhere the frozen teacher's depth.
+    color_objmask [B,3,H,W], objdepth [B,1,1] as the collated dataset hands them over (mono_dataset.py:254-255)."""
+    def depth(d):
+        min_disp, max_disp = 1 / max_depth, 1 / min_depth
+        return torch.clamp(1 / (min_disp + (max_disp - min_disp) * d) * 5.4, 1e-3, 80)
+    with torch.no_grad():
+        disp_gt = gt_model(color_ben)
+    m = color_objmask[:, [0], :, :]
+    gt_depth = m * objdepth.unsqueeze(3) + depth(disp_gt) * (1 - m)
+    return nn.MSELoss()(gt_depth, depth(disp0))

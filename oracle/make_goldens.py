@@ -35,7 +35,7 @@ sys.path.insert(0, REPO)
 
 from oracle import tv082  # noqa: E402
 from oracle.synth import (TinyDepthNet, kitti_like, make_intrinsics, make_object, make_loss_case,  # noqa: E402
-                          KITTI_CALIB_TEXT)
+                          KITTI_CALIB_TEXT, gt_depth_case)
 
 
 # --------------------------------------------------------------------------- shims
@@ -458,6 +458,20 @@ def gold_sup_loss(trainer_mod, layers):
          g_feat_aug=feats_aug[0].grad)
 
 
+def gold_gt_depth(trainer_mod, layers):
+    """MD2/trainer.py:546-557 with --adv_train --supervised_adv --gt_depth --no_original_train: sup_loss on metric depths."""
+    color_ben, disp, mask, objdepth = gt_depth_case()
+    disp = disp.requires_grad_(True)
+    opt = SimpleNamespace(adv_train=True, supervised_adv=True, contrastive_learning=False, no_original_train=True,
+                          gt_depth=True, min_depth=0.1, max_depth=100.0)
+    self = SimpleNamespace(opt=opt, gt_model=TinyDepthNet(seed=5).eval(), sup_loss_creteria=nn.MSELoss(), models={})
+    inputs = {("color_ben", 0, 0): color_ben, ("color_objmask", 0, 0): mask, ("objdepth", 0, 0): objdepth}
+    losses = trainer_mod.Trainer.compute_losses(self, inputs, {("disp", 0): disp})
+    losses["loss"].backward()
+    save("addon_gt_depth", seed=np.array([63]), sup_loss=losses["sup_loss"].detach(), loss=losses["loss"].detach(),
+         g_disp=disp.grad, clamped_frac=np.array([float((disp.grad == 0).float().mean())]))
+
+
 def gold_compute_errors(evaluate_depth, layers):
     """MD2/evaluate_depth.py:57-99 both branches, fed through the depth conversion of :193-194."""
     g = torch.Generator().manual_seed(71)
@@ -552,6 +566,8 @@ def main():
     if want("addons"):
         gold_simsiam(contrastive)
         gold_sup_loss(md2_trainer, layers)
+    if want("addons") or want("gt_depth"):
+        gold_gt_depth(md2_trainer, layers)
     import evaluate_depth
     if want("errors"):
         gold_compute_errors(evaluate_depth, layers)

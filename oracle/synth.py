@@ -153,3 +153,20 @@ def options_case(B, H, W, seed, frames):
     masks = [torch.cat([smooth_field(B, H >> s, W >> s, g, 0.05, 0.95, k=max(3, 9 // 2 ** s) | 1) for _ in frames], 1).contiguous()
              for s in range(4)]
     return inputs, disps, poses, masks
+
+
+def gt_depth_case():
+    """Inputs of tests/golden/addon_gt_depth.npz (also regenerated by the tests from these seeds): disparities that reach
+    both clamp bounds of the metric depth (5.4 * depth > 80 for disp < 0.0058), a soft-edged object mask, one distance per
+    sample."""
+    B, H, W = 4, 32, 96
+    g = torch.Generator().manual_seed(63)
+    color_ben = kitti_like(B, 3, H, W, g)
+    disp = torch.rand(B, 1, H, W, generator=g) * 0.3 + 0.01
+    disp = torch.where(torch.rand(B, 1, H, W, generator=g) < 0.15, disp * 0.02, disp)      # far pixels: clamped to 80 m
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    cx = torch.tensor([30.0, 48.0, 60.0, 20.0]).view(B, 1, 1)
+    r = ((xx - cx) ** 2 / 18.0 ** 2 + (yy - 18.0) ** 2 / 9.0 ** 2).sqrt()
+    mask = (1.5 - r).clamp(0, 1).unsqueeze(1).expand(-1, 3, -1, -1).contiguous()            # bilinear-warped masks have soft edges
+    objdepth = torch.tensor([5.0, 7.4, 9.8, 6.2]).view(B, 1, 1)
+    return color_ben, disp, mask, objdepth

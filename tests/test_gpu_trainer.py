@@ -770,6 +770,43 @@ def test_addon_losses_match_reference_golden(tmp_path, golden):
     assert float((ga - gr).norm() / gr.norm()) < 1e-3, float((ga - gr).norm() / gr.norm())
 
 
+def test_gt_depth_sup_loss_matches_reference_golden(tmp_path, golden):
+    """--supervised_adv --gt_depth (MD2/trainer.py:551-557) through Trainer.compute_losses and the fused K6b kernel against the
+    number and the disparity gradient the reference's own compute_losses produced (tests/golden/addon_gt_depth.npz): 2e-5 on
+    the loss; the gradient element-wise 1e-4 relative with the SAME zero set (pixels whose metric depth sits on the 80 m clamp)."""
+    import numpy as np
+    from depthmodelhardening_amd import ops
+    from oracle.synth import TinyDepthNet, gt_depth_case
+    g = golden("addon_gt_depth")
+    tr = _trainer(tmp_path, ["--adv_train", "--supervised_adv", "--gt_depth", "--no_original_train"])
+    color_ben, disp, mask, objdepth = gt_depth_case()
+    tr.gt_model = TinyDepthNet(seed=5).cuda().eval()
+    d = disp.cuda().requires_grad_(True)
+    inputs = {("color_ben", 0, 0): color_ben.cuda(), ("color_objmask", 0, 0): mask.cuda(), ("objdepth", 0, 0): objdepth.cuda()}
+    losses = tr.compute_losses(inputs, {("disp", 0): d})
+    assert set(losses) == {"sup_loss", "loss"}
+    losses["loss"].backward()
+    ref = float(g["sup_loss"])
+    assert abs(float(losses["sup_loss"]) - ref) <= 2e-5 * abs(ref), (float(losses["sup_loss"]), ref)
+    g_ref = torch.from_numpy(np.asarray(g["g_disp"]))
+    got = d.grad.cpu()
+    assert torch.equal(got == 0, g_ref == 0), "clamped pixels differ"
+    err = (got - g_ref).abs()
+    assert bool((err <= 1e-4 * g_ref.abs() + 1e-7 * g_ref.abs().max()).all()), float((err / (g_ref.abs() + 1e-12)).max())
+    # the dataset's layout: a one-channel mask expanded to three (stride 0) and objdepth as [B,1] -- same numbers, no copy needed
+    m1 = mask[:, :1].contiguous().cuda()
+    d2 = disp.cuda().requires_grad_(True)
+    l2 = ops.gt_depth_mse(d2, tr.gt_model(color_ben.cuda()).detach(), m1.expand(-1, 3, -1, -1), objdepth.view(-1, 1).cuda())
+    l2.backward()
+    assert torch.equal(l2.detach(), losses["sup_loss"].detach()) and torch.equal(d2.grad, d.grad)
+    with pytest.raises(RuntimeError):
+        ops.gt_depth_mse(d2, d2.detach(), m1[:, :, :-1], objdepth.cuda())
+    # one whole training iteration with the flag on the synthetic dataset (color_objmask / objdepth supplied by next_batch)
+    tr2 = _trainer(tmp_path, ["--adv_train", "--supervised_adv", "--gt_depth", "--atk_steps", "1"])
+    out = tr2.train_step()
+    assert torch.isfinite(out["loss"]) and float(out["sup_loss"]) > 0
+
+
 def test_eval_mode_with_trainable_batchnorm_takes_the_module_path():
     """Fine-tuning with frozen statistics (encoder.eval(), grad on, outside frozen_weights()): BatchNorm weight / bias
     must receive their gradients exactly as nn.BatchNorm2d gives them; inside an attack scope the fused path is taken

@@ -262,6 +262,20 @@ def test_addon_losses(golden):
     torch.testing.assert_close(feats_aug[0].grad, t(g["g_feat_aug"]), rtol=1e-4, atol=1e-9)
 
 
+def test_gt_depth_sup_loss(golden):
+    """sup_loss of MD2/trainer.py:551-557 (--supervised_adv --gt_depth): metric depths, the object's distance under its mask."""
+    from oracle.dataset_ref import sup_loss_gt_depth
+    from oracle.synth import gt_depth_case
+    g = golden("addon_gt_depth")
+    color_ben, disp, mask, objdepth = gt_depth_case()
+    disp = disp.requires_grad_(True)
+    sup = sup_loss_gt_depth(TinyDepthNet(seed=5).eval(), color_ben, disp, mask, objdepth)
+    sup.backward()
+    torch.testing.assert_close(sup.detach(), t(g["sup_loss"]), rtol=1e-6, atol=0)
+    torch.testing.assert_close(disp.grad, t(g["g_disp"]), rtol=1e-5, atol=1e-9)
+    assert abs(float((disp.grad == 0).float().mean()) - float(g["clamped_frac"][0])) < 1e-9      # the clamp at 80 m bites
+
+
 def prep_case(side, do_flip):
     """Frames, patches and the (z0, alpha) draw of one tests/golden/prep_adv_data.npz case."""
     obj, mask = make_object()
