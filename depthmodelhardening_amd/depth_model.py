@@ -29,7 +29,8 @@ class DepthModelWrapper(torch.nn.Module):
         with ``clean`` (the same frames without the object: input_image equals it outside the plan's boxes) the encoder
         head's forward does too."""
         from . import ops
-        roi_dec = plan is not None and hasattr(self.decoder, "roi_ok")
+        # the decoder's static capability is asked BEFORE the encoder may hand back window-shaped features
+        roi_dec = plan is not None and hasattr(self.decoder, "roi_ok") and self.decoder.roi_static_ok(plan)
         if plan is not None:        # what THIS call's encoder does with the plan (a plan may be used for more than one call)
             plan.head_windowed = plan.f0_compact = False
         if roi_dec and getattr(self.encoder, "roi_backward", False):
@@ -39,7 +40,9 @@ class DepthModelWrapper(torch.nn.Module):
         if roi_dec and self.decoder.roi_ok(feats, plan):
             return self.decoder.masked_sq_mean(feats, mask, plan, tab)
         if plan is not None and (plan.head_windowed or plan.f0_compact):
-            raise RuntimeError("masked_sq_mean: the encoder ran its windowed head but the decoder cannot take the plan")
+            # the decoder turned the plan down on the features' sizes after all: the whole-frame path serves the call
+            plan.head_windowed = plan.f0_compact = False
+            feats = self.encoder(input_image)
         if feats[-1].is_cuda and hasattr(self.decoder, "_forward_fused"):
             disp = self.decoder(feats, only_scales=(0,))[("disp", 0)]
         else:
@@ -48,19 +51,31 @@ class DepthModelWrapper(torch.nn.Module):
 
 
 def import_depth_model(scene_size, model_type='monodepth2', pre_model_path=None):
-    """Build the Monodepth2 ResNet-18 depth model and load ``encoder.pth`` / ``depth.pth`` from
-    ``pre_model_path`` when given (depth_model.py:117-153 filters the encoder dict by key the same way).
-    Without weights on disk the model is randomly initialised (no network in this environment).
+    """Build the ResNet-18 depth model of ``model_type`` and load ``encoder.pth`` / ``depth.pth`` (depth_model.py:89-161, which
+    filters the encoder dict by key the same way).  'monodepth2' (``mono+stereo_1024x320``) and 'depthhints'
+    (``DH_MS_320_1024``, BASELINE config 4) are the same architecture -- DepthHints' networks/ is Monodepth2's -- and differ in
+    the weights folder only; 'manydepth' (cost-volume encoder) is outside the hot path.  The reference reads
+    ``DepthNetworks/<fork>/models/<name>``; here the folder is ``pre_model_path`` or ``$DMH_MODELS_DIR/<name>``; without
+    weights on disk the model is randomly initialised (no network in this environment).
 
     scene_size: (width, height)."""
-    if model_type != 'monodepth2':
-        raise RuntimeError("only the monodepth2 depth model is in scope, got %r" % (model_type,))
+    names = {'monodepth2': 'mono+stereo_1024x320', 'depthhints': 'DH_MS_320_1024'}
     if tuple(scene_size) not in ((1024, 320),):
         raise RuntimeError("scene size undefined!")
+    if model_type == 'manydepth':
+        raise RuntimeError("the manydepth depth model (cost-volume encoder) is outside the hot-path scope")
+    if model_type not in names:
+        raise RuntimeError("depth model unfound")
+    model_path = pre_model_path
+    if model_path is None and os.environ.get("DMH_MODELS_DIR"):
+        cand = os.path.join(os.environ["DMH_MODELS_DIR"], names[model_type])
+        model_path = cand if os.path.isdir(cand) else None
     encoder = networks.ResnetEncoder(18, False)
     decoder = networks.DepthDecoder(num_ch_enc=encoder.num_ch_enc, scales=range(4))
-    if pre_model_path is not None:
-        enc = torch.load(os.path.join(pre_model_path, "encoder.pth"), map_location="cpu")
+    if model_path is not None:
+        enc = torch.load(os.path.join(model_path, "encoder.pth"), map_location="cpu")
         encoder.load_state_dict({k: v for k, v in enc.items() if k in encoder.state_dict()})
-        decoder.load_state_dict(torch.load(os.path.join(pre_model_path, "depth.pth"), map_location="cpu"))
-    return DepthModelWrapper(encoder, decoder)
+        decoder.load_state_dict(torch.load(os.path.join(model_path, "depth.pth"), map_location="cpu"))
+    model = DepthModelWrapper(encoder, decoder)
+    model.model_type, model.model_name = model_type, names[model_type]
+    return model

@@ -60,14 +60,19 @@ class DepthDecoder(nn.Module):
                 self.outputs[("disp", i)] = self.sigmoid(conv(self.convs[("dispconv", i)], p))
         return self.outputs
 
+    def roi_static_ok(self, plan):
+        """What can be said about ``roi_ok`` before any feature exists (asked by DepthModelWrapper BEFORE the encoder is allowed
+        to run its windowed head: a decoder that cannot take the plan must be handed whole-frame features)."""
+        return bool(self.use_skips and self.upsample_mode == 'nearest' and 0 in self.scales and self.num_output_channels == 1
+                    and plan.depth in (2, 3, 4))
+
     def roi_ok(self, input_features, plan):
         """The attack's windowed cost (ops.roi_tail_cost) applies to these features under ``plan`` (roi.RoiPlan): the fused
         CUDA path, scale 0 among the heads, the reference's channel plan, the frame sizes of a five-level pyramid (feature 0
         may be its compact "hz" window: plan.f0_compact)."""
         from .. import ops
         depth = plan.depth
-        if not (input_features[-1].is_cuda and self.use_skips and self.upsample_mode == 'nearest' and 0 in self.scales
-                and len(input_features) == 5 and self.num_output_channels == 1 and depth in (2, 3, 4)):
+        if not (input_features[-1].is_cuda and len(input_features) == 5 and self.roi_static_ok(plan)):
             return False
         h1, w1 = plan.H >> 2, plan.W >> 2
         if any(tuple(f.shape[2:]) != (h1 >> (k - 1), w1 >> (k - 1)) for k, f in enumerate(input_features) if k >= 1):

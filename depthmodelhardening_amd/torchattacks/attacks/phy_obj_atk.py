@@ -49,6 +49,7 @@ class Phy_obj_atk(Attack):
         self._targeted = True
         self.scene_size = [320, 1024]
         self.random_start_noise = None  # test hook: a tensor here replaces the uniform_(-eps, eps) draw
+        self.trace = None       # test hook: set to a list to record (cost, patch gradient) of every step
         # (z0, alpha) are drawn WITHOUT replacement from 25 distances / 13 angles (physicalTrans.py:150,155), so the
         # reference raises ValueError beyond 13 scenes.  pose_group = g (<= 13) lifts that for larger batches: every run
         # of g consecutive scenes gets its own draw without replacement (physical_adv_training at batch 32: 13 + 13 + 6).
@@ -157,6 +158,8 @@ class Phy_obj_atk(Attack):
             grad = torch.autograd.grad(cost, obj_img_adv, retain_graph=False, create_graph=False)[0]
             if mine is not None:        # 0.94 MB: the one exchange of the shared-patch attack, before the sign
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+            if self.trace is not None:
+                self.trace.append((float(cost), grad.detach().clone()))
             obj_img_adv = ops.pgd_linf_step(obj_img_adv, self.obj_img, grad, self.alpha, self.eps)
 
         self.phy_trans_adv.reset_img(obj_img_adv, self.obj_mask)

@@ -168,6 +168,7 @@ class Trainer:
         # the fused loss derives the pixel grid on chip, so those ~170 MB of device buffers (B=32) are not allocated.
         # compute_reprojection_loss (stand-alone surface) builds its SSIM lazily.
         self._ssim = None
+        self.tie_break_noise = None     # test hook: four [B,1,H,W] tensors (already x 1e-5) instead of the in-kernel Philox draw
         self.timings = {}
         self.val_eval_count = 10   # evaluate_attacks(..., eval_count=10), MD2/trainer.py:465
         if self.rank == 0:
@@ -371,7 +372,7 @@ class Trainer:
             [outputs[("disp", s)] for s in self.opt.scales], [inputs[("color", 0, s)] for s in self.opt.scales],
             min_depth=self.opt.min_depth, max_depth=self.opt.max_depth, variant=self.opt.loss_variant,
             automask=not self.opt.disable_automasking, no_ssim=self.opt.no_ssim,
-            smooth_wt=self.opt.disparity_smoothness, noise="philox",
+            smooth_wt=self.opt.disparity_smoothness, noise="philox" if self.tie_break_noise is None else self.tie_break_noise,
             depth_hint=inputs["depth_hint"] if self.opt.use_depth_hints else None,
             depth_hint_mask=inputs["depth_hint_mask"] if self.opt.use_depth_hints else None)
         for i, scale in enumerate(self.opt.scales):

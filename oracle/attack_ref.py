@@ -125,10 +125,10 @@ def paste(scene_imgs, trans, batch_size, z0_sample=None, alpha_sample=None):
 
 def phy_obj_atk(model, obj_img, obj_mask, images, batch_size, eps=0.3, alpha=2 / 255, steps=40,
                 random_start=True, dist_range=None, eval=False, P2=KITTI_P2, start_noise=None, record=None,
-                draws=None, final_draw=None):
+                draws=None, final_draw=None, trace=None):
     """Phy_obj_atk.forward (phy_obj_atk.py:59-123) wrapped as Attack.__call__ does
     (attack.py:296-312: model.eval() during the attack, train mode restored).
-    ``record``: optional list that receives the patch after every step.
+    ``record``: optional list that receives the patch after every step; ``trace``: one that receives (cost, patch gradient).
     ``draws`` / ``final_draw``: explicit (z0_sample, alpha_sample) per step / for the returned scenes, handed to
     project() through its own z0_sample / alpha_sample arguments (physicalTrans.py:130,146-155) instead of its
     ``random.sample`` -- used for batches beyond the 13 poses one draw without replacement can give."""
@@ -151,6 +151,8 @@ def phy_obj_atk(model, obj_img, obj_mask, images, batch_size, eps=0.3, alpha=2 /
         adv_scenes, masks, _, _, _ = paste(scene_imgs, trans_adv, batch_size, z0_i, al_i)
         cost = -loss(model(adv_scenes) * masks, target)
         grad = torch.autograd.grad(cost, adv, retain_graph=False, create_graph=False)[0]
+        if trace is not None:
+            trace.append((float(cost), grad.detach().clone()))
         with torch.no_grad():
             adv = adv + alpha * grad.sign()
             delta = torch.clamp(adv - obj_img, min=-eps, max=eps)

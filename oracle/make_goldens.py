@@ -35,7 +35,7 @@ sys.path.insert(0, REPO)
 
 from oracle import tv082  # noqa: E402
 from oracle.synth import (TinyDepthNet, kitti_like, make_intrinsics, make_object, make_loss_case,  # noqa: E402
-                          KITTI_CALIB_TEXT, gt_depth_case)
+                          KITTI_CALIB_TEXT, gt_depth_case, decoder_case)
 
 
 # --------------------------------------------------------------------------- shims
@@ -472,6 +472,28 @@ def gold_gt_depth(trainer_mod, layers):
          g_disp=disp.grad, clamped_frac=np.array([float((disp.grad == 0).float().mean())]))
 
 
+def gold_unet_decoder(networks):
+    """MD2/networks/depth_decoder.py:17-65 -- the reference's own DepthDecoder (with layers.ConvBlock / Conv3x3 / upsample) on
+    seeded features: the four disparities, the feature gradients of a weighted sum, and per-parameter checksums of the
+    seeded initial weights and of their gradients.  Pins oracle/unet_ref.DepthDecoderRef (same seed -> same weights)."""
+    torch.manual_seed(71)
+    dec = networks.DepthDecoder(np.array([64, 64, 128, 256, 512]))
+    feats, wts = decoder_case()
+    feats = [f.requires_grad_(True) for f in feats]
+    out = dec(feats)
+    total = sum((out[("disp", s)] * wts[s]).sum() for s in range(4))
+    total.backward()
+    names = [n for n, _ in dec.named_parameters()]
+    keep = {"seeds": np.array([71, 72]), "total": total.detach(), "param_names": np.array(names),
+            "param_abssum": np.array([float(p.detach().double().abs().sum()) for _, p in dec.named_parameters()]),
+            "param_grad_abssum": np.array([float(p.grad.double().abs().sum()) for _, p in dec.named_parameters()])}
+    for s in range(4):
+        keep["disp_%d" % s] = out[("disp", s)].detach()
+    for k, f in enumerate(feats):
+        keep["g_feat_%d" % k] = f.grad[:, ::8, ::2, ::2] if k < 2 else f.grad[:, ::8]
+    save("unet_decoder", **keep)
+
+
 def gold_compute_errors(evaluate_depth, layers):
     """MD2/evaluate_depth.py:57-99 both branches, fed through the depth conversion of :193-194."""
     g = torch.Generator().manual_seed(71)
@@ -568,6 +590,9 @@ def main():
         gold_sup_loss(md2_trainer, layers)
     if want("addons") or want("gt_depth"):
         gold_gt_depth(md2_trainer, layers)
+    if want("unet"):
+        import networks as md2_networks        # resnet_encoder.py's torchvision import meets the stand-in; only the decoder runs
+        gold_unet_decoder(md2_networks)
     import evaluate_depth
     if want("errors"):
         gold_compute_errors(evaluate_depth, layers)

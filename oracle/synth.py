@@ -170,3 +170,13 @@ def gt_depth_case():
     mask = (1.5 - r).clamp(0, 1).unsqueeze(1).expand(-1, 3, -1, -1).contiguous()            # bilinear-warped masks have soft edges
     objdepth = torch.tensor([5.0, 7.4, 9.8, 6.2]).view(B, 1, 1)
     return color_ben, disp, mask, objdepth
+
+
+def decoder_case(seed=72, B=2, H=64, W=192):
+    """Inputs of tests/golden/unet_decoder.npz: five encoder-shaped feature maps of a H x W frame and one weight map per
+    disparity scale (the scalar sum_s <disp_s, w_s> is differentiated)."""
+    g = torch.Generator().manual_seed(seed)
+    ch = [64, 64, 128, 256, 512]
+    feats = [torch.rand(B, c, H >> (k + 1), W >> (k + 1), generator=g) * 2 - 0.5 for k, c in enumerate(ch)]
+    wts = [torch.rand(B, 1, H >> s, W >> s, generator=g) - 0.3 for s in range(4)]
+    return feats, wts

@@ -27,18 +27,21 @@ def make_train_inputs(B, H, W, seed):
     return inputs
 
 
-def train_step(encoder, decoder, optimizer, inputs):
-    """process_batch + compute_losses + backward + step, on the CPU."""
+def train_step(encoder, decoder, optimizer, inputs, noise="randn", variant="md2", full=False):
+    """process_batch + compute_losses + backward + step, on the CPU.  ``noise``: "randn" draws the tie-break noise as the
+    reference does (trainer.py:644-645), None switches it off, a dict {scale: tensor} passes it in (already x 1e-5).
+    Returns the total loss, or with ``full`` the whole losses dict (gradients stay on the parameters)."""
     feats = encoder(inputs[("color_aug", 0, 0)])
     outputs = decoder(feats)
     loss_ref.generate_images_pred(inputs, outputs)
     B, _, H, W = inputs[("color", 0, 0)].shape
-    noise = {s: torch.randn(B, 1, H, W) * 0.00001 for s in range(4)}
-    losses, _ = loss_ref.compute_losses(inputs, outputs, noise=noise)
+    if isinstance(noise, str):
+        noise = {s: torch.randn(B, 1, H, W) * 0.00001 for s in range(4)}
+    losses, _ = loss_ref.compute_losses(inputs, outputs, noise=noise, variant=variant)
     optimizer.zero_grad()
     losses["loss"].backward()
     optimizer.step()
-    return losses["loss"].detach()
+    return {k: v.detach() for k, v in losses.items()} if full else losses["loss"].detach()
 
 
 def timed_iteration(model, B_train, Ba, atk_steps, H=320, W=1024, seed=1234, threads=None):

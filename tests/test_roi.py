@@ -302,6 +302,47 @@ def test_attack_with_windows_equals_attack_without():
 
 
 @pytest.mark.gpu
+def test_l0_attack_with_windows_equals_attack_without():
+    """BASELINE config 3's timed path: Phy_obj_atk_l0 takes the same windowed cost (phy_obj_atk_l0.py:118-127 through
+    DepthModelWrapper.masked_sq_mean).  use_roi on / off: the same per-iteration trace, the same pattern gradients handed to
+    Adam in every iteration, the same patterns and patch afterwards."""
+    import random
+
+    from depthmodelhardening_amd.torchattacks import Phy_obj_atk_l0
+    from oracle import synth
+    dev = torch.device("cuda")
+    model = _unet(dev, seed=4)
+    obj, pmask = synth.make_object()
+    scenes = synth.kitti_like(12, 3, 375, 1242, torch.Generator().manual_seed(18)).to(dev)
+    out = []
+    for use_roi in (False, True):
+        atk = Phy_obj_atk_l0(model, obj.to(dev), pmask.to(dev), adam_lr=0.5, steps=3, mask_wt=0.06, l0_thresh=0.1,
+                             dist_range=list(np.arange(5, 10, 0.2)))
+        atk.use_roi = use_roi
+        atk.trace, atk.grad_trace = [], []
+        random.seed(13)
+        np.random.seed(13)
+        adv, ben, m, patch = atk(scenes, 12)
+        out.append((atk.trace, atk.grad_trace, atk.pattern_pos_tensor.detach().cpu(), atk.pattern_neg_tensor.detach().cpu(),
+                    patch.cpu(), m.cpu()))
+    (t0, g0, pp0, pn0, pa0, m0), (t1, g1, pp1, pn1, pa1, m1) = out
+    assert len(t0) == len(t1) >= 3
+    assert torch.equal(m0, m1)
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(t0, t1)):
+        assert a[0] == b[0] and a[1] == b[1], (i, a, b)                         # L0 count, mask weight
+        assert abs(a[2] - b[2]) <= 1e-6 * abs(a[2]) and a[3] == b[3], (i, a, b)  # adversarial cost, mask cost
+    for i, ((gp0, gn0), (gp1, gn1)) in enumerate(zip(g0, g1)):
+        for x, y in ((gp0, gp1), (gn0, gn1)):
+            worst = max(worst, float((x - y).double().norm() / x.double().norm()))
+    print("L0 attack, windows on vs off: pattern gradients rel-L2 <= %.3g over %d iterations" % (worst, len(g0)))
+    assert worst <= 2e-6
+    # Adam(lr = 0.5) turns the sign of a ~0 gradient into a step of 0.5: identical except on such texels
+    for x, y in ((pp0, pp1), (pn0, pn1), (pa0, pa1)):
+        assert ((x - y).abs() <= 1e-6).float().mean().item() > 0.999
+
+
+@pytest.mark.gpu
 def test_windowed_encoder_head_gradient_equals_the_full_one_inside_the_window():
     """ops.encoder_head_eval: features identical to the separate nodes; d / d image identical inside the plan's image
     window for an upstream gradient that is dense on feature 1 and lives inside "r_f0" on feature 0, zero outside it."""
