@@ -434,8 +434,8 @@ def _gt_depth_operands(disp, disp_gt, objmask, objdepth):
         raise RuntimeError("gt_depth_mse: color_objmask must be [B,C,H,W] at the disparity's size")
     if objmask.stride(3) != 1 or objmask.stride(2) != W or objmask.stride(0) < H * W:
         objmask = objmask[:, :1].contiguous()      # e.g. the dataset's expand(-1, 3, -1, -1) view of a one-channel mask
-    if objmask.dtype != torch.float32 or objmask.device != disp.device:
-        raise RuntimeError("gt_depth_mse: color_objmask must be float32 on the disparity's device")
+    if objmask.dtype != torch.float32 or objmask.device != disp.device or not objmask.is_cuda:
+        raise RuntimeError("gt_depth_mse: color_objmask must be float32 on the disparity's (ROCm) device")
     objdepth = _c(objdepth.reshape(-1))
     if objdepth.numel() != B:
         raise RuntimeError("gt_depth_mse: objdepth needs one distance per sample")
@@ -449,7 +449,8 @@ class _GtDepthMse(torch.autograd.Function):
         disp, disp_gt, objmask, bstride, objdepth, B, HW = _gt_depth_operands(disp, disp_gt, objmask, objdepth)
         part = torch.empty(lib.dmh_sq_mean_partials_size(B * HW), device=disp.device, dtype=torch.float32)
         cost = torch.empty((), device=disp.device, dtype=torch.float32)
-        N.check(lib.dmh_gt_depth_mse_fwd(N.ptr(disp), N.ptr(disp_gt), N.ptr(objmask), bstride, N.ptr(objdepth), B, HW,
+        # channel 0 of the mask is read in place through its batch stride (layout validated by _gt_depth_operands)
+        N.check(lib.dmh_gt_depth_mse_fwd(N.ptr(disp), N.ptr(disp_gt), C.c_void_p(objmask.data_ptr()), bstride, N.ptr(objdepth), B, HW,
                                          float(min_depth), float(max_depth), N.ptr(part), N.ptr(cost), N.stream()))
         ctx.save_for_backward(disp, disp_gt, objmask, objdepth)
         ctx.geo = (bstride, B, HW, float(min_depth), float(max_depth))
@@ -460,7 +461,7 @@ class _GtDepthMse(torch.autograd.Function):
         disp, disp_gt, objmask, objdepth = ctx.saved_tensors
         bstride, B, HW, min_depth, max_depth = ctx.geo
         g_disp = torch.empty_like(disp)
-        N.check(N.lib().dmh_gt_depth_mse_bwd(N.ptr(disp), N.ptr(disp_gt), N.ptr(objmask), bstride, N.ptr(objdepth), B, HW,
+        N.check(N.lib().dmh_gt_depth_mse_bwd(N.ptr(disp), N.ptr(disp_gt), C.c_void_p(objmask.data_ptr()), bstride, N.ptr(objdepth), B, HW,
                                              min_depth, max_depth, N.ptr(_c(g.to(torch.float32))), N.ptr(g_disp), N.stream()))
         return g_disp, None, None, None, None, None
 

@@ -210,8 +210,13 @@ def _run_loss(trainer_mod, layers, case, noise, variant, use_depth_hints=False, 
     return res
 
 
-def gold_losses(trainer_mod, layers, tag):
-    for name, (B, H, W, seed) in {"small": (2, 32, 96, 21), "cfg1": (2, 192, 640, 22)}.items():
+def gold_losses(trainer_mod, layers, tag, only=None):
+    shapes = {"small": (2, 32, 96, 21), "cfg1": (2, 192, 640, 22)}
+    if tag == "md2":
+        shapes["hd"] = (2, 320, 1024, 23)       # the headline resolution (BASELINE configs 2-5)
+    for name, (B, H, W, seed) in shapes.items():
+        if only is not None and name not in only:
+            continue
         case = make_loss_case(B, H, W, seed)
         g = torch.Generator().manual_seed(seed + 100)
         nshape = (B, 1, H, W)
@@ -220,7 +225,7 @@ def gold_losses(trainer_mod, layers, tag):
         res1 = _run_loss(trainer_mod, layers, case, noise, tag)
         keep = {"shape": np.array([B, H, W, seed])}
         # inputs are regenerated from the seed by oracle.synth.make_loss_case; only outputs are stored
-        big = name != "small"
+        big, hd = name != "small", name == "hd"
         for k, v in res0.items():
             if big and (k.startswith("warped") or k.startswith("sample") or k.startswith("depth")):
                 continue
@@ -228,11 +233,14 @@ def gold_losses(trainer_mod, layers, tag):
         for k, v in res1.items():
             if k.startswith("warped") or k.startswith("sample") or k.startswith("depth"):
                 continue
+            if hd and not k.startswith("loss"):     # 320 x 1024: the noise run keeps its loss values only (file size)
+                continue
             keep["noise_" + k] = v
         for k in list(keep):
             if "identity_selection" in k:      # 0/1 maps: store as bits
                 keep[k] = np.packbits(keep[k].numpy().astype(np.uint8))
-            elif big and k.endswith("grad_disp_0"):   # every 3rd row/col + exact double sums
+            elif big and (k.endswith("grad_disp_0") or (hd and "grad_disp_" in k and not k.endswith("_3"))):
+                # every 3rd row/col + exact double sums
                 g0 = keep.pop(k)
                 keep[k + "_sub3"] = g0[:, :, ::3, ::3]
                 keep[k + "_sum"] = g0.double().sum((1, 2, 3))
@@ -574,6 +582,8 @@ def main():
     import trainer as md2_trainer
     if want("losses"):
         gold_losses(md2_trainer, layers, "md2")
+    elif want("hd"):
+        gold_losses(md2_trainer, layers, "md2", only=("hd",))
     if want("v1ms"):
         gold_v1_multiscale(md2_trainer, layers)
     if want("options"):

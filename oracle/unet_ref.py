@@ -197,8 +197,9 @@ def randomize_batchnorm(model, seed):
                 m.bias.copy_((torch.rand(c, generator=g) - 0.5) * 0.2)
 
 
-def set_relu_margins(model, images=None, k=8.0, seed=0):
-    """Give every ReLU of the encoder a margin: no pre-activation within ~k - 5 standard deviations of zero.
+def set_relu_margins(model, images=None, k=16.0, seed=0):
+    """Give every ReLU of the encoder a margin: no pre-activation within ~k - 8 standard deviations of zero (convolution
+    outputs at object edges reach 8 sigma on KITTI-like frames: k = 8 leaves margins of 1e-5, k = 16 of 0.2).
 
     Why: the gradient of the attack cost is discontinuous in the ReLU masks, and an fp32 implementation flips the mask of a
     unit whose pre-activation is ~1e-5 of its scale.  ONE such flip changes the image gradient by 1e-5 ... 1e-3 of its norm

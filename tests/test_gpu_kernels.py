@@ -126,10 +126,14 @@ def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
     pool.check("%s %s noise=%s" % (variant, shape, with_noise))
 
 
-def test_photo_loss_golden_cfg1(golden):
-    """HIP path against the reference's own numbers (tests/golden, BASELINE config-1 shape)."""
+@pytest.mark.parametrize("name", ["loss_md2_cfg1", "loss_md2_hd"])
+def test_photo_loss_golden_cfg1(golden, name):
+    """HIP path against the reference's own numbers (tests/golden): BASELINE config-1 shape 2 x 192 x 640, and ``hd`` =
+    2 x 320 x 1024, the resolution of configs 2-5 -- K1's 62 / 60-column strips and 16 / 32-row strips tile it differently,
+    and the fp32 coordinate noise the tolerance model rests on grows with x (the hd fixture keeps gradients of its noise-free
+    run only)."""
     N, ops, loss_ref, _, synth, _ = _mods()
-    g = golden("loss_md2_cfg1")
+    g = golden(name)
     B, H, W, seed = [int(v) for v in g["shape"]]
     inputs, disps = synth.make_loss_case(B, H, W, seed)
     gen = torch.Generator().manual_seed(seed + 100)
@@ -149,6 +153,8 @@ def test_photo_loss_golden_cfg1(golden):
         for s in range(4):
             ref = float(g["%s_loss_%d" % (tag, s)])
             assert abs(f[N.FIN_LOSS_S + s].item() - ref) <= 2e-5 * abs(ref)
+            if "%s_identity_selection_%d" % (tag, s) not in g.files:
+                continue
             sel = np.unpackbits(g["%s_identity_selection_%d" % (tag, s)])[:B * H * W].reshape(B, H, W)
             assert (out.sel[s].cpu().numpy() != sel).mean() <= 5e-4   # fp32 near-ties only
             # gradients: the golden is an fp32 run of the reference; both it and the HIP result are measured against
@@ -163,11 +169,24 @@ def test_photo_loss_golden_cfg1(golden):
                 got = d_disps[s].grad.double().abs().sum((1, 2, 3)).cpu()
                 torch.testing.assert_close(got, np_t(g[key + "_abssum"]), rtol=5e-3, atol=0)
             e_h, e_r = rel_l2(got_g, a64), rel_l2(ref_g, a64)
-            assert e_h <= 1.5 * e_r + 1e-6, (key, e_h, e_r)
-            tol_abs = 1e-4 * a64.abs().max().item()
-            n_h = int(((got_g - a64).abs() > tol_abs + 1e-4 * a64.abs()).sum())
-            n_r = int(((ref_g - a64).abs() > tol_abs + 1e-4 * a64.abs()).sum())
+            tol_el = 1e-4 * a64.abs().max().item() + 1e-4 * a64.abs()
+            n_h = int(((got_g - a64).abs() > tol_el).sum())
+            n_r = int(((ref_g - a64).abs() > tol_el).sum())
             assert n_h <= 1.5 * n_r + 1e-3 * a64.numel(), (key, n_h, n_r)
+            # systematic accuracy, absolute: on the elements HIP has within tolerance (all but the n_h counted above) it
+            # agrees with float64 to 5e-5 in rel-L2 (measured 4e-6 at scale 0 ... 2e-5 at scale 3)
+            core = (got_g - a64).abs() <= tol_el
+            e_core = float((got_g - a64)[core].norm() / a64[core].norm())
+            print("%s %s: vs fp64 rel-L2 hip %.3g reference %.3g | beyond tolerance hip %d reference %d of %d | HIP on its "
+                  "in-tolerance elements %.3g" % (name, key, e_h, e_r, n_h, n_r, a64.numel(), e_core))
+            assert e_core <= 5e-5, (key, e_core)
+            if name == "loss_md2_cfg1":
+                assert e_h <= 1.5 * e_r + 1e-6, (key, e_h, e_r)
+            # at 320 x 1024 ONE pixel decides the untrimmed rel-L2 of a single case: (b 1, y 294, x 567) of this fixture has
+            # its sample 4.6e-6 px from a texel boundary in float64 (an fp32 coordinate at x = 567 resolves 6e-5, HIP's
+            # pixel + delta form ~2e-6) and carries 99 % of HIP's squared error, while the reference's fp32 run flips 94
+            # other elements (tools/diag_grad_outliers.py 2 320 1024 23); the pooled form of the rel-L2 bound is
+            # test_gradients_within_fp32_conditioning_of_the_fp64_oracle at this shape (three seeds, all elements)
 
 
 def _general_pose(B, seed):
