@@ -1,6 +1,8 @@
 // Shared host/device helpers for libdmh_hip.so (gfx950 only; wave = 64).
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -129,6 +131,21 @@ __device__ __forceinline__ float2 normal_pair_from_bits(uint32_t u0, uint32_t u1
     float sn, cs;
     __sincosf(6.283185307179586f * b, &sn, &cs);
     return make_float2(rad * cs, rad * sn);
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives a second GPU (or
+// launches from two threads) must not inherit a per-process "already configured" flag.  One bit per device ordinal, set
+// with release order after the attribute call succeeded; devices beyond 63 configure on every launch (cheap, correct).
+template <typename Kernel>
+inline hipError_t configure_dynamic_lds(Kernel kernel, size_t bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return hipSuccess;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess && bit) done.fetch_or(bit, std::memory_order_release);
+    return e;
 }
 
 }  // namespace dmh

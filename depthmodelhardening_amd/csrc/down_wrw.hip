@@ -195,13 +195,9 @@ int dmh_down_wrw(const float* x, const float* g3, const float* gd, int B, int C,
     const int pairs = (K / 64) * (C / 64);
     a.S = slices_for(pairs, a.ntiles);
     constexpr size_t smem = (size_t)(64 * XP + 2 * 64 * GP) * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(down_wrw_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_down_wrw");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
+    if (configure_dynamic_lds(down_wrw_kernel, smem, configured) != hipSuccess)
+        return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_down_wrw");
     hipLaunchKernelGGL(down_wrw_kernel, dim3((unsigned)(pairs * a.S)), dim3(NT), smem, (hipStream_t)stream, a);
     hipLaunchKernelGGL(down_wrw_reduce_kernel, dim3((unsigned)(((int64_t)K * C * 10 + NT - 1) / NT)), dim3(NT), 0,
                        (hipStream_t)stream, workspace, K, C, a.S, dw3, gd ? dwd : nullptr);

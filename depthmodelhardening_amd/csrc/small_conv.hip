@@ -160,13 +160,9 @@ int launch(SArgs& a, hipStream_t st) {
     constexpr int RH = TH + 2, RWA = 4 * ((TW + 2 + 6) / 4);
     constexpr int CS = ((RH * RWA + 15) / 32) * 32 + 16;
     constexpr size_t smem = (size_t)4 * NQ * CS * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_conv_kernel<NQ, NKB, TH>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_conv3x3_small");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
+    if (configure_dynamic_lds(small_conv_kernel<NQ, NKB, TH>, smem, configured) != hipSuccess)
+        return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_conv3x3_small");
     a.gx = (a.Wo + TW - 1) / TW;
     a.gy = (a.Ho + TH - 1) / TH;
     const long long blocks = (long long)a.B * a.gx * a.gy;

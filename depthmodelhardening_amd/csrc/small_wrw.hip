@@ -211,13 +211,9 @@ template <int NCB, int TR>
 int launch(WArgs& a, float* g_w, float* g_b, hipStream_t st) {
     using G = Geo<NCB, TR>;
     constexpr size_t smem = (size_t)G::LDS_FLOATS * sizeof(float);
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(small_wrw_kernel<NCB, TR>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_conv3x3_small_wrw");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
+    if (configure_dynamic_lds(small_wrw_kernel<NCB, TR>, smem, configured) != hipSuccess)
+        return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_conv3x3_small_wrw");
     a.tx = (a.Wo + TW - 1) / TW;
     a.ty = (a.Ho + TR - 1) / TR;
     const long long tiles = (long long)a.B * a.tx * a.ty;

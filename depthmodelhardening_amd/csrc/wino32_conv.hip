@@ -380,13 +380,9 @@ int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B,
     DMH_REQUIRE(items < ((int64_t)1 << 30), "too many work items");
     a.nitems = (int)items;
     constexpr size_t smem = (size_t)(2 * UBUF + VBUF) * 16 + (size_t)2 * RAW_BUF * 4;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino32_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino32_conv3x3");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
+    if (configure_dynamic_lds(wino32_conv_kernel, smem, configured) != hipSuccess)
+        return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino32_conv3x3");
     const int grid = a.nitems < num_cus() ? a.nitems : num_cus();
     hipLaunchKernelGGL(wino32_conv_kernel, dim3((unsigned)grid), dim3(NT), smem, (hipStream_t)stream, a);
     return check_launch("dmh_wino32_conv3x3");

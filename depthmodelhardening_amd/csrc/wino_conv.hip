@@ -535,13 +535,9 @@ int launch(WArgs& a, hipStream_t st) {
     // U and V images (double-buffered, 128 KB) + the raw input region(s): see FLAT in the kernel
     constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);     // 16-byte words, see the kernel
     constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_conv_kernel<TRW, FLAT, EPI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
+    if (configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, EPI>, smem, configured) != hipSuccess)
+        return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
     // persistent: one workgroup per CU (its 154 KB of LDS and 512 registers per lane fill the CU), each walking a
     // contiguous range of work items
     // DMH_K10_RESERVE_CUS=n leaves n CUs without a K10 workgroup: a contingency for multi-GPU runs, where RCCL's kernels

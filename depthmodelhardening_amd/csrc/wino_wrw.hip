@@ -408,13 +408,9 @@ void plan(RArgs& a, int kch, int cch) {
 template <int KS, int CS>
 int launch(const RArgs& a, hipStream_t st) {
     constexpr size_t smem = Cfg<KS, CS>::SMEM;
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wrw_kernel<KS, CS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)smem) != hipSuccess)
-            return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_wrw");
-        configured = true;
-    }
+    static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
+    if (configure_dynamic_lds(wino_wrw_kernel<KS, CS>, smem, configured) != hipSuccess)
+        return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_wrw");
     hipLaunchKernelGGL((wino_wrw_kernel<KS, CS>), dim3((unsigned)(a.nk * a.nc * a.S)), dim3(NT), smem, st, a);
     return check_launch("dmh_wino_wrw");
 }

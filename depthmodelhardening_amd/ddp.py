@@ -9,6 +9,7 @@ is placed AFTER the next iteration's attack has been enqueued, so the collective
 xGMI is point-to-point (7 links x ~153 GB/s): a ring moves 2*(N-1)/N * 57.3 MB per GPU ~ 0.65 ms at
 N=8 -- latency-, not bandwidth-bound, hence one bucket rather than many.
 """
+import contextlib
 import os
 
 import torch
@@ -49,13 +50,18 @@ def shorten_timeout(minutes=None):
     import datetime
     minutes = int(os.environ.get("DMH_DIST_STEADY_TIMEOUT_MIN", "10")) if minutes is None else minutes
     setter = getattr(torch.distributed.distributed_c10d, "_set_pg_timeout", None)
-    if setter is None:
-        return False
-    try:
-        setter(datetime.timedelta(minutes=minutes), dist.group.WORLD)
-        return True
-    except Exception:
-        return False
+    why = "this torch build has no distributed_c10d._set_pg_timeout"
+    if setter is not None:
+        try:
+            setter(datetime.timedelta(minutes=minutes), dist.group.WORLD)
+            return True
+        except Exception as e:      # a private API: say so instead of silently keeping the start-up timeout
+            why = "%s: %s" % (type(e).__name__, e)
+    if dist.get_rank() == 0:
+        import sys
+        print("[ddp] note: the process group keeps its start-up timeout (a stuck rank fails the job later than %d min): %s"
+              % (minutes, why), file=sys.stderr, flush=True)
+    return False
 
 
 class GradBucket(object):
@@ -130,6 +136,17 @@ class GradBucket(object):
             torch._foreach_copy_(dsts, grads)
         for p, v in zip(self.params, views):
             p.grad = v
+
+    @contextlib.contextmanager
+    def released(self):
+        """``with bucket.released(): loss.backward()`` -- release() before, collect() after, and collect() ALSO when backward
+        raises: otherwise every ``.grad`` stays detached and the next zero() / check_attached() fails with a message about
+        zero_grad(set_to_none=True) that hides the real error."""
+        self.release()
+        try:
+            yield self
+        finally:
+            self.collect()
 
     def start_all_reduce(self):
         """Enqueue sum-all-reduce + 1/N of the bucket; returns immediately."""

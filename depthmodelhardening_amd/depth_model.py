@@ -33,6 +33,7 @@ class DepthModelWrapper(torch.nn.Module):
         roi_dec = plan is not None and hasattr(self.decoder, "roi_ok") and self.decoder.roi_static_ok(plan)
         if plan is not None:        # what THIS call's encoder does with the plan (a plan may be used for more than one call)
             plan.head_windowed = plan.f0_compact = False
+            tab = plan.device_table(input_image.device, tab)    # the plan's own table; one of another plan raises
         if roi_dec and getattr(self.encoder, "roi_backward", False):
             feats = self.encoder(input_image, roi=(plan, tab), clean=clean)
         else:

@@ -89,7 +89,8 @@ def get_smooth_loss(disp, img):
     through the registered kernel ``torch.ops.dmh.smooth_loss`` (one pass forward, a four-neighbour gather backward; the
     gradient flows to ``disp`` -- ``img`` is data); anything else takes the reference's formula below."""
     if (disp.is_cuda and disp.dtype == torch.float32 and img.dtype == torch.float32 and disp.dim() == 4 and disp.shape[1] == 1
-            and img.dim() == 4 and disp.shape[2] >= 2 and disp.shape[3] >= 2 and not img.requires_grad):
+            and img.dim() == 4 and disp.shape[2] >= 2 and disp.shape[3] >= 2 and not img.requires_grad
+            and disp.shape[0] <= 65535 and disp.shape[2] * disp.shape[3] < (1 << 30)):       # the kernel's own grid limits
         from . import library  # noqa: F401  (registers torch.ops.dmh.*)
         return torch.ops.dmh.smooth_loss(disp, img)
     gdx = torch.abs(disp[:, :, :, :-1] - disp[:, :, :, 1:])
@@ -111,7 +112,8 @@ class SSIM(nn.Module):
 
     def forward(self, x, y):
         if x.is_cuda and x.dtype == torch.float32 and y.dtype == torch.float32 and x.dim() == 4 and x.shape == y.shape \
-                and x.shape[2] >= 2 and x.shape[3] >= 2:
+                and x.shape[2] >= 2 and x.shape[3] >= 2 and x.shape[0] * x.shape[1] <= 65535 \
+                and x.shape[2] * x.shape[3] < (1 << 30):      # the kernel's own grid limits: larger shapes take the formula
             # the registered kernel (torch.ops.dmh.ssim_map: window sums forward, coefficient-field gathers backward)
             from . import library  # noqa: F401
             return torch.ops.dmh.ssim_map(x, y)

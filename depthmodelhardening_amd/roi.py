@@ -192,6 +192,34 @@ class RoiPlan(object):
         """int32 [len(TABLE), B, 2] origins, in TABLE order."""
         return np.stack([self.org[n] for n in TABLE], 0)
 
+    def bind_table(self, tab):
+        """Tie the device copy of ``table()`` to this plan.  The kernels trust the device origins (a window is read and written
+        at org + (i, j) without a frame-bound check), so the plan and its table must not be paired up by hand at every call:
+        once bound, ``device_table`` hands out this tensor and refuses any other.  DMH_ROI_CHECK=1 also compares the device
+        copy with the host table (one synchronising read; debugging)."""
+        import os
+        import torch
+        want = (len(TABLE), self.B, 2)
+        if tuple(tab.shape) != want or tab.dtype != torch.int32 or not tab.is_contiguous():
+            raise RuntimeError("RoiPlan: the origin table must be a contiguous int32 %s tensor" % (want,))
+        if os.environ.get("DMH_ROI_CHECK", "0") == "1" and not np.array_equal(tab.cpu().numpy(), self.table()):
+            raise RuntimeError("RoiPlan: the device table does not hold this plan's origins")
+        self._tab = tab
+        return tab
+
+    def device_table(self, device, given=None):
+        """The device table of this plan on ``device``: the bound one (``given``, if passed, must BE it -- a table of another
+        plan is an error, not silently wrong windows), else ``given`` is bound, else the host table is uploaded and bound."""
+        tab = getattr(self, "_tab", None)
+        if tab is None:
+            if given is None:
+                import torch
+                given = torch.from_numpy(np.ascontiguousarray(self.table())).to(device)
+            return self.bind_table(given)
+        if given is not None and (given.data_ptr() != tab.data_ptr() or tuple(given.shape) != tuple(tab.shape)):
+            raise RuntimeError("RoiPlan: this origin table belongs to another plan (plans[s] paired with tabs[t != s]?)")
+        return tab
+
     def area_fraction(self):
         """Window area / frame area per window (reporting)."""
         return {n: self.size[n][0] * self.size[n][1] / float((self.H >> LEVEL[n]) * (self.W >> LEVEL[n])) for n in TABLE}

@@ -138,6 +138,8 @@ class Phy_obj_atk(Attack):
         if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
             plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
+            for p_, t_ in zip(plans, tabs):     # one H2D copy for all steps; each plan keeps ITS slice (RoiPlan.bind_table)
+                p_.bind_table(t_)
             # the frames without the object (a paste with an all-zero mask: scene (1 - 0) + patch 0, then the same Resize):
             # every step's pasted frames equal them outside the step's boxes, so the model may start from their features
             with torch.no_grad():

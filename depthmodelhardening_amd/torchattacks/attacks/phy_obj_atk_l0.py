@@ -104,13 +104,22 @@ class Phy_obj_atk_l0(Attack):
         for _ in range(max_iter):
             draws.append(pt.draw_samples(batch_size))
             rng_states.append(random.getstate())
-        final_draw = None
-        if mine is not None:        # the job's draws are rank 0's (the final pose draw included); keep the own scenes' poses
-            fin = (sample(pt.dist_range, batch_size), sample(pt.angle_range, batch_size))
-            box = [draws + [fin]]
+        # The poses of the returned scenes (:161-163) are drawn AFTER the loop, i.e. from the RNG state that follows the draws
+        # of the iterations that really ran (steps ... 2 steps of them, known only at the end).  One candidate per possible
+        # count, each with the state it leaves behind: the loop's exit picks its own, and later draws continue from there --
+        # in the one-process attack and, with rank 0's candidates broadcast, in the sharded one alike.
+        finals, states_after = {}, {}
+        for r in range(self.steps, max_iter + 1):
+            random.setstate(rng_states[r])
+            z0_f, al_f = sample(pt.dist_range, batch_size), sample(pt.angle_range, batch_size)
+            if eval:                # the override belongs to GLOBAL scene 0 (:165-167): applied before the scenes are dealt out
+                z0_f[0], al_f[0] = 6.1, 0
+            finals[r], states_after[r] = (z0_f, al_f), random.getstate()
+        if mine is not None:        # the job's draws are rank 0's (the final pose draws included); keep the own scenes' poses
+            box = [(draws, finals)]
             dist.broadcast_object_list(box, src=src, group=group)
-            allp = [([z[i] for i in mine], [a[i] for i in mine]) for z, a in box[0]]
-            draws, final_draw = allp[:-1], allp[-1]
+            draws = [([z[i] for i in mine], [a[i] for i in mine]) for z, a in box[0][0]]
+            finals = {r: ([z[i] for i in mine], [a[i] for i in mine]) for r, (z, a) in box[0][1].items()}
             batch_size = n_local
         coeffs_host = np.stack([pt.coeffs_for(z0, al) for z0, al in draws], 0)
         coeffs = to_device_async(coeffs_host, self.device)
@@ -121,6 +130,8 @@ class Phy_obj_atk_l0(Attack):
         if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
             plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
+            for p_, t_ in zip(plans, tabs):     # one H2D copy for all steps; each plan keeps ITS slice (RoiPlan.bind_table)
+                p_.bind_table(t_)
             with torch.no_grad():       # the frames without the object: see Phy_obj_atk.forward
                 clean, _ = ops.eot_paste(scene_imgs, self.obj_img, torch.zeros_like(mask), coeffs[0], l_pad, t_pad,
                                          self.scene_size)
@@ -165,8 +176,7 @@ class Phy_obj_atk_l0(Attack):
             ran += 1
             if self.trace is not None:
                 self.trace.append((int(l0_norm), float(mw), float(adv_cost), float(mask_cost)))
-        if mine is None:
-            random.setstate(rng_states[ran])
+        random.setstate(states_after[ran])     # as if only the iterations that ran, and then the final poses, had drawn
         # the loop runs ``steps`` ... 2 ``steps`` iterations, by the patch's L0 ratio (:105-109): callers that time the attack
         # (bench.py) report how many it ran
         self.total_iterations = getattr(self, "total_iterations", 0) + ran
@@ -176,14 +186,7 @@ class Phy_obj_atk_l0(Attack):
             obj_img_adv, _ = ops.l0_compose(self.obj_img, self.pattern_pos_tensor.detach(),
                                             self.pattern_neg_tensor.detach(), self.l0_clip, finalize=True)
         self.phy_trans_adv.reset_img(obj_img_adv, self.obj_mask)
-        if final_draw is not None:
-            z0_sample, alpha_sample = final_draw
-        else:
-            z0_sample = sample(pt.dist_range, batch_size)
-            alpha_sample = sample(pt.angle_range, batch_size)
-        if eval:
-            z0_sample[0] = 6.1
-            alpha_sample[0] = 0
+        z0_sample, alpha_sample = finals[ran]
         cf = to_device_async(pt.coeffs_for(z0_sample, alpha_sample), self.device)
         with torch.no_grad():
             adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, cf, l_pad, t_pad, self.scene_size)

@@ -220,9 +220,8 @@ class Trainer:
                 self.update_adv_obj()
         inputs = self.dataset.next_batch(self.opt.batch_size)
         outputs, losses = self.process_batch(inputs)
-        self.bucket.release()                    # model_optimizer.zero_grad()
-        losses["loss"].backward()
-        self.bucket.collect()
+        with self.bucket.released():             # model_optimizer.zero_grad(); gradients land in the flat bucket afterwards
+            losses["loss"].backward()
         self.bucket.start_all_reduce()
         self._pending = True
         if not overlap:

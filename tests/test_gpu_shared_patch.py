@@ -140,9 +140,14 @@ def _l0_worker(rank, world, port, ret):
     random.seed(13 if rank == 0 else 999)       # rank 0's pose draws and initial patterns are the job's
     np.random.seed(17 if rank == 0 else 4242)
     atk.grad_trace = []
-    _, _, m, patch = atk(scenes[rank::world].contiguous(), SCENES)
+    mine = scenes[rank::world].contiguous()
+    _, _, m, patch = atk(mine, SCENES)
+    first = (patch.cpu(), float(m.sum()), [g.cpu() for g in atk.grad_trace[0]])
+    # a SECOND attack, in eval mode: its poses continue rank 0's RNG stream where the first attack's LAST EXECUTED draw left
+    # it, and the eval override (6.1 m, 0 degrees) belongs to global scene 0 -- rank 0's first scene and nobody else's
+    _, _, m2, _ = atk(mine, SCENES, eval=True)
     torch.cuda.synchronize()
-    ret[rank] = (patch.cpu(), float(m.sum()), [g.cpu() for g in atk.grad_trace[0]])
+    ret[rank] = first + (m.sum((1, 2, 3)).cpu(), m2.sum((1, 2, 3)).cpu(), random.random())
     dist.barrier()
     dist.destroy_process_group()
 
@@ -151,7 +156,7 @@ def test_sharded_l0_attack_equals_the_one_process_attack():
     """Phy_obj_atk_l0 under a shard: Adam on the two pattern tensors with their gradients summed over the ranks."""
     ret = mp.Manager().dict()
     mp.spawn(_l0_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
-    (p0, m0, g0), (p1, m1, g1) = ret[0], ret[1]
+    (p0, m0, g0, ma0, mb0, r0), (p1, m1, g1, ma1, mb1, _) = ret[0], ret[1]
     assert torch.equal(p0, p1) and m0 > 0 and m1 > 0 and all(torch.equal(a, b) for a, b in zip(g0, g1))
     dev = torch.device("cuda")
     model, obj, pmask, scenes, _ = _setup(dev)
@@ -159,8 +164,18 @@ def test_sharded_l0_attack_equals_the_one_process_attack():
     random.seed(13)
     np.random.seed(17)
     atk.grad_trace = []
-    _, _, _, patch = atk(scenes, SCENES)
+    _, _, m_a, patch = atk(scenes, SCENES)
+    first_grads = atk.grad_trace[0]
+    _, _, m_b, _ = atk(scenes, SCENES, eval=True)
     assert not torch.equal(patch.cpu(), obj.cpu())
+    # the poses of the returned scenes of BOTH calls are the one-process attack's (a pasted object's mask area identifies its
+    # pose), scene by scene, and rank 0's RNG stream stands where the one-process stream stands
+    for got0, got1, want in ((ma0, ma1, m_a), (mb0, mb1, m_b)):
+        want = want.sum((1, 2, 3)).cpu()
+        torch.testing.assert_close(got0, want[0::2], rtol=1e-6, atol=0)
+        torch.testing.assert_close(got1, want[1::2], rtol=1e-6, atol=0)
+    assert r0 == random.random()
+    atk.grad_trace = [first_grads]
     # the first iteration's gradients (same initial patterns, same poses): the sum over the ranks IS the one-process gradient.
     # (Later iterations and the final patch are not compared texel by texel: Adam's first update is lr * g / |g|, so a texel
     # whose gradient is ~0 lands 2 lr apart after one step whichever way the last bit of the sum rounds.)
