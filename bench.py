@@ -41,10 +41,27 @@ BASELINE_CONFIGS = {      # BASELINE.json "configs" (index = position in that li
 }
 
 
+K1_SOURCES = ("depthmodelhardening_amd/csrc/photo_loss.hip", "depthmodelhardening_amd/csrc/smooth_loss.hip",
+              "depthmodelhardening_amd/csrc/common.hpp")
+
+
+def k1_source_hash():
+    """sha256 over the sources the K1 / K2 kernels are compiled from: the key that ties a committed counter summary to the
+    code it was measured on (tools/summarize_profiles.py writes it into profiles/rNN_k1k2_shape.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in K1_SOURCES:
+        with open(os.path.join(REPO, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def measured_traffic(B, H, W):
     """HBM bytes per launch of the K1 kernels from the newest committed rocprofv3 PMC summary (profiles/rNN_k1k2_pmc.csv:
     FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes by tools/collect_profiles.sh, unit KiB), valid for the
-    shape that summary was taken at (profiles/rNN_k1k2_shape.json).  FETCH_SIZE is taken 1:1: these kernels read one
+    shape that summary was taken at AND for the kernel source it was taken on (profiles/rNN_k1k2_shape.json: B, H, W and
+    ``k1_source_sha256``): counters of another shape or of an older photo_loss.hip are NOT reported -- ``stale`` says why and
+    the JSON's ``traffic`` is null.  FETCH_SIZE is taken 1:1: these kernels read one
     dword per lane, and the x2 correction of MI355X_MICROARCH.md section HBM is for 16-byte-per-lane streaming reads
     only ("other access widths are uncalibrated: calibrate on a known byte count in your own access pattern") --
     calibrated on smooth_fwd_kernel, which reads its 222.9 MB exactly once and reports FETCH_SIZE = 198.8 MB.  The
@@ -54,46 +71,57 @@ def measured_traffic(B, H, W):
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "r[0-9][0-9]_k1k2_pmc.csv")))
     if not files:
-        return {}
+        return {"stale": "no profiles/rNN_k1k2_pmc.csv"}
     f = files[-1]
     shape_file = f.replace("_pmc.csv", "_shape.json")
-    shape = json.load(open(shape_file)) if os.path.exists(shape_file) else {"B": 32, "H": 320, "W": 1024}
-    if (shape["B"], shape["H"], shape["W"]) != (B, H, W):
-        return {}
-    out = {"source": os.path.relpath(f, REPO)}
+    shape = json.load(open(shape_file)) if os.path.exists(shape_file) else {}
+    src = os.path.relpath(f, REPO)
+    if (shape.get("B"), shape.get("H"), shape.get("W")) != (B, H, W):
+        return {"stale": "%s was collected at another shape" % src}
+    if shape.get("k1_source_sha256") != k1_source_hash():
+        return {"stale": "%s was collected on another version of the kernel source (%s != %s): re-run tools/collect_profiles.sh"
+                         % (src, shape.get("k1_source_sha256"), k1_source_hash())}
+    out = {"source": src}
     for r in csv.DictReader(open(f)):
         for key in ("photo_fwd", "photo_bwd"):
             if key + "_kernel" in r["Kernel"]:
                 out[key] = (float(r["FETCH_SIZE"]) + float(r["WRITE_SIZE"])) * 1024.0
                 if r.get("SQ_INSTS_VALU"):
                     out[key + "_valu_insts"] = float(r["SQ_INSTS_VALU"])
+                if r.get("GRBM_GUI_ACTIVE"):
+                    out[key + "_gui_active"] = float(r["GRBM_GUI_ACTIVE"])
     return out
 
 
-# one scalar (non-packed) fp32 vector instruction per SIMD, in cycles of the nominal 2.4 GHz clock, MEASURED on all 256 CUs with
-# tools/micro/valu_rate.hip (profiles/r04_valu_rate.txt): 7.87 / 5.84 / 5.07 / 4.81 / 4.52 / 4.44 at 1 / 2 / 3 / 4 / 6 / 8 waves per
-# SIMD -- the data sheet's 2-cycle rate is approached by packed `v_pk_*_f32` only (4.83 cycles per packed instruction = two
-# operations per lane)
-SCALAR_FP32_ISSUE_CYCLES = {1: 7.87, 2: 5.84, 3: 5.07, 4: 4.81, 6: 4.52, 8: 4.44}
-VALU_F32_SCALAR_TFLOPS = round(1024 * 64 * 2 * 2.4e9 / SCALAR_FP32_ISSUE_CYCLES[8] / 1e12, 1)     # 70.9
-K1_WAVES_PER_SIMD = {"photo_fwd": 3, "photo_bwd": 2}     # 167 / 214 VGPRs (hipcc -Rpass-analysis=kernel-resource-usage)
+# A wave64 vector instruction that is not packed occupies its SIMD's issue port for 4 cycles (MI355X_MICROARCH.md, constants
+# table: "vector-instruction ISSUE cost ... v_add_f32 / v_fma_f32 4"; the 2-cycle figure of the data sheet is reached by packed
+# v_pk_*_f32 only: tools/micro/valu_rate.hip measured 4.44 nominal-clock cycles for scalar fp32 FMAs at 8 waves per SIMD and
+# 4.83 for packed ones, profiles/r04_valu_rate.txt).  The roof is counted in MEASURED cycles: GRBM_GUI_ACTIVE of the same counter
+# run (8 XCDs) is the kernel's duration in shader cycles at the clock the chip really held (2.2 GHz under this load, not 2.4).
+VALU_ISSUE_CYCLES = 4.0
+N_SIMD, N_XCD = 1024, 8
+VALU_F32_SCALAR_TFLOPS = round(N_SIMD * 64 * 2 * 2.4e9 / 4.44 / 1e12, 1)     # 70.9: K12's roof (measured saturated issue rate)
 
 
-def valu_roof(insts, measured_ms, waves_per_simd=None):
-    """The vector-issue roof of a VALU-bound kernel: SQ_INSTS_VALU wave-instructions at the chip's peak rate of one wave64
-    instruction per 2 cycles per SIMD (MI355X_MICROARCH.md: 32 lanes per cycle), 1024 SIMDs, 2.4 GHz -- and, beside it, at the
-    rate a stream of scalar fp32 vector instructions was MEASURED to issue at: saturated (8 waves per SIMD), and at the
-    kernel's own occupancy (``waves_per_simd``: 3 for K1 forward at 167 VGPRs, 2 for the backward at 214)."""
-    def floor(cyc):
-        ms = insts * cyc / 1024.0 / 2.4e9 * 1e3
-        return {"cycles_per_wave_instruction": cyc, "floor_ms": round(ms, 4), "frac": round(ms / measured_ms, 4) if measured_ms else None}
-    out = {"bound": "valu", "SQ_INSTS_VALU": insts}
-    out.update(floor(2))
-    out["measured_scalar_fp32_issue"] = dict(floor(SCALAR_FP32_ISSUE_CYCLES[8]), waves_per_simd=8,
-                                             source="tools/micro/valu_rate.hip on all 256 CUs, profiles/r04_valu_rate.txt")
-    if waves_per_simd in SCALAR_FP32_ISSUE_CYCLES:
-        out["measured_scalar_fp32_issue_at_occupancy"] = dict(floor(SCALAR_FP32_ISSUE_CYCLES[waves_per_simd]),
-                                                              waves_per_simd=waves_per_simd)
+def valu_roof(insts, measured_ms, gui_active=None):
+    """The vector-issue roof of a VALU-bound kernel: SQ_INSTS_VALU wave-instructions x 4 issue cycles on 1024 SIMDs, against
+    the kernel's duration in shader cycles (GRBM_GUI_ACTIVE / 8 XCDs, same counter collection).  ``frac`` = the share of the
+    kernel's cycles in which its SIMDs' vector issue ports are taken; by construction <= 1.  Without the cycle counter the
+    nominal 2.4 GHz converts the HIP-event time instead, and the entry says so."""
+    per_simd = insts / float(N_SIMD)
+    out = {"bound": "valu", "SQ_INSTS_VALU": insts, "issue_cycles_per_wave_instruction": VALU_ISSUE_CYCLES}
+    if gui_active:
+        cyc = gui_active / N_XCD
+        out.update({"kernel_cycles": round(cyc), "clock": "measured (GRBM_GUI_ACTIVE / 8)",
+                    "measured_cycles_per_wave_instruction_per_simd": round(cyc / per_simd, 3),
+                    "frac": round(VALU_ISSUE_CYCLES * per_simd / cyc, 4)})
+        if measured_ms:
+            out["clock_ghz_during_kernel"] = round(cyc / (measured_ms * 1e-3) / 1e9, 3)
+    elif measured_ms:
+        cyc = measured_ms * 1e-3 * 2.4e9
+        out.update({"clock": "nominal 2.4 GHz (no cycle counter in the summary): an upper bound on the cycles, so a lower "
+                             "bound on frac", "frac": round(min(1.0, VALU_ISSUE_CYCLES * per_simd / cyc), 4)})
+    out["data_sheet_2_cycle_floor_ms"] = round(insts * 2.0 / N_SIMD / 2.4e9 * 1e3, 4)
     return out
 
 
@@ -551,11 +579,12 @@ def run_rank(a):
                             "K3 EOT paste (the hot-path kernel of this harness): SURVEY 8d bytes per launch, averaged over the "
                             "launches of the timed region",
                     "avg_ms": round(kms[dom], 4), "algorithmic_bytes": nbytes,
-                    "valu_roof": valu_roof(meas[dom + "_valu_insts"], kms[dom], K1_WAVES_PER_SIMD.get(dom))
+                    "traffic_stale": meas.get("stale"),
+                    "valu_roof": valu_roof(meas[dom + "_valu_insts"], kms[dom], meas.get(dom + "_gui_active"))
                     if meas.get(dom + "_valu_insts") else None,
                     "others": {names[k][0]: {"avg_ms": round(v, 4), "GB/s": round(names[k][1] / (v * 1e-3) / 1e9, 1),
                                              "algorithmic_bytes": names[k][1], "traffic": meas.get(k),
-                                             "valu_roof": valu_roof(meas[k + "_valu_insts"], v, K1_WAVES_PER_SIMD.get(k))
+                                             "valu_roof": valu_roof(meas[k + "_valu_insts"], v, meas.get(k + "_gui_active"))
                                              if meas.get(k + "_valu_insts") else None}
                                for k, v in kms.items() if k != dom}}
             # streaming kernels of the decoder glue: shapes vary per launch, so total bytes / total time

@@ -45,7 +45,10 @@ for d in ["k1_pmc_a", "k1_pmc_b", "k1_fetch", "k1_write", "k1_tcc"]:
             tabs[k]["_meta"] = meta[k]
 cols = sorted({c for v in tabs.values() for c in v if c != "_meta"})
 if tabs:    # the shape tools/prof_k1.py runs: bench.py uses the traffic figures only for this shape
-    json.dump({"B": 32, "H": 320, "W": 1024, "scales": 4, "tool": "tools/prof_k1.py"}, open("profiles/%s_k1k2_shape.json" % tag, "w"))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench          # the source hash that ties these counters to the kernel they were taken on (bench.measured_traffic)
+    json.dump({"B": 32, "H": 320, "W": 1024, "scales": 4, "tool": "tools/prof_k1.py", "k1_source_sha256": bench.k1_source_hash(),
+               "k1_sources": list(bench.K1_SOURCES)}, open("profiles/%s_k1k2_shape.json" % tag, "w"))
 with open("profiles/%s_k1k2_pmc.csv" % tag, "w") as f:
     w = csv.writer(f)
     w.writerow(["Kernel", "VGPR_Count", "LDS_Block_Size", "Grid_Size", "Workgroup_Size"] + cols)
