@@ -86,5 +86,61 @@ def _build_locked(force, verbose):
     return LIB_PATH
 
 
+ASAN_LIB_PATH = os.path.join(LIB_DIR, "libdmh_hip_asan.so")
+
+
+def build_asan(verbose=False):
+    """The HOST side of every source under AddressSanitizer: ``hipcc --offload-host-only -fsanitize=address`` (no device code:
+    GPU ASan is not available on this pool, and the host side -- argument checks, workspace sizing, error formatting -- is
+    what runs before every launch).  Links lib/libdmh_hip_asan.so and the C driver tests/asan/host_checks.c against it;
+    returns the driver's path.  tests/test_asan_host.py runs it in the CPU suite."""
+    hipcc = _hipcc()
+    odir = os.path.join(OBJ_DIR, "asan")
+    os.makedirs(odir, exist_ok=True)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    # --offload-new-driver: the host-only object then carries no reference to a device fat binary (the classic driver leaves
+    # an undefined __hip_fatbin_<hash> behind), so the library links and loads without any device code
+    flags = ["--offload-arch=gfx950", "--offload-host-only", "--offload-new-driver", "-O1", "-g", "-fsanitize=address",
+             "-fno-omit-frame-pointer",
+             "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-I" + INCLUDE]
+    headers = [os.path.join(CSRC, "common.hpp"), os.path.join(INCLUDE, "dmh_hip.h")]
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("ASan host build failed:\n" + " ".join(cmd) + "\n" + r.stdout)
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            objs, jobs = [], []
+            for src in SOURCES:
+                s_, o = os.path.join(CSRC, src), os.path.join(odir, src.replace(".hip", ".o"))
+                objs.append(o)
+                if _stale(o, [s_] + headers):
+                    jobs.append([hipcc] + flags + ["-c", s_, "-o", o])
+            with ThreadPoolExecutor(max_workers=4) as ex:
+                list(ex.map(run, jobs))
+            clang = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang")
+            clang = clang if os.path.exists(clang) else "/opt/rocm/lib/llvm/bin/clang"
+            rocm_lib = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib")
+            rocm_lib = rocm_lib if os.path.exists(os.path.join(rocm_lib, "libamdhip64.so")) else "/opt/rocm/lib"
+            if jobs or _stale(ASAN_LIB_PATH, objs):
+                run([clang + "++", "-fsanitize=address", "-shared", "-fPIC"] + objs
+                    + ["-L" + rocm_lib, "-lamdhip64", "-Wl,-rpath," + rocm_lib, "-o", ASAN_LIB_PATH])
+            driver_src = os.path.join(REPO, "tests", "asan", "host_checks.c")
+            driver = os.path.join(odir, "host_checks")
+            if _stale(driver, [driver_src, ASAN_LIB_PATH] + headers):
+                run([clang, "-std=c11", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-Wall", "-I" + INCLUDE,
+                     driver_src, "-L" + LIB_DIR, "-ldmh_hip_asan", "-Wl,-rpath," + LIB_DIR, "-Wl,-rpath,/opt/rocm/lib", "-o", driver])
+            return driver
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--asan" in sys.argv:
+        print(build_asan(verbose=True))
+    else:
+        print(build(force="--force" in sys.argv))

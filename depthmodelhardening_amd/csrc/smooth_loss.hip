@@ -383,7 +383,8 @@ int check_smooth(const dmh_smooth_args* a) {
 extern "C" {
 
 int64_t dmh_smooth_partials_size(const dmh_smooth_args* a) {
-    if (!a) return 0;
+    // (found by the ASan host build: a num_scales beyond the struct's arrays was indexed here before any check)
+    if (!a || a->num_scales < 1 || a->num_scales > DMH_MAX_SCALES || a->B <= 0) return 0;
     const Layout l = make_layout(*a);
     return (int64_t)l.blk_base[a->num_scales] * 3;
 }
