@@ -14,7 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from ... import ops
+from ... import color_jitter, ops
 from ...my_utils import object_dataset_root, ori_H, ori_W, to_device_async
 from ...physicalTrans import PhysicalTrans
 from ...roi import RoiPlan
@@ -44,6 +44,9 @@ class Phy_obj_atk_l0(Attack):
                                            dist_range=dist_range)
         self.phy_trans_ben = PhysicalTrans(self.obj_img, self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
+        # ONE random colour transform per attack object, drawn here as the reference does (:41; four random.uniform + one
+        # random.shuffle of the global ``random`` generator), applied by forward(..., color_jit=True)
+        self.color_aug = color_jitter.get_params((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
         self.use_roi = True     # evaluate the adversarial cost on windows around the object when the model offers it
         self.shard = None       # (rank, world, group): data-parallel shared-patch mode, see Phy_obj_atk.shard
         self.trace = None  # set to a list to record (l0, mask_weight, adv_cost, mask_cost) per iteration
@@ -57,9 +60,6 @@ class Phy_obj_atk_l0(Attack):
 
     def forward(self, images, batch_size, cfg_path=f'{object_dataset_root}/training/calib/003086.txt', eval=False,
                 color_jit=False):
-        if color_jit:
-            raise NotImplementedError("color_jit needs torchvision ColorJitter (phy_obj_atk_l0.py:41,124); the "
-                                      "training path never enables it (mono_dataset.py:182)")
         img_B, img_C, img_H, img_W = images.size()
         if img_H != ori_H or img_W != ori_W:
             images = F.interpolate(images, size=[ori_H, ori_W], mode="bilinear", align_corners=False)
@@ -127,7 +127,10 @@ class Phy_obj_atk_l0(Attack):
         mask = self.obj_mask.to(self.device)
         # the adversarial cost reads the disparity under the object only: see Phy_obj_atk.forward
         plans = tabs = clean = None
-        if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
+        # (with color_jit the whole frame changes with the patch -- the contrast step blends with the pasted image's mean --
+        # so neither the windows' "unchanged outside the box" nor the cached clean-frame features hold: whole-frame path)
+        if (ops.ROI_ENABLED and self.use_roi and not color_jit and hasattr(self.model, "masked_sq_mean")
+                and self.device.type == "cuda"):
             plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
             for p_, t_ in zip(plans, tabs):     # one H2D copy for all steps; each plan keeps ITS slice (RoiPlan.bind_table)
@@ -156,6 +159,8 @@ class Phy_obj_atk_l0(Attack):
             if plans is not None:
                 adv_cost = self.model.masked_sq_mean(adv_scenes, adv_obj_mask, plans[stp], tabs[stp], clean)
             else:
+                if color_jit:       # :122-124 (off the hot path: composed from tensor operations, see color_jitter.py)
+                    adv_scenes = self.color_aug(adv_scenes)
                 adv_depth = self.model(adv_scenes)
                 adv_cost = ops.masked_sq_mean(adv_depth, adv_obj_mask)
             mask_cost = ops.l0_mask_cost(self.pattern_pos_tensor, self.pattern_neg_tensor)

@@ -193,9 +193,10 @@ def l0_mask_cost(pos_t, neg_t):
 
 
 def phy_obj_atk_l0(model, obj_img, obj_mask, images, batch_size, adam_lr=0.5, steps=10, mask_wt=0.1,
-                   l0_thresh=0.1, dist_range=None, eval=False, P2=KITTI_P2, record=None):
-    """Phy_obj_atk_l0.forward (phy_obj_atk_l0.py:54-174), color_jit=False, under
-    Attack.__call__'s eval-mode bracket."""
+                   l0_thresh=0.1, dist_range=None, eval=False, P2=KITTI_P2, record=None, color_aug=None):
+    """Phy_obj_atk_l0.forward (phy_obj_atk_l0.py:54-174) under Attack.__call__'s eval-mode bracket.  ``color_aug``: the
+    callable the constructor got from ColorJitter.get_params (:41; tv082.color_jitter_get_params) when ``color_jit`` is set
+    (:122-124), None otherwise."""
     dist_range = list(range(5, 31, 2)) if dist_range is None else dist_range
     clip_max = 1
     l0_clip = clip_max / 255.0
@@ -234,6 +235,8 @@ def phy_obj_atk_l0(model, obj_img, obj_mask, images, batch_size, adam_lr=0.5, st
             mw = mask_wt
         trans_adv.reset_img(adv, obj_mask)
         adv_scenes, masks, _, _, _ = paste(scene_imgs, trans_adv, batch_size)
+        if color_aug is not None:
+            adv_scenes = color_aug(adv_scenes)
         adv_cost = loss(model(adv_scenes) * masks, target)
         mask_cost = l0_mask_cost(pos_t, neg_t)
         total = adv_cost + mw * mask_cost

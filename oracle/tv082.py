@@ -81,3 +81,102 @@ def perspective(img, startpoints, endpoints, interpolation=2, fill=None):
     coeffs = get_perspective_coeffs([list(map(float, p)) for p in startpoints],
                                     [list(map(float, p)) for p in endpoints])
     return perspective_coeffs(img, coeffs)
+
+
+# ------------------------------------------------------------------------------------------------------ ColorJitter
+# phy_obj_atk_l0.py:41 builds ``self.color_aug = ColorJitter.get_params((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))`` ONCE,
+# in the constructor, and :122-124 applies it to the pasted scenes when ``color_jit`` is set.  In 0.8.2 get_params draws the
+# four factors with ``random.uniform`` (brightness, contrast, saturation, hue, in this order), wraps each adjust_* call in a
+# Lambda, ``random.shuffle``s the list and returns the Compose -- a callable, which is what the reference stores (later
+# versions return a tuple).  The tensor ops are functional_tensor.py's (v0.8.2), restated op for op below.  PARITY UNPINNED
+# like the rest of this file.
+def _blend(img1, img2, ratio):
+    return (ratio * img1 + (1.0 - ratio) * img2).clamp(0, 1.0)
+
+
+def rgb_to_grayscale(img):
+    r, g, b = img.unbind(dim=-3)
+    return (0.2989 * r + 0.587 * g + 0.114 * b).unsqueeze(dim=-3)
+
+
+def adjust_brightness(img, factor):
+    return _blend(img, torch.zeros_like(img), factor)
+
+
+def adjust_contrast(img, factor):
+    mean = torch.mean(rgb_to_grayscale(img), dim=(-3, -2, -1), keepdim=True)
+    return _blend(img, mean, factor)
+
+
+def adjust_saturation(img, factor):
+    return _blend(img, rgb_to_grayscale(img), factor)
+
+
+def _rgb2hsv(img):
+    r, g, b = img.unbind(dim=-3)
+    maxc = torch.max(img, dim=-3).values
+    minc = torch.min(img, dim=-3).values
+    eqc = maxc == minc
+    cr = maxc - minc
+    ones = torch.ones_like(maxc)
+    s = cr / torch.where(eqc, ones, maxc)
+    cr_divisor = torch.where(eqc, ones, cr)
+    rc = (maxc - r) / cr_divisor
+    gc = (maxc - g) / cr_divisor
+    bc = (maxc - b) / cr_divisor
+    hr = (maxc == r) * (bc - gc)
+    hg = ((maxc == g) & (maxc != r)) * (2.0 + rc - bc)
+    hb = ((maxc != g) & (maxc != r)) * (4.0 + gc - rc)
+    h = (hr + hg + hb)
+    h = torch.fmod((h / 6.0 + 1.0), 1.0)
+    return torch.stack((h, s, maxc), dim=-3)
+
+
+def _hsv2rgb(img):
+    h, s, v = img.unbind(dim=-3)
+    i = torch.floor(h * 6.0)
+    f = (h * 6.0) - i
+    i = i.to(dtype=torch.int32)
+    p = torch.clamp((v * (1.0 - s)), 0.0, 1.0)
+    q = torch.clamp((v * (1.0 - s * f)), 0.0, 1.0)
+    t = torch.clamp((v * (1.0 - (s * (1.0 - f)))), 0.0, 1.0)
+    i = i % 6
+    mask = i.unsqueeze(dim=-3) == torch.arange(6, device=i.device).view(-1, 1, 1)
+    a1 = torch.stack((v, q, p, p, t, v), dim=-3)
+    a2 = torch.stack((t, v, v, q, p, p), dim=-3)
+    a3 = torch.stack((p, p, t, v, v, q), dim=-3)
+    a4 = torch.stack((a1, a2, a3), dim=-4)
+    return torch.einsum("...ijk, ...xijk -> ...xjk", mask.to(dtype=img.dtype), a4)
+
+
+def adjust_hue(img, hue_factor):
+    if not (-0.5 <= hue_factor <= 0.5):
+        raise ValueError('hue_factor ({}) is not in [-0.5, 0.5].'.format(hue_factor))
+    h, s, v = _rgb2hsv(img).unbind(dim=-3)
+    h = (h + hue_factor) % 1.0
+    return _hsv2rgb(torch.stack((h, s, v), dim=-3))
+
+
+def color_jitter_get_params(brightness, contrast, saturation, hue):
+    """transforms.ColorJitter.get_params (v0.8.2): the composed callable.  Draws from ``random`` in the published order."""
+    import random
+    transforms = []
+    if brightness is not None:
+        bf = random.uniform(brightness[0], brightness[1])
+        transforms.append(lambda img: adjust_brightness(img, bf))
+    if contrast is not None:
+        cf = random.uniform(contrast[0], contrast[1])
+        transforms.append(lambda img: adjust_contrast(img, cf))
+    if saturation is not None:
+        sf = random.uniform(saturation[0], saturation[1])
+        transforms.append(lambda img: adjust_saturation(img, sf))
+    if hue is not None:
+        hf = random.uniform(hue[0], hue[1])
+        transforms.append(lambda img: adjust_hue(img, hf))
+    random.shuffle(transforms)
+
+    def compose(img):
+        for t in transforms:
+            img = t(img)
+        return img
+    return compose

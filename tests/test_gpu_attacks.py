@@ -119,6 +119,36 @@ def test_l0_attack_trace_vs_oracle():
         assert abs(ac - acr) <= 1e-3 * abs(acr) + 1e-7 and abs(mc - mcr) <= 1e-4 * abs(mcr)
 
 
+def test_l0_attack_with_color_jit_vs_oracle():
+    """Phy_obj_atk_l0(..., color_jit=True) (phy_obj_atk_l0.py:41,122-124): ONE ColorJitter transform drawn in the constructor
+    (four random.uniform + a shuffle), applied to the pasted scenes of every iteration, the pattern gradients flowing through
+    it.  Against the oracle attack given torchvision-0.8.2's get_params (oracle/tv082.py) from the same ``random`` state."""
+    ta, attack_ref, synth, obj, mask = _setup()
+    from oracle import tv082
+    scenes = synth.kitti_like(2, 3, 375, 1242, torch.Generator().manual_seed(8))
+    rec = []
+    _seed_all(23)
+    aug = tv082.color_jitter_get_params((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))    # the reference's constructor draw
+    attack_ref.phy_obj_atk_l0(synth.TinyDepthNet(seed=5), obj, mask, scenes, 2, adam_lr=0.5, steps=2, mask_wt=0.06,
+                              l0_thresh=0.1, dist_range=attack_ref.TRAIN_DIST_RANGE, record=rec, color_aug=aug)
+    rec_plain = []
+    _seed_all(23)
+    tv082.color_jitter_get_params((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
+    attack_ref.phy_obj_atk_l0(synth.TinyDepthNet(seed=5), obj, mask, scenes, 2, adam_lr=0.5, steps=2, mask_wt=0.06,
+                              l0_thresh=0.1, dist_range=attack_ref.TRAIN_DIST_RANGE, record=rec_plain)
+    _seed_all(23)
+    atk = ta.Phy_obj_atk_l0(synth.TinyDepthNet(seed=5).cuda(), obj.cuda(), mask.cuda(), adam_lr=0.5, steps=2,
+                            mask_wt=0.06, l0_thresh=0.1, dist_range=list(np.arange(5, 10, 0.2)))
+    atk.trace = []
+    adv, ben, m, patch = atk(scenes.cuda(), 2, color_jit=True)
+    assert len(atk.trace) == len(rec)
+    assert abs(rec[0][2] - rec_plain[0][2]) > 1e-3 * abs(rec_plain[0][2])       # the augmentation changes the cost at all
+    for (l0, mw, ac, mc), (l0r, mwr, acr, mcr) in zip(atk.trace, rec):
+        assert abs(l0 - l0r) <= max(3, 1e-3 * l0r) and abs(mw - mwr) < 1e-7
+        assert abs(ac - acr) <= 1e-3 * abs(acr) + 1e-7 and abs(mc - mcr) <= 1e-4 * abs(mcr)
+    assert tuple(adv.shape) == (2, 3, 320, 1024) and float((patch - obj.cuda()).abs().max()) > 0
+
+
 @pytest.mark.parametrize("targeted", [True, False])
 def test_pgd_depth_matches_reference_golden(golden, targeted):
     ta, attack_ref, synth, obj, mask = _setup()

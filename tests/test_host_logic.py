@@ -194,3 +194,33 @@ def test_bench_presets_name_the_baseline_configs():
     # the step-FLOP model builds at any size (import_depth_model refuses everything but 1024x320)
     f = bench.unet_flops(64, 192)
     assert f["fwd"] > 0 and f["bwd_full"] > f["bwd_data"] > 0
+
+
+def test_color_jitter_matches_the_torchvision_restatement():
+    """color_jitter.get_params / its four operations (the product's closed-form HSV rotation) against oracle/tv082.py's op-for-op
+    restatement of torchvision 0.8.2 (six-case table): the same draws from ``random`` in the same order, the same images, the
+    same gradients -- over 20 random transforms, flat (grey) pixels and channel ties included."""
+    import random
+    import torch
+    from depthmodelhardening_amd import color_jitter as cj
+    from oracle import tv082
+    x = torch.rand(2, 3, 24, 40, dtype=torch.float64, generator=torch.Generator().manual_seed(3))
+    x[0, :, :4] = 0.3                   # flat pixels: max == min
+    x[1, 0, 4:8] = x[1, 1, 4:8]         # two channels tie for the maximum
+    for seed in range(20):
+        random.seed(seed)
+        ref = tv082.color_jitter_get_params((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
+        state = random.getstate()
+        random.seed(seed)
+        mine = cj.get_params((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))
+        assert random.getstate() == state               # same number of draws from the same generator
+        a, b = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = ref(a), mine(b)
+        assert float((ya - yb).abs().max()) < 1e-12, (seed, mine)
+        w = torch.rand(ya.shape, dtype=torch.float64, generator=torch.Generator().manual_seed(seed))
+        (ya * w).sum().backward()
+        (yb * w).sum().backward()
+        assert float((a.grad - b.grad).abs().max()) < 1e-9, (seed, mine)
+    with __import__("pytest").raises(ValueError):
+        cj._hue(x, 0.7)
+
