@@ -59,7 +59,27 @@ struct WArgs {
                                  // their halves into a zeroed y (fills the chip when there are few regions)
     int bitems;                  // B (2x32 regions: per image) or 1 (4x16 regions: tile rows flattened over the batch)
     int nitems;                  // bitems * gy * gx * kg * csplit work items
+    float* part;                 // SK: workspace of the partial items (2 * sk_grid slots of SK_SLOT floats)
+    // stream-K decomposition (SK instantiations): the (item, channel chunk) space of sk_units = regions * C/8 units is dealt
+    // to the sk_grid workgroups in contiguous, equal ranges; a range that starts or ends inside an item leaves a PARTIAL item,
+    // whose sums go to slot 2 * wg (the workgroup's first piece) / 2 * wg + 1 (its last) of `part` (SK_SLOT floats each) and are
+    // added in chunk order by wino_sk_fixup_kernel
+    int sk_units, sk_grid;
 };
+constexpr int SK_SLOT = 16 * NT * 4;      // floats of one partial item: [output channel v 16][thread 256] float4 (y00, y01, y10, y11)
+
+// first unit of workgroup w's range (w = 0 .. sk_grid).  A boundary inside an item is kept at least 3 chunks away from both
+// of the item's ends (the staging pipeline is 3 chunks deep); items of fewer than 6 chunks are never cut.
+__host__ __device__ inline int sk_boundary(int units, int grid, int nch, int w) {
+    const long long b = (long long)w * units / grid;
+    const int item = (int)(b / nch);
+    int c = (int)(b - (long long)item * nch);
+    if (c != 0) {
+        if (nch >= 6) c = c < 3 ? 3 : (c > nch - 3 ? nch - 3 : c);
+        else c = (2 * c < nch) ? 0 : nch;
+    }
+    return item * nch + c;
+}
 
 // pre-transform the filter: U = G g G^T, scattered into the chunked layout the kernel streams.
 // mode 0: forward   u[k][c] from w[k][c][ky][kx]
@@ -114,12 +134,14 @@ __global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict
 // back to back on the same CU and re-read its input from L1/L2.
 struct Item {
     int b, ty0, tx0, k0, c0;     // c0: first channel chunk of the item (channel split)
+    int si;                      // which part of the channel split
 };
 template <int TRW>
 __device__ __forceinline__ Item decode_item(const WArgs& a, int item) {
     constexpr int TRH = 64 / TRW;
     Item it;
-    it.c0 = (item % a.csplit) * (a.C / CK / a.csplit);  item /= a.csplit;
+    it.si = item % a.csplit;
+    it.c0 = it.si * (a.C / CK / a.csplit);  item /= a.csplit;
     it.k0 = (item % a.kg) * 64;  item /= a.kg;
     it.tx0 = (item % a.gx) * TRW;  item /= a.gx;
     it.ty0 = (item % a.gy) * TRH;
@@ -127,7 +149,7 @@ __device__ __forceinline__ Item decode_item(const WArgs& a, int item) {
     return it;
 }
 
-template <int TRW, bool FLAT, bool EPI>
+template <int TRW, bool FLAT, bool EPI, bool SK = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_conv_kernel(WArgs a) {
     constexpr int TRH = 64 / TRW;
     // Tile regions normally lie inside one image and their tile rows share input rows.  FLAT (4 x 16 regions on images
@@ -163,10 +185,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int nch = a.C / CK / a.csplit;                    // channel chunks per item
 
     // ---- this workgroup's contiguous item range, flattened with the channel chunks into one iteration space
-    const int q = a.nitems / (int)gridDim.x, r = a.nitems % (int)gridDim.x;
-    const int item0 = (int)blockIdx.x * q + min((int)blockIdx.x, r);
-    const int nmine = q + ((int)blockIdx.x < r ? 1 : 0);
+    int item0, nmine, cb0 = 0, ce_last = nch;   // SK: the first piece starts at chunk cb0 of item0, the last ends before ce_last
+    if (SK) {       // equal ranges of (item, chunk) units: a range may begin and end inside an item (see WArgs)
+        const int u0 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x);
+        const int u1 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x + 1);
+        if (u0 >= u1) return;
+        item0 = u0 / nch;
+        const int il = (u1 - 1) / nch;
+        nmine = il - item0 + 1;
+        cb0 = u0 - item0 * nch;
+        ce_last = u1 - il * nch;
+    } else {
+        const int q = a.nitems / (int)gridDim.x, r = a.nitems % (int)gridDim.x;
+        item0 = (int)blockIdx.x * q + min((int)blockIdx.x, r);
+        nmine = q + ((int)blockIdx.x < r ? 1 : 0);
+    }
     const int item_last = item0 + nmine - 1;
+    int pn = nch;           // channel chunks of the current piece (SK: a partial item has fewer)
 
     // transform role: wave wv owns chunk channels {2wv, 2wv+1} = (h = wv>>1, s = 2(wv&1) + {0,1}); lane = tile
     const int tly = lane / TRW, tlx = lane - tly * TRW;
@@ -187,12 +222,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // masked the value: ~55 vector instructions per chunk that the fp32 MFMA, sharing the vector pipe, could not shadow).
     const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.C * HW * 4));
     const rsrc_t urs = make_rsrc(a.U, (unsigned)((size_t)(a.C / CK) * 32 * a.Kp * 16));
+    const rsrc_t prs = make_rsrc(SK ? (const void*)a.part : (const void*)a.U, SK ? (unsigned)(2 * a.sk_grid) * (unsigned)(SK_SLOT * 4) : 16u);
     unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
     unsigned uoff = 0, uoff_n = 0;           // byte offset of the item's first filter chunk (uniform)
     int ixa = 0, ixa_n = 0;                  // first staged column of the item (uniform; `partial` only)
 #define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, UOFF, IXA)                                               \
     {                                                                                             \
-        const Item it = decode_item<TRW>(a, ITEM);                                                \
+        Item it = decode_item<TRW>(a, ITEM);                                                      \
+        if (SK) it.c0 = ((ITEM) == item0) ? cb0 : 0;      /* a workgroup's first piece may start inside its item */ \
         const int ix0 = 2 * it.tx0 - a.pad - coff;        /* multiple of 4: tx0 is a multiple of 16 */ \
         IXA = ix0;                                                                                \
         /* thread index rebuilt from v_mbcnt + the scalar wave index: a copy of `tid` kept from kernel entry is  */ \
@@ -334,13 +371,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const f32x4* Uc = U_lds + cur * BUF + aidx;
             const f32x4* Vc = V_lds + cur * BUF + bidx;
             const float* rs = rsrc + nxt * RAW_BUF * 4;
-            const int ixw = (ch + 2 >= nch) ? ixa_n : ixa;  // the registers written to LDS below hold chunk ch+2
+            const int ixw = (ch + 2 >= pn) ? ixa_n : ixa;   // the registers written to LDS below hold chunk ch+2
             float* vd = vdst + nxt * BUF * 4;
             // load-stage operands of this iteration: raw chunk ch+3 and filter chunk ch+1, possibly of the next item;
             // the raw registers written to LDS in this iteration hold chunk ch+2
-            const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
+            const bool r_next = ch + 3 >= pn, u_next = ch + 1 >= pn;
             unsigned xcb = (unsigned)__builtin_amdgcn_readfirstlane(   // raw chunk ch+3: byte offset in its item
-                (int)((unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes));
+                (int)((unsigned)(r_next ? ch + 3 - pn : ch + 3) * chunk_bytes));
             // pinned to an SGPR: a scalar offset the compiler parks in a VGPR turns every load that uses it into a waterfall
             // loop (readfirstlane + compare + branch) -- the FLAT instantiations did, 17 loops per chunk
             asm volatile("" : "+s"(xcb));
@@ -421,8 +458,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             asm volatile("" ::: "memory");
             ++g;
         };
+        if (SK) pn = (item == item_last ? ce_last : nch) - (item == item0 ? cb0 : 0);
         chunk(0, std::true_type());
-        for (int ch = 1; ch < nch; ++ch) chunk(ch, std::false_type());
+        for (int ch = 1; ch < pn; ++ch) chunk(ch, std::false_type());
         // ---- item done: output transform  Y = A^T M A, store; lane -> tile,
         //      register -> output channel
         {
@@ -473,7 +511,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     s0[j] = acc[j][v] + acc[4 + j][v] + acc[8 + j][v];
                     s1[j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
                 }
-                if (inside && ko < a.K) {
+                if (SK && pn < nch) {       // a partial item: its raw sums to the workgroup's slot, finished by wino_sk_fixup_kernel
+                    // buffer store: the slot's base is a descriptor in SGPRs, the (slot, channel) offset an SGPR, the thread's
+                    // 16 bytes one VGPR -- no 64-bit per-lane address beside the 256 live accumulators
+                    const int slot = 2 * (int)blockIdx.x + ((item != item0 && item == item_last) ? 1 : 0);
+                    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slot * 16 + v) * (NT * 16));
+                    const f32x4 pv = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pv),
+                                                           prs, (unsigned)(wv_s * 64 + lane_o) * 16u, soff, 0);
+                } else if (inside && ko < a.K) {
                     const float bs = (a.bias && it.c0 == 0) ? a.bias[ko] : 0.f;
                     float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
                     float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
@@ -518,6 +564,55 @@ __global__ __launch_bounds__(NT) void zero_fill_kernel(f32x4* __restrict__ p, si
     if (i < n4) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
+// Stream-K second stage: one workgroup per range boundary that cuts an item.  The workgroup of the FIRST cut of an item adds the
+// item's partial pieces in chunk order (fixed: deterministic, no atomics), applies the bias and writes the item's outputs with
+// the main kernel's own thread -> (tile, channel) map.
+template <int TRW, bool FLAT>
+__global__ __launch_bounds__(NT) void wino_sk_fixup_kernel(WArgs a) {
+    constexpr int TRH = 64 / TRW;
+    const int nch = a.C / CK;
+    const int w = (int)blockIdx.x + 1;
+    const int b = sk_boundary(a.sk_units, a.sk_grid, nch, w);
+    const int item = b / nch;
+    if (b == item * nch) return;                                 // the boundary falls between two items
+    const int bp = sk_boundary(a.sk_units, a.sk_grid, nch, w - 1);
+    if (bp > item * nch) return;                                 // an earlier boundary cuts this item: its workgroup sums
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kb = wv & 1, tb = wv >> 1;
+    const f32x4* part = reinterpret_cast<const f32x4*>(a.part);
+    // the pieces in chunk order: the last piece of workgroup w-1 (its only one if it starts exactly at the item), then the first
+    // piece of every workgroup whose range starts inside the item
+    f32x4 acc[16];
+    {
+        const int slot = 2 * (w - 1) + (bp == item * nch ? 0 : 1);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = part[((size_t)slot * 16 + v) * NT + tid];
+    }
+    for (int ww = w;; ++ww) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += part[((size_t)(2 * ww) * 16 + v) * NT + tid];
+        if (sk_boundary(a.sk_units, a.sk_grid, nch, ww + 1) >= (item + 1) * nch) break;
+    }
+    const Item it = decode_item<TRW>(a, item);
+    const int Ht = a.Ho >> 1, NR = a.B * Ht;
+    const int tl = tb * 32 + (lane & 31);
+    const int Rt = it.ty0 + tl / TRW;
+    const int ob = FLAT ? min(Rt, NR - 1) / Ht : it.b;
+    const int oy = 2 * (FLAT ? Rt - ob * Ht : Rt), ox = 2 * (it.tx0 + tl % TRW);
+    const bool inside = (FLAT ? Rt < NR : oy < a.Ho) && ox < a.Wo;
+    float* yb = a.y + (size_t)ob * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
+    const int kbase = it.k0 + kb * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int ko = kbase + (v & 3) + 8 * (v >> 2);
+        if (inside && ko < a.K) {
+            const float bs = a.bias ? a.bias[ko] : 0.f;
+            float* yp = yb + (size_t)ko * a.Ho * a.Wo;
+            *reinterpret_cast<float2*>(yp) = make_float2(acc[v][0] + bs, acc[v][1] + bs);
+            *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(acc[v][2] + bs, acc[v][3] + bs);
+        }
+    }
+}
+
 int num_cus() {
     static int n = 0;
     if (n == 0) {
@@ -551,10 +646,41 @@ int launch(WArgs& a, hipStream_t st) {
 
 // few regions (small images): split the channels of every region over two items so that the launch covers the chip
 template <int TRW, bool FLAT>
-int launch_split(WArgs& a, hipStream_t st, bool epi) {
+int launch_split(WArgs& a, hipStream_t st, bool epi, float* ws, int64_t ws_floats) {
     const int64_t regions = (int64_t)a.bitems * a.gx * a.gy * a.kg;
     if (regions >= ((int64_t)1 << 30)) return fail(DMH_EINVAL, "%s: too many work items", "dmh_wino_conv3x3");
     const int nch = a.C / CK;
+    a.part = nullptr; a.sk_units = 0; a.sk_grid = 0;
+    // Stream-K with a caller-provided workspace (plain convolutions only: a fused activation keeps whole items, and the
+    // windowed encoder launches stay bit-identical to their whole-frame twins).  A launch is as long as its slowest workgroup:
+    // with whole items that is ceil(items / CUs) x (one item's channel loop); here every workgroup gets the same number of
+    // (item, chunk) units and at most two partial items, whose sums meet in wino_sk_fixup_kernel.  Taken when the model below
+    // (3.05 us per chunk, ~4 us per item epilogue, ~6 us for the second launch: profiles/README.md) says it is >= 8 % faster.
+    if (!epi && ws) {
+        const int cus = num_cus();
+        const long long units = regions * nch;
+        const int G = (int)(units / 8 < cus ? units / 8 : cus);
+        if (G >= 2 && units < ((long long)1 << 30) && (long long)2 * G * SK_SLOT <= ws_floats) {
+            const int cs = (regions < (3 * cus) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;      // what the legacy path would do
+            const long long items = regions * cs;
+            const double t_cur = (double)((items + cus - 1) / cus) * ((nch / cs) * 3.05 + 4.0) + (cs > 1 ? 6.0 : 0.0);
+            const double per = (double)units / G;
+            const double t_sk = per * 3.05 + 4.0 * (per / nch + 1.5) + 6.0;
+            if (t_sk < 0.92 * t_cur) {
+                a.csplit = 1; a.nitems = (int)regions; a.part = ws; a.sk_units = (int)units; a.sk_grid = G;
+                static std::atomic<uint64_t> configured{0};
+                constexpr int TRH = 64 / TRW;
+                constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);
+                constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
+                if (configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, false, true>, smem, configured) != hipSuccess)
+                    return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
+                hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, false, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
+                if (int rc = check_launch("dmh_wino_conv3x3 (stream-K)")) return rc;
+                hipLaunchKernelGGL((wino_sk_fixup_kernel<TRW, FLAT>), dim3((unsigned)(G - 1)), dim3(NT), 0, st, a);
+                return check_launch("dmh_wino_conv3x3 (stream-K fix-up)");
+            }
+        }
+    }
     // (a fused activation needs the complete sum in one item: no split)
     a.csplit = (!epi && regions < (3 * num_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
     a.nitems = (int)regions * a.csplit;
@@ -596,7 +722,8 @@ int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float*
 }
 
 static int wino_conv_common(const float* x, const float* U, const float* bias, const float* residual, int relu, bool epi,
-                            int B, int C, int K, int H, int W, int pad, float* y, void* stream) {
+                            int B, int C, int K, int H, int W, int pad, float* y, void* stream, float* ws = nullptr,
+                            int64_t ws_floats = 0) {
     DMH_REQUIRE(x && U && y, "null pointer");
     DMH_REQUIRE(B > 0 && C >= 3 * CK && K > 0 && C % CK == 0, "input channels must be a multiple of 8, at least 24");
     DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
@@ -616,18 +743,25 @@ static int wino_conv_common(const float* x, const float* U, const float* bias, c
         // rows of tiles flattened over the batch when per-image regions would waste >= 1/5 of their tile rows
         if (5 * Ht <= 4 * ((Ht + 3) / 4 * 4) && (int64_t)B * C * H * W < ((int64_t)1 << 31)) {
             a.gy = (B * Ht + 3) / 4; a.bitems = 1;
-            return launch_split<16, true>(a, (hipStream_t)stream, epi);
+            return launch_split<16, true>(a, (hipStream_t)stream, epi, ws, ws_floats);
         }
         a.gy = (Ht + 3) / 4; a.bitems = B;
-        return launch_split<16, false>(a, (hipStream_t)stream, epi);
+        return launch_split<16, false>(a, (hipStream_t)stream, epi, ws, ws_floats);
     }
     a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2; a.bitems = B;
-    return launch_split<32, false>(a, (hipStream_t)stream, epi);
+    return launch_split<32, false>(a, (hipStream_t)stream, epi, ws, ws_floats);
 }
 
 int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
                      float* y, void* stream) {
     return wino_conv_common(x, U, bias, nullptr, 0, false, B, C, K, H, W, pad, y, stream);
+}
+
+int dmh_wino_conv3x3_ws(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                        float* y, float* workspace, int64_t workspace_floats, void* stream) {
+    DMH_REQUIRE(workspace == nullptr || workspace_floats > 0, "a workspace needs its size");
+    DMH_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "the workspace must be 16-byte aligned");
+    return wino_conv_common(x, U, bias, nullptr, 0, false, B, C, K, H, W, pad, y, stream, workspace, workspace_floats);
 }
 
 int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,

@@ -935,6 +935,7 @@ def _wino_filter(weight, backward, scale=None):
     return U
 
 
+WINO_SK = os.environ.get("DMH_WINO_SK", "1") != "0"       # A/B switch: stream-K decomposition of the plain K10 launches
 _WINO_MIN_ITEMS = int(os.environ.get("DMH_WINO_MIN_ITEMS", "200"))      # work items below which MIOpen is level or ahead (A/B switch)
 
 
@@ -961,6 +962,8 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     regions *= -(-n_out // 64)
     nch = n_in // 8
     split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
+    if allow_split and WINO_SK and regions * nch >= 8 * _WINO_MIN_ITEMS:
+        return True     # stream-K (_wino_conv): >= 8 channel chunks for each of >= 200 workgroups, however few the regions
     return regions * split >= _WINO_MIN_ITEMS
 
 
@@ -1024,13 +1027,26 @@ def _wino32_conv(x, U, bias, K, pad):
     return y
 
 
+_sk_ws = {}         # device -> workspace of the stream-K launches (caller-owned: the library keeps nothing)
+_SK_WS_FLOATS = 8 << 20         # 32 MB = 2 slots x 256 workgroups x 16,384 floats (one partial work item each)
+
+
 def _wino_conv(x, U, bias, K, pad):
     lib = N.lib()
     B, Cc, H, W = x.shape
     y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
     nb = 4 * (x.numel() + y.numel()) + 4 * U.numel()
-    N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad,
-                                                               N.ptr(y), N.stream()), nb, 18 * Cc * y.numel()))
+    ws = None
+    if WINO_SK:
+        # the library decides per launch (dmh_wino_conv3x3_ws): stream-K where whole work items would leave the chip idle for
+        # part of a round.  ONE buffer per device -- the launches of a stream are ordered, and the fix-up kernel that reads
+        # the partial items is enqueued right behind the kernel that wrote them
+        ws = _sk_ws.get(x.device)
+        if ws is None:
+            ws = _sk_ws[x.device] = torch.empty(_SK_WS_FLOATS, device=x.device, dtype=torch.float32)
+    N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_ws(
+        N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad, N.ptr(y), N.ptr(ws), 0 if ws is None else ws.numel(), N.stream()),
+        nb, 18 * Cc * y.numel()))
     return y
 
 

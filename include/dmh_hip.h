@@ -431,6 +431,15 @@ int64_t dmh_wino_weight_size(int n_out, int n_in);
 int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream);
 int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
                      float* y, void* stream);
+/* The same with a caller-owned workspace (device, 16-byte aligned, workspace_floats floats; the library keeps nothing).
+ * With whole work items (64 output channels x 64 tiles x ALL input channels) a launch lasts ceil(items / CUs) item times: 288
+ * items on 256 CUs take two rounds, 60 items leave 196 CUs idle.  Given a workspace of 2 * CUs * 16,384 floats (32 MB on
+ * MI355X) the launch is decomposed stream-K style instead: the (item, 8-channel chunk) units are dealt to the workgroups in
+ * equal contiguous ranges, a range that begins or ends inside an item stores that item's partial sums to the workspace,
+ * and a second kernel adds an item's pieces in chunk order + bias -- deterministic, no atomics, no zero fill.  Taken only
+ * where a cost model says it is faster; NULL / too small a workspace = dmh_wino_conv3x3. */
+int dmh_wino_conv3x3_ws(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                        float* y, float* workspace, int64_t workspace_floats, void* stream);
 /* conv -> BatchNorm(eval) -> (+ identity) -> ReLU of a BasicBlock in one launch (torchvision BasicBlock.forward under
  * MD2/networks/resnet_encoder.py:85-98, model in eval()): the per-channel scale is folded into the filter by
  * weight_transform_scaled (backward != 0: into the filter of the backward-data pass, whose input is then the masked

@@ -52,7 +52,11 @@ FWD_SHAPES = [("K10 layer1 64->64 @80x256", 12, 64, 64, 80, 256, 1),
               ("K10 layer3 256->256 @20x64", 12, 256, 256, 20, 64, 1),
               ("K10 upconv(2,1) 128->64 @82x258 pad0", 12, 128, 64, 82, 258, 0),
               ("K17 upconv(1,1) 96->32 @162x514 pad0", 12, 96, 32, 162, 514, 0),
-              ("K11 upconv(0,1) 16->16 @322x1026 pad0", 4, 16, 16, 322, 1026, 0)]
+              ("K11 upconv(0,1) 16->16 @322x1026 pad0", 4, 16, 16, 322, 1026, 0),
+              # stream-K launches (round 5): 60 regions (MIOpen until then), 144 regions = 288 half items on 256 CUs, 54 regions
+              ("K10 upconv(4,0) 512->256 @12x34 pad0 stream-K", 12, 512, 256, 12, 34, 0),
+              ("K10 upconv(4,1) window 512->256 @22x30 pad0 stream-K", 12, 512, 256, 22, 30, 0),
+              ("K10 upconv(3,0) window 256->128 @20x26 pad0 stream-K", 12, 256, 128, 20, 26, 0)]
 
 
 @pytest.mark.parametrize("shape", FWD_SHAPES, ids=[s[0].split(" @")[0].replace(" ", "_") for s in FWD_SHAPES])
@@ -199,3 +203,27 @@ def test_stem_weight_gradient_vs_fp64(shape):
     y2 = ops.stem_conv(xr, w)
     (gw3,) = torch.autograd.grad(y2, w, g)
     assert _rel(gw3, gw64) <= 2 * _rel(gw, gw64) + 1e-7
+
+
+def test_stream_k_is_deterministic_and_equals_whole_items():
+    """Stream-K launches of the plain K10 path (csrc/wino_conv.hip): run twice bit for bit, with a bias, ragged tile regions
+    included, and against the whole-item launch of the same kernel (DMH_WINO_SK switch) to fp32 re-association."""
+    from depthmodelhardening_amd import ops
+    for (B, C, K, H, W, pad) in ((12, 512, 256, 12, 34, 0), (12, 512, 256, 22, 30, 0), (12, 128, 256, 18, 24, 2),
+                                 (12, 128, 64, 52, 66, 0), (5, 64, 128, 28, 36, 2), (12, 512, 512, 10, 32, 1)):
+        x, w = _data(B, C, K, H, W, 21)
+        b = torch.randn(K, generator=torch.Generator().manual_seed(22)).cuda()
+        assert ops.WINO_SK
+        with ops.frozen_weights():
+            y1 = ops.conv3x3(x, w, b, pad)
+            y2 = ops.conv3x3(x, w, b, pad)
+            ops.WINO_SK = False
+            try:
+                y0 = ops.conv3x3(x, w, b, pad)      # whole items (2-way split with atomics, or MIOpen below the fill threshold)
+            finally:
+                ops.WINO_SK = True
+        assert torch.equal(y1, y2), (B, C, K, H, W)
+        y64 = F.conv2d(x.double(), w.double(), b.double(), 1, pad)
+        e1, e0 = _rel(y1, y64), _rel(y0, y64)
+        print("stream-K %s: rel-L2 vs fp64 %.3g (whole items / library %.3g)" % ((B, C, K, H, W, pad), e1, e0))
+        assert e1 <= 1.5 * e0 + 1e-7, (e1, e0)

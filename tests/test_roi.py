@@ -342,9 +342,10 @@ def test_l0_attack_with_windows_equals_attack_without():
     # direction in one of the runs and the later iterations compare gradients at (slightly) different patterns
     assert per_iter[0] <= 2e-6, per_iter
     assert max(per_iter) <= 0.25, per_iter
-    # Adam(lr = 0.5) turns the sign of a ~0 gradient into a step of 0.5: identical except on such texels
+    # Adam(lr = 0.5) turns the sign of a ~0 gradient into a step of 0.5: the same patterns (gradients that agree to 1e-6 move
+    # a texel by 5e-7 per iteration) except on such texels
     for x, y in ((pp0, pp1), (pn0, pn1), (pa0, pa1)):
-        assert ((x - y).abs() <= 1e-6).float().mean().item() > 0.999
+        assert ((x - y).abs() <= 1e-4).float().mean().item() > 0.999
 
 
 @pytest.mark.gpu

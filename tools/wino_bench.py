@@ -38,10 +38,15 @@ def transform(w, backward):
     return U
 
 
+import os
+WS = torch.empty(8 << 20, device=dev) if os.environ.get("WINO_WS", "1") != "0" else None     # stream-K workspace (WINO_WS=0: whole items)
+
+
 def wino_k10(x, U, bias, K, pad):
     Bn, C, H, W = x.shape
     y = torch.empty(Bn, K, H + 2 * pad - 2, W + 2 * pad - 2, device=dev)
-    N.check(lib.dmh_wino_conv3x3(N.ptr(x), N.ptr(U), N.ptr(bias), Bn, C, K, H, W, pad, N.ptr(y), N.stream()))
+    N.check(lib.dmh_wino_conv3x3_ws(N.ptr(x), N.ptr(U), N.ptr(bias), Bn, C, K, H, W, pad, N.ptr(y), N.ptr(WS),
+                                    0 if WS is None else WS.numel(), N.stream()))
     return y
 
 
@@ -57,7 +62,6 @@ def timeit(fn):
     return e0.elapsed_time(e1) / IT * 1e3
 
 
-import os
 if os.environ.get("WINO_SHAPES"):    # "C,K,Ho,Wo,pad;..." for scaling experiments
     SHAPES = [tuple(int(v) for v in t.split(",")) + ("custom",) for t in os.environ["WINO_SHAPES"].split(";")]
 print("batch %d, %d iterations; times in us, TF/s = direct-convolution flops / time" % (B, IT), flush=True)
