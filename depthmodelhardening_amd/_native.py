@@ -40,7 +40,7 @@ class PasteArgs(C.Structure):
     _fields_ = [("scene", _fp), ("scene_bstride", C.c_int64), ("patch", _fp), ("pmask", _fp), ("coeffs", _fp),
                 ("N", C.c_int), ("SH", C.c_int), ("SW", C.c_int), ("PH", C.c_int), ("PW", C.c_int),
                 ("OH", C.c_int), ("OW", C.c_int), ("l_pad", C.c_int), ("t_pad", C.c_int), ("mode", C.c_int),
-                ("flip", _fp)]
+                ("flip", _fp), ("scene_index", _fp)]
 
 
 class RoiGlueArgs(C.Structure):
@@ -85,6 +85,7 @@ _SIGNATURES = {
     "dmh_gt_depth_mse_bwd": (C.c_int, [_fp, _fp, _fp, C.c_int64, _fp, C.c_int, C.c_int64, C.c_float, C.c_float, _fp, _fp, _fp]),
     "dmh_ssim_map": (C.c_int, [_fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "dmh_ssim_map_bwd": (C.c_int, [_fp, _fp, _fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
+    "dmh_avg_pyramid": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp, _fp]),
     "dmh_edge_smooth_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dmh_edge_smooth": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [_fp, _fp, _fp]),
     "dmh_edge_smooth_bwd": (C.c_int, [_fp, _fp] + [C.c_int] * 4 + [_fp, _fp, _fp]),
@@ -123,6 +124,7 @@ _SIGNATURES = {
     "dmh_wino32_weight_size": (C.c_int64, [C.c_int, C.c_int]),
     "dmh_wino32_weight_transform": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "dmh_wino32_conv3x3": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp]),
+    "dmh_wino32_conv3x3_ws": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp, C.c_int64, _fp]),
     "dmh_wino_wrw_workspace_size": (C.c_int64, [C.c_int] * 6),
     "dmh_wino_wrw": (C.c_int, [_fp, _fp] + [C.c_int] * 6 + [_fp, _fp, _fp]),
     "dmh_conv3x3_small": (C.c_int, [_fp] * 3 + [C.c_int] * 7 + [_fp, _fp]),

@@ -133,6 +133,21 @@ __device__ __forceinline__ float2 normal_pair_from_bits(uint32_t u0, uint32_t u1
     return make_float2(rad * cs, rad * sn);
 }
 
+// ---- stream-K decomposition of the Winograd convolution kernels (K10 wino_conv.hip, K17 wino32_conv.hip) -------------------
+// first unit of workgroup w's range (w = 0 .. sk_grid).  A boundary inside an item is kept at least 3 chunks away from both
+// of the item's ends (the staging pipeline is 3 chunks deep); items of fewer than 6 chunks are never cut.
+__host__ __device__ inline int sk_boundary(int units, int grid, int nch, int w) {
+    const long long b = (long long)w * units / grid;
+    const int item = (int)(b / nch);
+    int c = (int)(b - (long long)item * nch);
+    if (c != 0) {
+        if (nch >= 6) c = c < 3 ? 3 : (c > nch - 3 ? nch - 3 : c);
+        else c = (2 * c < nch) ? 0 : nch;
+    }
+    return item * nch + c;
+}
+
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives a second GPU (or
 // launches from two threads) must not inherit a per-process "already configured" flag.  One bit per device ordinal, set
 // with release order after the attribute call succeeded; devices beyond 63 configure on every launch (cheap, correct).

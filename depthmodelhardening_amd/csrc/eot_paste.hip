@@ -138,7 +138,7 @@ __global__ __launch_bounds__(NT) void paste_fwd_kernel(const dmh_paste_args a, f
     const RTap r = resize_tap(oy, ox, a.SH, a.SW, a.OH, a.OW);
     const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW;
     const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
-    const float* sc = warp_only ? nullptr : a.scene + (size_t)n * a.scene_bstride;
+    const float* sc = warp_only ? nullptr : a.scene + (size_t)(a.scene_index ? a.scene_index[n] : n) * a.scene_bstride;
     const int Ys[2] = {r.y0, r.y1}, Xs[2] = {r.x0, r.x1};
     float comp[2][2][3], mm[2][2];
 #pragma unroll
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(NT) void paste_fwd4_kernel(const dmh_paste_args a, 
     const bool box_ok = bb.ok;
     const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW, ohw = (size_t)a.OH * a.OW;
     const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
-    const float* sc = warp_only ? nullptr : a.scene + (size_t)n * a.scene_bstride;
+    const float* sc = warp_only ? nullptr : a.scene + (size_t)(a.scene_index ? a.scene_index[n] : n) * a.scene_bstride;
     // source columns of the group
     int x0[4], x1[4];
     float lx[4];
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(NT) void paste_fwd_tile_kernel(const dmh_paste_args
     const int ne = nr * nc;
     const size_t shw = (size_t)a.SH * a.SW, phw = (size_t)a.PH * a.PW, ohw = (size_t)a.OH * a.OW;
     const bool warp_only = a.mode == DMH_PASTE_WARP_ONLY;
-    const float* sc = warp_only ? nullptr : a.scene + (size_t)n * a.scene_bstride;
+    const float* sc = warp_only ? nullptr : a.scene + (size_t)(a.scene_index ? a.scene_index[n] : n) * a.scene_bstride;
 
     // ---- 1a: scene rectangle -> LDS (mask plane 0)
     {

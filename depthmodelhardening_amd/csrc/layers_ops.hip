@@ -183,6 +183,62 @@ inline int red_blocks(int n) {
     return b < 1 ? 1 : (b > 256 ? 256 : b);
 }
 
+// ------------------------------------------------------------------------------------------------ colour pyramid
+// inputs[("color", 0, s)], s = 1 .. 3, of the GPU-side sample synthesis (the reference's loader builds them per sample on the
+// CPU, MD2/datasets/mono_dataset.py:119-144; here they are block means of the synthesised frame): the three average-pool
+// levels in ONE pass over the frame -- a thread owns an 8 x 8 block, reads it once and writes 16 + 4 + 1 means.  Every mean
+// is formed as ATen's avg_pool2d forms it (the window's values added row by row in float, then divided by the window size), so
+// the result is bit-identical to F.avg_pool2d(x, 2 / 4 / 8).
+__global__ __launch_bounds__(NT) void avg_pyramid_kernel(const float* __restrict__ x, int H, int W, float* __restrict__ o1,
+                                                         float* __restrict__ o2, float* __restrict__ o3, int64_t nblk) {
+    const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+    if (i >= nblk) return;
+    const int bw = W >> 3, bh = H >> 3;
+    const int bx = (int)(i % bw);
+    const int by = (int)((i / bw) % bh);
+    const int64_t pl = i / ((int64_t)bw * bh);
+    const float* src = x + (pl * H + 8 * by) * (int64_t)W + 8 * bx;
+    float v[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const float4 a = *reinterpret_cast<const float4*>(src + (int64_t)r * W);
+        const float4 b = *reinterpret_cast<const float4*>(src + (int64_t)r * W + 4);
+        v[r][0] = a.x; v[r][1] = a.y; v[r][2] = a.z; v[r][3] = a.w; v[r][4] = b.x; v[r][5] = b.y; v[r][6] = b.z; v[r][7] = b.w;
+    }
+    const int W1 = W >> 1, W2 = W >> 2, W3 = W >> 3;
+    float* d1 = o1 + (pl * (H >> 1) + 4 * by) * (int64_t)W1 + 4 * bx;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float4 m;
+        m.x = (((v[2 * r][0] + v[2 * r][1]) + v[2 * r + 1][0]) + v[2 * r + 1][1]) / 4.f;
+        m.y = (((v[2 * r][2] + v[2 * r][3]) + v[2 * r + 1][2]) + v[2 * r + 1][3]) / 4.f;
+        m.z = (((v[2 * r][4] + v[2 * r][5]) + v[2 * r + 1][4]) + v[2 * r + 1][5]) / 4.f;
+        m.w = (((v[2 * r][6] + v[2 * r][7]) + v[2 * r + 1][6]) + v[2 * r + 1][7]) / 4.f;
+        *reinterpret_cast<float4*>(d1 + (int64_t)r * W1) = m;
+    }
+    float* d2 = o2 + (pl * (H >> 2) + 2 * by) * (int64_t)W2 + 2 * bx;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        float m[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            float acc = 0.f;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) acc += v[4 * r + rr][4 * c + cc];
+            m[c] = acc / 16.f;
+        }
+        *reinterpret_cast<float2*>(d2 + (int64_t)r * W2) = make_float2(m[0], m[1]);
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 8; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) acc += v[rr][cc];
+    o3[(pl * (H >> 3) + by) * (int64_t)W3 + bx] = acc / 64.f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -225,6 +281,17 @@ int dmh_edge_smooth_bwd(const float* disp, const float* img, int B, int C, int H
     hipLaunchKernelGGL(edge_smooth_bwd_kernel, dim3(blocks_for((int64_t)H * W), B), dim3(NT), 0, (hipStream_t)stream, disp, img, C,
                        H, W, gscale, (float)(1.0 / ((double)B * H * (W - 1))), (float)(1.0 / ((double)B * (H - 1) * W)), g_disp);
     return check_launch("dmh_edge_smooth_bwd");
+}
+
+int dmh_avg_pyramid(const float* x, int planes, int H, int W, float* out1, float* out2, float* out3, void* stream) {
+    DMH_REQUIRE(x && out1 && out2 && out3, "null pointer");
+    DMH_REQUIRE(planes > 0 && H >= 8 && W >= 8 && H % 8 == 0 && W % 8 == 0, "H and W must be multiples of 8");
+    DMH_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)out1 & 15) == 0 && ((uintptr_t)out2 & 7) == 0, "pointers must be 16-byte aligned");
+    const int64_t nblk = (int64_t)planes * (H / 8) * (W / 8);
+    DMH_REQUIRE(nblk < ((int64_t)1 << 31) * NT, "too many blocks");
+    hipLaunchKernelGGL(avg_pyramid_kernel, dim3((unsigned)((nblk + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, x, H, W, out1,
+                       out2, out3, nblk);
+    return check_launch("dmh_avg_pyramid");
 }
 
 }  // extern "C"

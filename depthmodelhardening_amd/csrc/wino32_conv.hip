@@ -50,7 +50,10 @@ struct W32Args {
     int B, C, K, Kp, H, W, Ho, Wo, pad;
     int gx, gy, kg;              // tile-region groups along x / y, output-channel groups of 32
     int nitems;                  // B * gy * gx * kg
+    float* part;                 // SK: workspace of the partial items (2 * sk_grid slots of SK_SLOT floats), see K10
+    int sk_units, sk_grid;       // SK: nitems * C/8 (item, chunk) units dealt to sk_grid workgroups in equal contiguous ranges
 };
+constexpr int SK_SLOT = 16 * NT * 4;      // floats of one partial item: [output channel v 16][thread 256] float4 (y00, y01, y10, y11)
 
 struct Item { int b, ty0, tx0, k0; };
 
@@ -63,6 +66,7 @@ __device__ __forceinline__ Item decode_item(const W32Args& a, int item) {
     return it;
 }
 
+template <bool SK>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino32_conv_kernel(W32Args a) {
     extern __shared__ f32x4 smem[];
     f32x4* U_lds = smem;                                        // [2][16][2][32]
@@ -74,10 +78,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const size_t HW = (size_t)a.H * a.W;
     const int nch = a.C / CK;
 
-    const int q = a.nitems / (int)gridDim.x, r = a.nitems % (int)gridDim.x;
-    const int item0 = (int)blockIdx.x * q + min((int)blockIdx.x, r);
-    const int nmine = q + ((int)blockIdx.x < r ? 1 : 0);
+    int item0, nmine, cb0 = 0, ce_last = nch;   // SK: the first piece starts at chunk cb0 of item0, the last ends before ce_last
+    if (SK) {       // equal ranges of (item, chunk) units: a range may begin and end inside an item (K10, wino_conv.hip)
+        const int u0 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x);
+        const int u1 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x + 1);
+        if (u0 >= u1) return;
+        item0 = u0 / nch;
+        const int il = (u1 - 1) / nch;
+        nmine = il - item0 + 1;
+        cb0 = u0 - item0 * nch;
+        ce_last = u1 - il * nch;
+    } else {
+        const int q = a.nitems / (int)gridDim.x, r = a.nitems % (int)gridDim.x;
+        item0 = (int)blockIdx.x * q + min((int)blockIdx.x, r);
+        nmine = q + ((int)blockIdx.x < r ? 1 : 0);
+    }
     const int item_last = item0 + nmine - 1;
+    int pn = nch;           // channel chunks of the current piece (SK: a partial item has fewer)
 
     // transform role: wave wv owns chunk channels {2wv, 2wv+1} = (h = wv>>1, s = 2(wv&1) + {0,1}); a lane transforms the two
     // vertically adjacent tiles (rows 2 (lane >> 5), + 1; column lane & 31) of the region (tile t = row t/32, column t%32)
@@ -95,6 +112,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // load; padded elements carry the offset 0xFFFFFFFF and read 0 (no clamp, no mask)
     const rsrc_t xrs = make_rsrc(a.x, (unsigned)((size_t)a.B * a.C * HW * 4));
     const rsrc_t urs = make_rsrc(a.U, (unsigned)((size_t)nch * 32 * a.Kp * 16));
+    const rsrc_t prs = make_rsrc(SK ? (const void*)a.part : (const void*)a.U, SK ? (unsigned)(2 * a.sk_grid) * (unsigned)(SK_SLOT * 4) : 16u);
     unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
     unsigned uoff = 0, uoff_n = 0;
     int ixa = 0, ixa_n = 0;
@@ -107,8 +125,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         int tid_o;                                                                                \
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tid_o)); \
         tid_o += wv_s * 64;                                                                       \
-        UOFF = (unsigned)it.k0 * 16u;                                                             \
-        const int cbase = it.b * a.C * (int)HW;                                                   \
+        const int cb_ = (SK && (ITEM) == item0) ? cb0 : 0;    /* a workgroup's first piece may start inside its item */ \
+        UOFF = (unsigned)it.k0 * 16u + (unsigned)cb_ * (unsigned)(32 * a.Kp * 16);                \
+        const int cbase = (it.b * a.C + cb_ * CK) * (int)HW;                                      \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
             const int c = e / (RH * NWR), rem = e - c * (RH * NWR), rr = rem / NWR, xx = 4 * (rem - rr * NWR); \
@@ -207,12 +226,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
         DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n, ixa_n)
-        for (int ch = 0; ch < nch; ++ch, ++g) {
+        if (SK) pn = (item == item_last ? ce_last : nch) - (item == item0 ? cb0 : 0);
+        for (int ch = 0; ch < pn; ++ch, ++g) {
             const int cur = g & 1, nxt = cur ^ 1;
             const f32x4* Uc = U_lds + cur * UBUF + aidx;
             const f32x4* Vc = V_lds + bidx;
-            const bool r_next = ch + 3 >= nch, u_next = ch + 1 >= nch;
-            unsigned xcb = (unsigned)(r_next ? ch + 3 - nch : ch + 3) * chunk_bytes;
+            const bool r_next = ch + 3 >= pn, u_next = ch + 1 >= pn;
+            unsigned xcb = (unsigned)(r_next ? ch + 3 - pn : ch + 3) * chunk_bytes;
             asm volatile("" : "+s"(xcb));          // a scalar offset parked in a VGPR would make every load a waterfall loop
             const unsigned ucb = u_next ? uoff_n : uoff + (unsigned)(ch + 1) * uchunk_bytes;
             f32x4 ua[16], vb[16];
@@ -234,7 +254,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     DMH_W32_GLDS_U_ROW(ucb, nxt, sl)
                 } else if (sl >= 8 && sl < 8 + RAW_PER_T) {  // raw registers (chunk g+2) -> raw[cur], then refill (chunk g+3)
                     const int k = sl - 8;
-                    DMH_W32_WRITE1(k, cur, (ch + 2 >= nch) ? ixa_n : ixa)
+                    DMH_W32_WRITE1(k, cur, (ch + 2 >= pn) ? ixa_n : ixa)
                     DMH_W32_LOAD1(k, xcb, r_next ? roff_n[k] : roff[k])
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -266,7 +286,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     s0[j] = acc[j][v] + acc[4 + j][v] + acc[8 + j][v];
                     s1[j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
                 }
-                if (inside && ko < a.K) {
+                if (SK && pn < nch) {       // a partial item: its raw sums to the workgroup's slot (wino32_sk_fixup_kernel adds them)
+                    const int slot = 2 * (int)blockIdx.x + ((item != item0 && item == item_last) ? 1 : 0);
+                    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slot * 16 + v) * (NT * 16));
+                    const f32x4 pv = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pv),
+                                                           prs, (unsigned)(wv_s * 64 + lane_o) * 16u, soff, 0);
+                } else if (inside && ko < a.K) {
                     const float bs = a.bias ? a.bias[ko] : 0.f;
                     const float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
                     const float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
@@ -285,6 +311,46 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
         uoff = uoff_n;
         ixa = ixa_n;
+    }
+}
+
+// Stream-K second stage (see wino_sk_fixup_kernel in wino_conv.hip): the workgroup of an item's FIRST cut adds the item's partial
+// pieces in chunk order, adds the bias and writes the outputs with the main kernel's thread -> (tile, channel) map.
+__global__ __launch_bounds__(NT) void wino32_sk_fixup_kernel(W32Args a) {
+    const int nch = a.C / CK;
+    const int w = (int)blockIdx.x + 1;
+    const int b = sk_boundary(a.sk_units, a.sk_grid, nch, w);
+    const int item = b / nch;
+    if (b == item * nch) return;
+    const int bp = sk_boundary(a.sk_units, a.sk_grid, nch, w - 1);
+    if (bp > item * nch) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const f32x4* part = reinterpret_cast<const f32x4*>(a.part);
+    f32x4 acc[16];
+    {
+        const int slot = 2 * (w - 1) + (bp == item * nch ? 0 : 1);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] = part[((size_t)slot * 16 + v) * NT + tid];
+    }
+    for (int ww = w;; ++ww) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) acc[v] += part[((size_t)(2 * ww) * 16 + v) * NT + tid];
+        if (sk_boundary(a.sk_units, a.sk_grid, nch, ww + 1) >= (item + 1) * nch) break;
+    }
+    const Item it = decode_item(a, item);
+    const int oy = 2 * (it.ty0 + wv), ox = 2 * (it.tx0 + (lane & 31));
+    const bool inside = oy < a.Ho && ox < a.Wo;
+    float* yb = a.y + (size_t)it.b * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
+    const int kbase = it.k0 + 4 * (lane >> 5);
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int ko = kbase + (v & 3) + 8 * (v >> 2);
+        if (inside && ko < a.K) {
+            const float bs = a.bias ? a.bias[ko] : 0.f;
+            float* yp = yb + (size_t)ko * a.Ho * a.Wo;
+            *reinterpret_cast<float2*>(yp) = make_float2(acc[v][0] + bs, acc[v][1] + bs);
+            *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(acc[v][2] + bs, acc[v][3] + bs);
+        }
     }
 }
 
@@ -360,8 +426,8 @@ int dmh_wino32_weight_transform(const float* w, int K, int C, int backward, floa
     return check_launch("dmh_wino32_weight_transform");
 }
 
-int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
-                       float* y, void* stream) {
+static int wino32_common(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                         float* y, float* ws, int64_t ws_floats, void* stream) {
     DMH_REQUIRE(x && U && y, "null pointer");
     DMH_REQUIRE(B > 0 && C >= 3 * CK && K > 0 && C % CK == 0, "input channels must be a multiple of 8, at least 24");
     DMH_REQUIRE(pad >= 0 && pad <= 2, "pad must be 0, 1 or 2");
@@ -380,12 +446,48 @@ int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B,
     DMH_REQUIRE(items < ((int64_t)1 << 30), "too many work items");
     a.nitems = (int)items;
     constexpr size_t smem = (size_t)(2 * UBUF + VBUF) * 16 + (size_t)2 * RAW_BUF * 4;
+    a.part = nullptr; a.sk_units = 0; a.sk_grid = 0;
+    const int cus = num_cus();
+    // stream-K with a caller-provided workspace, where the cost model (3.4 us per chunk of this kernel, 4 us per item epilogue,
+    // 6 us for the second launch) predicts >= 8 % over whole items: see launch_split() in wino_conv.hip
+    if (ws) {
+        const int nch = C / CK;
+        const long long units = items * nch;
+        const int G = (int)(units / 8 < cus ? units / 8 : cus);
+        if (G >= 2 && units < ((long long)1 << 30) && (long long)2 * G * SK_SLOT <= ws_floats) {
+            const double t_cur = (double)((items + cus - 1) / cus) * (nch * 3.4 + 4.0);
+            const double per = (double)units / G;
+            const double t_sk = per * 3.4 + 4.0 * (per / nch + 1.5) + 6.0;
+            if (t_sk < 0.92 * t_cur) {
+                a.part = ws; a.sk_units = (int)units; a.sk_grid = G;
+                static std::atomic<uint64_t> configured_sk{0};
+                if (configure_dynamic_lds(wino32_conv_kernel<true>, smem, configured_sk) != hipSuccess)
+                    return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino32_conv3x3");
+                hipLaunchKernelGGL(wino32_conv_kernel<true>, dim3((unsigned)G), dim3(NT), smem, (hipStream_t)stream, a);
+                if (int rc = check_launch("dmh_wino32_conv3x3 (stream-K)")) return rc;
+                hipLaunchKernelGGL(wino32_sk_fixup_kernel, dim3((unsigned)(G - 1)), dim3(NT), 0, (hipStream_t)stream, a);
+                return check_launch("dmh_wino32_conv3x3 (stream-K fix-up)");
+            }
+        }
+    }
     static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
-    if (configure_dynamic_lds(wino32_conv_kernel, smem, configured) != hipSuccess)
+    if (configure_dynamic_lds(wino32_conv_kernel<false>, smem, configured) != hipSuccess)
         return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino32_conv3x3");
-    const int grid = a.nitems < num_cus() ? a.nitems : num_cus();
-    hipLaunchKernelGGL(wino32_conv_kernel, dim3((unsigned)grid), dim3(NT), smem, (hipStream_t)stream, a);
+    const int grid = a.nitems < cus ? a.nitems : cus;
+    hipLaunchKernelGGL(wino32_conv_kernel<false>, dim3((unsigned)grid), dim3(NT), smem, (hipStream_t)stream, a);
     return check_launch("dmh_wino32_conv3x3");
+}
+
+int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                       float* y, void* stream) {
+    return wino32_common(x, U, bias, B, C, K, H, W, pad, y, nullptr, 0, stream);
+}
+
+int dmh_wino32_conv3x3_ws(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                          float* y, float* workspace, int64_t workspace_floats, void* stream) {
+    DMH_REQUIRE(workspace == nullptr || workspace_floats > 0, "a workspace needs its size");
+    DMH_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "the workspace must be 16-byte aligned");
+    return wino32_common(x, U, bias, B, C, K, H, W, pad, y, workspace, workspace_floats, stream);
 }
 
 }  // extern "C"

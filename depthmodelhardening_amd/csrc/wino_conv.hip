@@ -68,19 +68,6 @@ struct WArgs {
 };
 constexpr int SK_SLOT = 16 * NT * 4;      // floats of one partial item: [output channel v 16][thread 256] float4 (y00, y01, y10, y11)
 
-// first unit of workgroup w's range (w = 0 .. sk_grid).  A boundary inside an item is kept at least 3 chunks away from both
-// of the item's ends (the staging pipeline is 3 chunks deep); items of fewer than 6 chunks are never cut.
-__host__ __device__ inline int sk_boundary(int units, int grid, int nch, int w) {
-    const long long b = (long long)w * units / grid;
-    const int item = (int)(b / nch);
-    int c = (int)(b - (long long)item * nch);
-    if (c != 0) {
-        if (nch >= 6) c = c < 3 ? 3 : (c > nch - 3 ? nch - 3 : c);
-        else c = (2 * c < nch) ? 0 : nch;
-    }
-    return item * nch + c;
-}
-
 // pre-transform the filter: U = G g G^T, scattered into the chunked layout the kernel streams.
 // mode 0: forward   u[k][c] from w[k][c][ky][kx]
 // mode 1: backward  u[c][k] from w[k][c][2-ky][2-kx]   (output channels of the pass = C of the filter)

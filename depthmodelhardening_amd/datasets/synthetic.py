@@ -51,11 +51,14 @@ class SyntheticKITTIDataset(object):
         self.gen = torch.Generator(device=self.device).manual_seed(seed)
         self.rng = random.Random(seed)
         self.pool_size = pool or 48
-        self.raw_left = kitti_like(self.pool_size, 3, ori_H, ori_W, self.device, self.gen)
+        raw_left = kitti_like(self.pool_size, 3, ori_H, ori_W, self.device, self.gen)
         # right view = left rolled 8 px (at 1024 wide) plus independent texture, so photometric error is non-trivial
         shift = max(2, int(round(8 * ori_W / 1024.0)))
-        self.raw_right = (0.9 * torch.roll(self.raw_left, shift, 3) +
-                          0.1 * kitti_like(self.pool_size, 3, ori_H, ori_W, self.device, self.gen)).contiguous()
+        raw_right = 0.9 * torch.roll(raw_left, shift, 3) + 0.1 * kitti_like(self.pool_size, 3, ori_H, ori_W, self.device, self.gen)
+        # ONE pool [2 P, 3, 375, 1242]: left frames, then right frames.  The synthesis reads its frames out of it by index
+        # (K3's scene_index) -- no index_select / side-pick copies of 32 full-resolution frames per batch
+        self.raw = torch.cat([raw_left, raw_right], 0).contiguous()
+        self.raw_left, self.raw_right = self.raw[:self.pool_size], self.raw[self.pool_size:]
         self.is_adv_train = False
         self.load_ben_color = False
         self.half_no_synthesis = False
@@ -65,6 +68,7 @@ class SyntheticKITTIDataset(object):
         self.flip_augmentation = True
         self.reference_stale_patch = False
         self.make_depth_hints = False
+        self.right_pyramid = False      # ("color", "s", s > 0): only --v1_multiscale reads them (MD2/trainer.py:478-483)
         self._epoch_patch = None
         self.K = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
         stereo_T = np.eye(4, dtype=np.float32)
@@ -132,15 +136,22 @@ class SyntheticKITTIDataset(object):
             geo["alpha"].append(self.rng.choice(self.adv_trans.angle_range) if self.is_adv_train else 0)
         return geo
 
-    def synthesize(self, raw_l, raw_r, geo, out_size):
+    def synthesize(self, raw_l, raw_r, geo, out_size, pool_index=None):
         """GPU-side ``prep_adv_data`` (mono_dataset.py:186-265) for a whole batch: frame 0 gets the adversarial object,
         the opposite stereo view and ``color_ben`` the benign one; with ``side == "r"`` frame 0 is the right image and
         the frame-0 geometry goes through ``project_w_trans(stereo_T)`` (:205-211), with ``do_flip`` the projected
         object and mask are mirrored onto the mirrored frame (:222-225).  Three K3 launches.
-        Returns (color_aug_0, color_aug_s, color_ben_0, objmask_0)."""
+        Returns (color_aug_0, color_aug_s, color_ben_0, objmask_0).
+        ``pool_index`` = (index of frame 0, index of the opposite view) per sample into ``self.raw`` (int32 device tensors):
+        the frames are then read in place by K3 and raw_l / raw_r are not touched."""
         dev = self.device
-        n = raw_l.shape[0]
-        frame0, frame_s = self._pick_sides(raw_l, raw_r, geo["side"])
+        n = len(geo["side"])
+        if pool_index is None:
+            frame0, frame_s = self._pick_sides(raw_l, raw_r, geo["side"])
+            i0 = i_s = None
+        else:
+            frame0 = frame_s = self.raw
+            i0, i_s = pool_index
         K, T = self.adv_K, self.stereo_T
         far = np.array([1, 0, 1e7, 0, 1, 1e7, 0, 0], dtype=np.float32)      # object lands outside the frame: no synthesis
         # coefficient tables only for the cameras this batch uses (all-left batches never need the frame-0 table through
@@ -160,9 +171,9 @@ class SyntheticKITTIDataset(object):
         patch = self._epoch_patch if (self.reference_stale_patch and self._epoch_patch is not None) else self.obj_img_adv
         lp, tp = self.adv_trans.l_pad, self.adv_trans.t_pad
         with torch.no_grad():
-            aug0, _ = ops.eot_paste(frame0, patch, self.obj_mask, c0, lp, tp, out_size, flip)
-            aug_s, _ = ops.eot_paste(frame_s, self.obj_img_ben, self.obj_mask, cs, lp, tp, out_size, flip)
-            ben0, mask0 = ops.eot_paste(frame0, self.obj_img_ben, self.obj_mask, c0, lp, tp, out_size, flip)
+            aug0, _ = ops.eot_paste(frame0, patch, self.obj_mask, c0, lp, tp, out_size, flip, i0)
+            aug_s, _ = ops.eot_paste(frame_s, self.obj_img_ben, self.obj_mask, cs, lp, tp, out_size, flip, i_s)
+            ben0, mask0 = ops.eot_paste(frame0, self.obj_img_ben, self.obj_mask, c0, lp, tp, out_size, flip, i0)
         return aug0, aug_s, ben0, mask0
 
     def _pick_sides(self, raw_l, raw_r, sides):
@@ -177,12 +188,15 @@ class SyntheticKITTIDataset(object):
 
     def next_batch(self, batch_size):
         dev, H, W = self.device, self.height, self.width
-        idx = to_device_async([self.rng.randrange(self.pool_size) for _ in range(batch_size)], dev, torch.int64)
-        raw_l, raw_r = self.raw_left.index_select(0, idx), self.raw_right.index_select(0, idx)
+        picks = [self.rng.randrange(self.pool_size) for _ in range(batch_size)]
         geo = self.draw_batch_geometry(batch_size)
         inputs = {}
         if self.is_adv_train:
-            aug0, aug_s, ben0, mask0 = self.synthesize(raw_l, raw_r, geo, (H, W))
+            # frame 0 / opposite view of every sample as indices into the pool (left frames first, then right): K3 reads them there
+            P = self.pool_size
+            both = to_device_async([[p + (0 if sd == "l" else P) for p, sd in zip(picks, geo["side"])],
+                                    [p + (P if sd == "l" else 0) for p, sd in zip(picks, geo["side"])]], dev, torch.int32)
+            aug0, aug_s, ben0, mask0 = self.synthesize(None, None, geo, (H, W), pool_index=(both[0], both[1]))
             inputs[("color_aug", 0, 0)] = aug0
             inputs[("color_ben", 0, 0)] = ben0
             if not self.half_no_synthesis:      # mono_dataset.py:248-250
@@ -190,6 +204,8 @@ class SyntheticKITTIDataset(object):
                 inputs[("objdepth", 0, 0)] = to_device_async(geo["z0"], dev, torch.float32).view(batch_size, 1)
             left, right = ben0, aug_s           # inputs[("color",0,-1)] = color_ben, ("color","s",-1) = color_aug("s"), :252-253
         else:
+            idx = to_device_async(picks, dev, torch.int64)
+            raw_l, raw_r = self.raw_left.index_select(0, idx), self.raw_right.index_select(0, idx)
             f0, fs = self._pick_sides(raw_l, raw_r, geo["side"])
             left = F.interpolate(f0, [H, W], mode="bilinear", align_corners=False)
             right = F.interpolate(fs, [H, W], mode="bilinear", align_corners=False)
@@ -197,9 +213,16 @@ class SyntheticKITTIDataset(object):
                 fl = to_device_async(geo["flip"], dev, torch.bool).view(batch_size, 1, 1, 1)
                 left, right = torch.where(fl, left.flip(3), left), torch.where(fl, right.flip(3), right)
             inputs[("color_aug", 0, 0)] = left
-        for s in range(self.num_scales):
-            inputs[("color", 0, s)] = left if s == 0 else F.avg_pool2d(left, 2 ** s)
-            inputs[("color", "s", s)] = right if s == 0 else F.avg_pool2d(right, 2 ** s)
+        fused = left.is_cuda and self.num_scales == 4 and H % 8 == 0 and W % 8 == 0
+        for view, img in ((0, left), ("s", right)):
+            # the three coarser levels in one pass (ops.avg_pyramid: bit-identical to F.avg_pool2d); the opposite view's levels
+            # are read by --v1_multiscale only, so they are built when somebody asks for them
+            inputs[("color", view, 0)] = img
+            if view == "s" and not self.right_pyramid:
+                continue
+            levels = ops.avg_pyramid(img) if fused else [F.avg_pool2d(img, 2 ** s) for s in range(1, self.num_scales)]
+            for s in range(1, self.num_scales):
+                inputs[("color", view, s)] = levels[s - 1]
         if self.make_depth_hints:
             # stand-in for DepthHints' precomputed SGM estimates (DH/datasets/mono_dataset.py:368-388): a smooth depth field
             # with holes; inputs["depth_hint_mask"] = (hint > 0)

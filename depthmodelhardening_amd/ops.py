@@ -324,7 +324,7 @@ def warp_view(source, disp, K, inv_K, T, H, W, min_depth=0.1, max_depth=100.0):
                            float(max_depth))
 
 
-def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_COMPOSITE, flip=None):
+def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_COMPOSITE, flip=None, scene_index=None):
     a = N.PasteArgs()
     if flip is not None:
         if flip.dtype != torch.int32 or flip.numel() != coeffs.shape[0]:
@@ -332,7 +332,11 @@ def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_
         a.flip = N.ptr(flip)
     n = coeffs.shape[0]
     a.mode = mode
-    if scene.shape[0] not in (1, n) or scene.shape[1] != 3:
+    if scene_index is not None:     # `scene` is a pool of frames; sample i reads frame scene_index[i] (range-checked by the caller)
+        if scene_index.dtype != torch.int32 or scene_index.numel() != n or scene.shape[1] != 3:
+            raise RuntimeError("eot_paste: scene_index must be an int32 tensor with one frame index per sample")
+        a.scene_index = N.ptr(scene_index)
+    elif scene.shape[0] not in (1, n) or scene.shape[1] != 3:
         raise RuntimeError("Batch size doesn't match!")
     if patch.dim() != 4 or patch.shape[0] != 1 or patch.shape[1] != 3 or tuple(pmask.shape) != (1, 1) + tuple(patch.shape[2:]):
         raise RuntimeError("eot_paste: patch must be [1,3,PH,PW] and mask [1,1,PH,PW]")
@@ -340,7 +344,7 @@ def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_
         raise RuntimeError("eot_paste: coeffs must be [N,8]")
     a.scene = N.ptr(scene) if mode == N.PASTE_COMPOSITE else None
     a.patch, a.pmask, a.coeffs = N.ptr(patch), N.ptr(pmask), N.ptr(coeffs)
-    a.scene_bstride = 0 if scene.shape[0] == 1 else scene.shape[1] * scene.shape[2] * scene.shape[3]
+    a.scene_bstride = 0 if (scene.shape[0] == 1 and scene_index is None) else scene.shape[1] * scene.shape[2] * scene.shape[3]
     a.N, a.SH, a.SW = n, scene.shape[2], scene.shape[3]
     a.PH, a.PW, a.OH, a.OW = patch.shape[2], patch.shape[3], OH, OW
     a.l_pad, a.t_pad = l_pad, t_pad
@@ -349,18 +353,20 @@ def _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode=N.PASTE_
 
 class _EotPaste(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, flip=None):
+    def forward(ctx, scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, flip=None, scene_index=None):
         lib = N.lib()
-        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, flip)
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, flip, scene_index)
         adv = torch.empty((a.N, 3, OH, OW), device=scene.device, dtype=torch.float32)
         mask_out = torch.empty((a.N, 1, OH, OW), device=scene.device, dtype=torch.float32)
         # algorithmic bytes: the scene read once (one copy when it is broadcast) + patch and mask + the two outputs
-        nb = 4 * (scene.numel() + patch.numel() + pmask.numel() + adv.numel() + mask_out.numel()) if mode == N.PASTE_COMPOSITE \
+        n_scene = scene.numel() if scene_index is None else a.N * 3 * a.SH * a.SW      # frames read, not the pool's size
+        nb = 4 * (n_scene + patch.numel() + pmask.numel() + adv.numel() + mask_out.numel()) if mode == N.PASTE_COMPOSITE \
             else 4 * (patch.numel() + pmask.numel() + adv.numel() + mask_out.numel())
         N.check(_timed("paste_fwd", lambda: lib.dmh_eot_paste_fwd(C.byref(a), N.ptr(adv), N.ptr(mask_out), N.stream()), nb))
         ctx.save_for_backward(scene, patch, pmask, coeffs)
         ctx.geo = (l_pad, t_pad, OH, OW, mode)
         ctx.flip = flip
+        ctx.scene_index = scene_index
         ctx.mark_non_differentiable(mask_out)
         return adv, mask_out
 
@@ -369,20 +375,22 @@ class _EotPaste(torch.autograd.Function):
         scene, patch, pmask, coeffs = ctx.saved_tensors
         l_pad, t_pad, OH, OW, mode = ctx.geo
         lib = N.lib()
-        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, ctx.flip)
+        a = _paste_args(scene, patch, pmask, coeffs, l_pad, t_pad, OH, OW, mode, ctx.flip, ctx.scene_index)
         g_patch = torch.empty_like(patch)
         g_adv = _c(g_adv)
         N.check(_timed("paste_bwd", lambda: lib.dmh_eot_paste_bwd(C.byref(a), N.ptr(g_adv), N.ptr(g_patch), N.stream()),
                        4 * (g_adv.numel() + g_patch.numel())))
-        return None, g_patch, None, None, None, None, None, None, None, None
+        return None, g_patch, None, None, None, None, None, None, None, None, None
 
 
-def eot_paste(scene, patch, pmask, coeffs, l_pad, t_pad, out_size, flip=None):
+def eot_paste(scene, patch, pmask, coeffs, l_pad, t_pad, out_size, flip=None, scene_index=None):
     """Pad -> perspective(patch, mask) -> composite -> Resize, fused (physicalTrans.py:107-166 +
     phy_obj_atk.py:87-90).  Returns (adv [N,3,OH,OW], mask_out [N,1,OH,OW]); differentiable w.r.t. patch.
-    ``flip`` (int32 [N], optional): samples to mirror horizontally (mono_dataset.py:222-225 on an un-flipped scene)."""
+    ``flip`` (int32 [N], optional): samples to mirror horizontally (mono_dataset.py:222-225 on an un-flipped scene).
+    ``scene_index`` (int32 [N], optional): ``scene`` is a POOL of frames [P,3,SH,SW] and sample i reads frame scene_index[i]
+    -- the loader's choice of frames and camera sides without copying them (the caller guarantees 0 <= index < P)."""
     return _EotPaste.apply(_c(scene), _c(patch), _c(pmask), _c(coeffs), int(l_pad), int(t_pad), int(out_size[0]),
-                           int(out_size[1]), N.PASTE_COMPOSITE, flip)
+                           int(out_size[1]), N.PASTE_COMPOSITE, flip, scene_index)
 
 
 def perspective_warp(patch, pmask, coeffs, l_pad, t_pad, frame_size):
@@ -471,6 +479,18 @@ def gt_depth_mse(disp, disp_gt, objmask, objdepth, min_depth=0.1, max_depth=100.
     pred / pseudo depth = clamp(disp_to_depth(.)[1] * 5.4, 1e-3, 80) and gt_depth = m objdepth + pseudo (1 - m), m = channel 0
     of color_objmask.  One fused pass forward, one backward (gradient w.r.t. ``disp`` only: disp_gt is the frozen teacher's)."""
     return _GtDepthMse.apply(disp, disp_gt.detach(), objmask, objdepth, min_depth, max_depth)
+
+
+def avg_pyramid(x):
+    """[F.avg_pool2d(x, 2), F.avg_pool2d(x, 4), F.avg_pool2d(x, 8)] of a [B,C,H,W] frame (H, W multiples of 8) in ONE launch,
+    bit-identical to the three ATen calls: the colour pyramid inputs[("color", f, s)] of the GPU-side sample synthesis (no
+    gradient: the frames are data)."""
+    x = _c(x.detach())
+    B, Cc, H, W = x.shape
+    outs = [torch.empty((B, Cc, H >> s, W >> s), device=x.device, dtype=torch.float32) for s in (1, 2, 3)]
+    N.check(_timed("avg_pyramid", lambda: N.lib().dmh_avg_pyramid(N.ptr(x), B * Cc, H, W, N.ptr(outs[0]), N.ptr(outs[1]),
+                                                                  N.ptr(outs[2]), N.stream()), 4 * (x.numel() * 85 // 64)))
+    return outs
 
 
 def pgd_linf_step(x, x0, grad, alpha, eps, out=None):
@@ -1022,8 +1042,10 @@ def _wino32_conv(x, U, bias, K, pad):
     B, Cc, H, W = x.shape
     y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
     nb = 4 * (x.numel() + y.numel()) + 4 * U.numel()
-    N.check(_timed("wino32_conv3x3", lambda: lib.dmh_wino32_conv3x3(N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad,
-                                                                   N.ptr(y), N.stream()), nb, 18 * Cc * y.numel()))
+    ws = _sk_workspace(x.device) if WINO_SK else None
+    N.check(_timed("wino32_conv3x3", lambda: lib.dmh_wino32_conv3x3_ws(
+        N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad, N.ptr(y), N.ptr(ws), 0 if ws is None else ws.numel(), N.stream()),
+        nb, 18 * Cc * y.numel()))
     return y
 
 
@@ -1031,19 +1053,22 @@ _sk_ws = {}         # device -> workspace of the stream-K launches (caller-owned
 _SK_WS_FLOATS = 8 << 20         # 32 MB = 2 slots x 256 workgroups x 16,384 floats (one partial work item each)
 
 
+def _sk_workspace(device):
+    """The library decides per launch (dmh_wino_conv3x3_ws / dmh_wino32_conv3x3_ws): stream-K where whole work items would leave
+    the chip idle for part of a round.  ONE buffer per device -- the launches of a stream are ordered, and the fix-up kernel
+    that reads the partial items is enqueued right behind the kernel that wrote them."""
+    ws = _sk_ws.get(device)
+    if ws is None:
+        ws = _sk_ws[device] = torch.empty(_SK_WS_FLOATS, device=device, dtype=torch.float32)
+    return ws
+
+
 def _wino_conv(x, U, bias, K, pad):
     lib = N.lib()
     B, Cc, H, W = x.shape
     y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
     nb = 4 * (x.numel() + y.numel()) + 4 * U.numel()
-    ws = None
-    if WINO_SK:
-        # the library decides per launch (dmh_wino_conv3x3_ws): stream-K where whole work items would leave the chip idle for
-        # part of a round.  ONE buffer per device -- the launches of a stream are ordered, and the fix-up kernel that reads
-        # the partial items is enqueued right behind the kernel that wrote them
-        ws = _sk_ws.get(x.device)
-        if ws is None:
-            ws = _sk_ws[x.device] = torch.empty(_SK_WS_FLOATS, device=x.device, dtype=torch.float32)
+    ws = _sk_workspace(x.device) if WINO_SK else None
     N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_ws(
         N.ptr(x), N.ptr(U), N.ptr(bias), B, Cc, K, H, W, pad, N.ptr(y), N.ptr(ws), 0 if ws is None else ws.numel(), N.stream()),
         nb, 18 * Cc * y.numel()))

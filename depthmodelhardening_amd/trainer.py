@@ -145,6 +145,7 @@ class Trainer:
         self.dataset.both_sides = self.dataset.flip_augmentation = not self.opt.no_flip_sides
         self.dataset.reference_stale_patch = bool(self.opt.reference_stale_patch)
         self.dataset.make_depth_hints = bool(self.opt.use_depth_hints)
+        self.dataset.right_pyramid = bool(self.opt.v1_multiscale)
         self.num_total_steps = len(self.dataset) // self.opt.batch_size * self.opt.num_epochs
 
         if self.opt.adv_train:

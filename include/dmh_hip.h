@@ -181,6 +181,9 @@ typedef struct dmh_paste_args {
     const int32_t* flip; /* [N] or NULL: != 0 mirrors sample n horizontally (do_flip of MD2/datasets/mono_dataset.py:288,
                           :222-225: the loader flips the frame, prep_adv_data flips the projected object and mask; the
                           scene passed here is the UN-flipped frame and the whole composite is written mirrored) */
+    const int32_t* scene_index; /* [N] or NULL: sample n reads frame scene_index[n] of `scene` (a pool of frames with batch
+                                   stride scene_bstride) instead of frame n -- the loader's index_select / side pick without
+                                   a copy of the frames.  Every index must lie inside the pool (checked by the caller). */
 } dmh_paste_args;
 
 /* adv [N,3,OH,OW], mask_out [N,1,OH,OW] (either may be NULL) */
@@ -271,6 +274,10 @@ int dmh_stem_wrw(const float* x, const float* g, int B, int H, int W, float mean
 int dmh_ssim_map(const float* x, const float* y, int planes, int H, int W, float* out, void* stream);
 int dmh_ssim_map_bwd(const float* x, const float* y, const float* g_out, int planes, int H, int W, float* workspace, float* g_x,
                      float* g_y, void* stream);
+/* colour pyramid of the synthesised frame (inputs[("color", f, s)], s = 1..3; the reference's loader resizes per sample on the
+ * CPU, MD2/datasets/mono_dataset.py:119-144): out_s[planes, H/2^s, W/2^s] = F.avg_pool2d(x, 2^s) for s = 1, 2, 3 in ONE pass
+ * over x[planes, H, W], bit-identical to three ATen avg_pool2d calls.  H, W multiples of 8. */
+int dmh_avg_pyramid(const float* x, int planes, int H, int W, float* out1, float* out2, float* out3, void* stream);
 int64_t dmh_edge_smooth_partials_size(int B, int H, int W);
 int dmh_edge_smooth(const float* disp, const float* img, int B, int C, int H, int W, float* partials, float* out, void* stream);
 int dmh_edge_smooth_bwd(const float* disp, const float* img, int B, int C, int H, int W, const float* gscale, float* g_disp,
@@ -462,6 +469,9 @@ int64_t dmh_wino32_weight_size(int n_out, int n_in);
 int dmh_wino32_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream);
 int dmh_wino32_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
                        float* y, void* stream);
+/* The same with a caller-owned stream-K workspace (see dmh_wino_conv3x3_ws): 2 * CUs * 16,384 floats. */
+int dmh_wino32_conv3x3_ws(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
+                          float* y, float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K18 weight gradient of a 3x3 stride-1 convolution with C and K multiples of 64, in the Winograd F(2x2,3x3) domain on the

@@ -227,3 +227,28 @@ def test_stream_k_is_deterministic_and_equals_whole_items():
         e1, e0 = _rel(y1, y64), _rel(y0, y64)
         print("stream-K %s: rel-L2 vs fp64 %.3g (whole items / library %.3g)" % ((B, C, K, H, W, pad), e1, e0))
         assert e1 <= 1.5 * e0 + 1e-7, (e1, e0)
+
+
+def test_stream_k_of_the_32_channel_kernel():
+    """K17's stream-K form (csrc/wino32_conv.hip) through the C ABI at the attack's window shapes of upconv(1,1) / upconv(1,0): the
+    same result as the whole-item launch up to fp32 re-association, against float64, run twice bit for bit."""
+    from depthmodelhardening_amd import _native as N, ops
+    lib = N.lib()
+    ws = torch.empty(8 << 20, device="cuda")
+    for (B, C, K, H, W, pad) in ((12, 96, 32, 94, 116, 0), (12, 64, 32, 50, 62, 0), (12, 32, 96, 92, 114, 2), (3, 96, 32, 30, 200, 0)):
+        x, w = _data(B, C, K, H, W, 31)
+        b = torch.randn(K, generator=torch.Generator().manual_seed(32)).cuda()
+        U = torch.empty(lib.dmh_wino32_weight_size(K, C), device="cuda")
+        N.check(lib.dmh_wino32_weight_transform(N.ptr(w), K, C, 0, N.ptr(U), N.stream()))
+        Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
+        ys = [torch.empty(B, K, Ho, Wo, device="cuda") for _ in range(3)]
+        for y in ys[:2]:
+            N.check(lib.dmh_wino32_conv3x3_ws(N.ptr(x), N.ptr(U), N.ptr(b), B, C, K, H, W, pad, N.ptr(y), N.ptr(ws), ws.numel(), N.stream()))
+        N.check(lib.dmh_wino32_conv3x3(N.ptr(x), N.ptr(U), N.ptr(b), B, C, K, H, W, pad, N.ptr(ys[2]), N.stream()))
+        assert torch.equal(ys[0], ys[1]), (B, C, K, H, W)
+        y64 = F.conv2d(x.double(), w.double(), b.double(), 1, pad)
+        e1, e0 = _rel(ys[0], y64), _rel(ys[2], y64)
+        print("K17 stream-K %s: rel-L2 vs fp64 %.3g (whole items %.3g); differs from whole items: %s" % (
+            (B, C, K, H, W, pad), e1, e0, not torch.equal(ys[0], ys[2])))
+        assert e1 <= 1.5 * e0 + 1e-7, (e1, e0)
+

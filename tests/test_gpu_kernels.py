@@ -583,3 +583,47 @@ def test_eot_paste_flip_is_the_mirrored_paste(out_size):
     gflip[0], gflip[2] = gadv[0].flip(2), gadv[2].flip(2)
     (a1 * gflip).sum().backward()
     assert torch.equal(p0.grad, p1.grad)
+
+
+def test_avg_pyramid_is_bitwise_aten_avg_pool():
+    """ops.avg_pyramid (one pass, three levels) against F.avg_pool2d(x, 2 / 4 / 8): identical bits (the sums are formed in
+    ATen's order), at the training resolution and a ragged batch / channel count."""
+    from depthmodelhardening_amd import ops
+    for shape in ((32, 3, 320, 1024), (3, 5, 24, 40), (1, 1, 8, 8)):
+        x = torch.rand(*shape, generator=torch.Generator().manual_seed(4)).cuda()
+        got = ops.avg_pyramid(x)
+        for s, g in zip((1, 2, 3), got):
+            assert torch.equal(g, F.avg_pool2d(x, 2 ** s)), (shape, s)
+    with pytest.raises(RuntimeError):
+        ops.avg_pyramid(torch.rand(1, 3, 20, 40).cuda())      # 20 is not a multiple of 8
+
+
+def test_synthesis_from_the_pool_by_index_equals_the_copy_path(tmp_path):
+    """The GPU-side prep_adv_data reads its frames out of the dataset's pool by index (K3's scene_index: no index_select /
+    side-pick copies): same bits as pasting into gathered copies of the frames, for mixed sides and flips."""
+    from depthmodelhardening_amd.datasets import SyntheticKITTIDataset, make_object
+    from depthmodelhardening_amd.my_utils import to_device_async
+    dev = torch.device("cuda")
+    ds = SyntheticKITTIDataset(64, 192, [0, "s"], 4, 8, dev, seed=3, pool=6)
+    obj, mask = make_object(dev)
+    # (the attack object of set_adv_train is not needed for the synthesis itself: set what synthesize() reads)
+    from depthmodelhardening_amd.physicalTrans import PhysicalTrans
+    from depthmodelhardening_amd.my_utils import ori_H, ori_W, train_dist_range
+    ds.is_adv_train, ds.obj_mask, ds.obj_img_ben, ds.obj_img_adv = True, mask, obj, (obj * 0.9).contiguous()
+    ds.ben_trans = PhysicalTrans(ds.obj_img_ben, mask, {'path': None}, (1, 3, ori_H, ori_W), dist_range=train_dist_range)
+    ds.adv_trans = PhysicalTrans(ds.obj_img_adv, mask, {'path': None}, (1, 3, ori_H, ori_W), dist_range=train_dist_range)
+    ds.adv_K = ds.K.copy()
+    ds.adv_K[0, :] *= ori_W
+    ds.adv_K[1, :] *= ori_H
+    picks = [4, 0, 5, 2]
+    geo = {"side": ["l", "r", "r", "l"], "flip": [False, True, False, True], "synth": [True, True, False, True],
+           "z0": [5.0, 7.4, 9.8, 6.2], "alpha": [0, -15, 30, 10]}
+    idx = to_device_async(picks, dev, torch.int64)
+    ref = ds.synthesize(ds.raw_left.index_select(0, idx), ds.raw_right.index_select(0, idx), geo, (64, 192))
+    P = ds.pool_size
+    i0 = to_device_async([p + (0 if sd == "l" else P) for p, sd in zip(picks, geo["side"])], dev, torch.int32)
+    i_s = to_device_async([p + (P if sd == "l" else 0) for p, sd in zip(picks, geo["side"])], dev, torch.int32)
+    got = ds.synthesize(None, None, geo, (64, 192), pool_index=(i0, i_s))
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+

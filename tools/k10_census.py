@@ -45,6 +45,9 @@ def wrap(name, shape_of):
 wrap("dmh_wino_conv3x3", lambda a: (a[3], a[4], a[5], a[6], a[7], a[8], "plain"))
 wrap("dmh_wino_conv3x3_act", lambda a: (a[5], a[6], a[7], a[8], a[9], a[10], "epi relu=%d res=%d" % (a[4], a[3] is not None and bool(a[3]))))
 wrap("dmh_wino32_conv3x3", lambda a: (a[3], a[4], a[5], a[6], a[7], a[8], "k17"))
+# the entry points with a stream-K workspace (round 5: ops.py calls these; the library decides per launch)
+wrap("dmh_wino_conv3x3_ws", lambda a: (a[3], a[4], a[5], a[6], a[7], a[8], "plain"))
+wrap("dmh_wino32_conv3x3_ws", lambda a: (a[3], a[4], a[5], a[6], a[7], a[8], "k17"))
 
 from depthmodelhardening_amd.options import MonodepthOptions  # noqa: E402
 from depthmodelhardening_amd.trainer import Trainer  # noqa: E402
@@ -70,7 +73,7 @@ CU = 256
 for (name, B, C, K, H, W, pad, kind), ts in agg.items():
     Ho, Wo = H + 2 * pad - 2, W + 2 * pad - 2
     Ht, Wt = Ho // 2, Wo // 2
-    if name == "dmh_wino32_conv3x3":
+    if name.startswith("dmh_wino32_conv3x3"):
         items = B * ((Wt + 31) // 32) * ((Ht + 3) // 4) * ((K + 31) // 32)
         split = 1
     else:
