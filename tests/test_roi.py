@@ -330,7 +330,7 @@ def test_l0_attack_with_windows_equals_attack_without():
     assert torch.equal(m0, m1)
     for i, (a, b) in enumerate(zip(t0, t1)):
         # L0 count (texels on the 1/255 threshold after Adam steps from gradients that agree to 1e-6), mask weight
-        assert abs(a[0] - b[0]) <= max(5, 5e-4 * a[0]) and a[1] == b[1], (i, a, b)
+        assert abs(a[0] - b[0]) <= max(5, 2e-3 * a[0]) and a[1] == b[1], (i, a, b)
         tol = 2e-6 if i == 0 else 1e-5      # Adam(lr = 0.5) turns the sign of a ~0 gradient into a step of 0.5 on that texel
         assert abs(a[2] - b[2]) <= tol * abs(a[2]) and abs(a[3] - b[3]) <= tol * abs(a[3]), (i, a, b)  # adversarial / mask cost
     per_iter = []
