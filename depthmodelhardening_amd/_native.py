@@ -55,6 +55,7 @@ _PtrArr = _fp * MAX_SCALES
 _SIGNATURES = {
     "dmh_version": (C.c_char_p, []),
     "dmh_last_error": (C.c_char_p, []),
+    "dmh_debug_channel_copy": (C.c_int, [_fp, _fp, C.c_int64, C.c_int, C.c_int, _fp]),
     "dmh_photo_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmh_photo_stage_size": (C.c_int64, [C.POINTER(PhotoArgs)]),
     "dmh_photo_loss_fwd": (C.c_int, [C.POINTER(PhotoArgs), _fp, _PtrArr, _fp, _fp]),

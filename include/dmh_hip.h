@@ -52,6 +52,10 @@ extern "C" {
 
 const char* dmh_version(void);
 const char* dmh_last_error(void);
+/* Diagnostics (tools/rccl_overlap.py): a stand-in with a ring collective's launch geometry -- `channels` persistent workgroups of
+ * 256 threads copy n floats src -> dst `rounds` times -- to observe, on ONE GPU, how such a kernel on a side stream is scheduled
+ * against the persistent convolution workgroups (a 1-rank RCCL all-reduce launches no device kernel).  Not on any product path. */
+int dmh_debug_channel_copy(const float* src, float* dst, int64_t n, int channels, int rounds, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K1  fused photometric loss: bilinear-upsample(disp_s) -> disp_to_depth -> BackprojectDepth

@@ -1,100 +1,86 @@
 #!/usr/bin/env python3
-"""What can be shown of the gradient all-reduce's overlap on ONE GPU ("single-GPU, prediction").
+"""What ONE GPU can show about the gradient all-reduce beside the attack -- "single-GPU, prediction".
 
-    export TMPDIR=/tmp; rocprofv3 --kernel-trace --output-format csv -d gpurun_out/rccl_ovl -- python3 tools/rccl_overlap.py
-    [DMH_K10_RESERVE_CUS=8 exported before rocprofv3 for the second run]
-    python3 tools/rccl_overlap.py --report gpurun_out/rccl_ovl          # after the run: parse the kernel trace
+    python3 tools/rccl_overlap.py                          # default launch geometry of K10
+    DMH_K10_RESERVE_CUS=8 python3 tools/rccl_overlap.py     # K10 / K17 leave eight CUs free
 
-The process initialises backend nccl (= RCCL) with world_size 1, builds the bench's trainer (config 2: 1024x320, 12 attack
-scenes, batch 32) and runs three iterations in the overlapped order of Trainer.train_step with the collective FORCED although
-there is one rank: the 57.3 MB flat bucket is handed to RCCL on the side stream right after backward, the next iteration's
-attack is enqueued on the compute stream, then the optimiser waits for the collective's event.  With one rank RCCL moves no
-bytes over xGMI, but its device kernel is launched, scheduled against the persistent K10 workgroups and timed: the trace says
-WHERE it runs -- beside K10 launches, or only in the gaps between them -- and when it finishes relative to the attack.
+Finding 1 (measured, `rocprofv3 --kernel-trace` of the r4 version of this tool): a 1-rank RCCL communicator launches NO device
+kernel for an in-place all-reduce -- 13,447 kernels in the trace of three iterations, none of RCCL's.  tests/test_gpu_ddp.py
+therefore proves stream / event ORDERING of the side-stream collective, not its scheduling against the convolutions.
+
+So this tool uses a stand-in with a ring collective's launch geometry (`dmh_debug_channel_copy`: C persistent workgroups of 256
+threads, no LDS, streaming 57.3 MB read + write `rounds` times -- ring all-reduce moves 2 (N-1)/N of the bucket per GPU), on the
+side stream, enqueued right after backward exactly where GradBucket.start_all_reduce() enqueues the collective, while the next
+iteration's attack runs on the compute stream (the overlapped order of Trainer.train_step).  Reported per configuration:
+the stand-in's duration alone and beside the attack, the attack's duration alone and beside the stand-in.  A K10 workgroup owns
+its CU (154 KB of LDS, 512 registers per lane): a channel workgroup can only start on a CU that is free of them, and once it is
+resident, a 256-workgroup K10 launch has to wait for that CU.
 """
-import argparse
-import csv
-import glob
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run():
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29541"), RANK="0", WORLD_SIZE="1",
-                      LOCAL_RANK="0", DMH_DIST_FORCE_INIT="1")
-    os.environ.pop("DMH_DIST_BACKEND", None)
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+def main():
     import torch
-    import torch.distributed as dist
-    from depthmodelhardening_amd.ddp import GradBucket, init_distributed
+    from depthmodelhardening_amd import _native as N
     from depthmodelhardening_amd.options import MonodepthOptions
     from depthmodelhardening_amd.trainer import Trainer
-    r, w, dev = init_distributed("cuda")
-    assert dist.get_backend() == "nccl" and w == 1
+    dev = torch.device("cuda")
     argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "320", "--width", "1024", "--batch_size", "32",
             "--atk_batch_size", "12", "--learning_rate", "1e-5", "--adv_train", "--norm_type", "l_inf", "--atk_steps", "10",
             "--weights_init", "scratch", "--model_name", "ovl", "--log_dir", "/tmp/dmh_ovl", "--synthetic_len", "1000000"]
     tr = Trainer(MonodepthOptions().parse(argv), rank=0, world_size=1, device=dev)
-    fc = {id(p) for p in tr.models["encoder"].encoder.fc.parameters()}
-    tr.bucket = GradBucket([p for p in tr.parameters_to_train if id(p) not in fc], world_size=1, force_collective=True)
     tr.set_train()
     tr.warm_kernels()
     tr.train_step()
     torch.cuda.synchronize()
-    marks = []
-    for it in range(3):
-        # the overlapped order of Trainer.train_step for world_size > 1: attack first (it reads weights one step old), then
-        # wait for the previous iteration's collective and apply the update
-        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        e0.record()
+    lib = N.lib()
+    n = tr.bucket.numel - tr.bucket.numel % 4
+    src = tr.bucket.flat[:n]
+    dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+
+    def ev():
+        return torch.cuda.Event(enable_timing=True)
+
+    def attack_ms(with_copy, channels, rounds):
+        a0, a1, c0, c1 = ev(), ev(), ev(), ev()
+        torch.cuda.synchronize()
+        if with_copy:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                c0.record(side)
+                N.check(lib.dmh_debug_channel_copy(N.ptr(src), N.ptr(dst), n, channels, rounds, C.c_void_p(side.cuda_stream)))
+                c1.record(side)
+        a0.record()
         tr.update_adv_obj()
-        e1.record()
-        tr._apply_pending_update()
-        inputs = tr.dataset.next_batch(tr.opt.batch_size)
-        _, losses = tr.process_batch(inputs)
-        with tr.bucket.released():
-            losses["loss"].backward()
-        tr.bucket.start_all_reduce()          # side stream; the NEXT iteration's attack is enqueued before anybody waits on it
-        tr._pending = True
-        e2.record()
-        marks.append((e0, e1, e2))
-    tr._apply_pending_update()
-    torch.cuda.synchronize()
-    for i, (e0, e1, e2) in enumerate(marks):
-        print("iteration %d: attack %.2f ms, forward/backward %.2f ms" % (i, e0.elapsed_time(e1), e1.elapsed_time(e2)))
-    dist.barrier()
-    dist.destroy_process_group()
+        a1.record()
+        torch.cuda.synchronize()
+        return a0.elapsed_time(a1), (c0.elapsed_time(c1) if with_copy else None)
 
+    def copy_alone(channels, rounds):
+        c0, c1 = ev(), ev()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(side):
+            c0.record(side)
+            N.check(lib.dmh_debug_channel_copy(N.ptr(src), N.ptr(dst), n, channels, rounds, C.c_void_p(side.cuda_stream)))
+            c1.record(side)
+        torch.cuda.synchronize()
+        return c0.elapsed_time(c1)
 
-def report(folder):
-    files = glob.glob(os.path.join(folder, "**", "*kernel_trace.csv"), recursive=True)
-    if not files:
-        print("no kernel trace under", folder)
-        return 1
-    rows = []
-    for f in files:
-        for r in csv.DictReader(open(f)):
-            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
-    rows.sort()
-    nccl = [r for r in rows if "nccl" in r[2].lower() or "rccl" in r[2].lower()]
-    k10 = [r for r in rows if "wino_conv_kernel" in r[2] or "wino32_conv_kernel" in r[2] or "wino_wrw_kernel" in r[2]]
-    print("%d kernels in the trace, %d RCCL kernels, %d persistent MFMA-convolution launches (K10 / K17 / K18)" % (len(rows), len(nccl), len(k10)))
-    for s, e, name in nccl:
-        inside = [(a, b, n) for a, b, n in k10 if a < e and b > s]
-        ovl = sum(min(e, b) - max(s, a) for a, b, n in inside)
-        others = [(a, b, n) for a, b, n in rows if a < e and b > s and "nccl" not in n.lower()]
-        # which kernel was running when it started / how long after the previous compute kernel's end it started
-        running = [n for a, b, n in rows if a <= s < b and "nccl" not in n.lower()]
-        print("  %-60s %8.1f us | overlaps %d K10-class launches for %.1f us (%.0f %% of its duration), %d kernels of the compute "
-              "stream ran meanwhile | started while running: %s" % (name[:60], (e - s) / 1e3, len(inside), ovl / 1e3, 100.0 * ovl / max(1, e - s),
-                                                                   len(others), (running[0][:50] if running else "nothing (a gap)")))
-    return 0
+    import ctypes as C
+    base = sorted(attack_ms(False, 0, 0)[0] for _ in range(3))[1]
+    print("K10 reserve CUs: %s; attack alone (10 steps, 12 scenes): %.2f ms" % (os.environ.get("DMH_K10_RESERVE_CUS", "0"), base))
+    for channels in (8, 16, 32, 64):
+        rounds = 2                  # ~ the 2 (N-1)/N bucket volumes a ring all-reduce moves per GPU
+        alone = sorted(copy_alone(channels, rounds) for _ in range(3))[1]
+        runs = sorted(attack_ms(True, channels, rounds) for _ in range(3))
+        atk, cp = runs[1]
+        print("  %2d channel workgroups, %d x 57.3 MB: stand-in alone %.3f ms; beside the attack %.3f ms; attack beside it %.2f ms "
+              "(%+.2f ms)" % (channels, rounds, alone, cp, atk, atk - base))
 
 
 if __name__ == "__main__":
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--report", default=None)
-    a = ap.parse_args()
-    sys.exit(report(a.report) if a.report else run())
+    main()

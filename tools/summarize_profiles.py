@@ -169,7 +169,7 @@ if bs and bt:
                          ("stem", "stem (K14 / K12 / K9 stem glue)"), ("head_", "K13 disparity heads"),
                          ("photo_", "K1-K6 loss + attack"), ("smooth_", "K1-K6 loss + attack"), ("finalize", "K1-K6 loss + attack"),
                          ("paste_", "K1-K6 loss + attack"), ("sq_mean", "K1-K6 loss + attack"), ("l0_", "K1-K6 loss + attack"),
-                         ("pgd_", "K1-K6 loss + attack"), ("unpack_sel", "K1-K6 loss + attack"), ("depth_err", "K1-K6 loss + attack"),
+                         ("pgd_", "K1-K6 loss + attack"), ("avg_pyramid", "K1-K6 loss + attack"), ("gt_depth", "K1-K6 loss + attack"), ("unpack_sel", "K1-K6 loss + attack"), ("depth_err", "K1-K6 loss + attack"),
                          ("igemm", "MIOpen"), ("miopen", "MIOpen"), ("MIOpen", "MIOpen"), ("batched_transpose", "MIOpen"),
                          ("Sp3Asm", "MIOpen"), ("ck::", "MIOpen"), ("gridwise", "MIOpen"),
                          ("at::native", "ATen / runtime"), ("rocclr", "ATen / runtime")):
