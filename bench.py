@@ -41,8 +41,7 @@ BASELINE_CONFIGS = {      # BASELINE.json "configs" (index = position in that li
 }
 
 
-K1_SOURCES = ("depthmodelhardening_amd/csrc/photo_loss.hip", "depthmodelhardening_amd/csrc/smooth_loss.hip",
-              "depthmodelhardening_amd/csrc/common.hpp")
+K1_SOURCES = ("depthmodelhardening_amd/csrc/photo_loss.hip", "depthmodelhardening_amd/csrc/smooth_loss.hip")
 
 
 def k1_source_hash():

@@ -134,19 +134,20 @@ __device__ __forceinline__ float2 normal_pair_from_bits(uint32_t u0, uint32_t u1
 }
 
 // ---- stream-K decomposition of the Winograd convolution kernels (K10 wino_conv.hip, K17 wino32_conv.hip) -------------------
-// first unit of workgroup w's range (w = 0 .. sk_grid).  A boundary inside an item is kept at least 3 chunks away from both
-// of the item's ends (the staging pipeline is 3 chunks deep); items of fewer than 6 chunks are never cut.
-__host__ __device__ inline int sk_boundary(int units, int grid, int nch, int w) {
-    const long long b = (long long)w * units / grid;
-    const int item = (int)(b / nch);
-    int c = (int)(b - (long long)item * nch);
+// first unit of workgroup w's range (w = 0 .. grid): the first units % grid workgroups get one unit more (no division: this runs
+// in every workgroup of the main kernel and several times per workgroup of the fix-up kernel).  A boundary inside an item is
+// kept at least 3 chunks away from both of the item's ends (the staging pipeline is 3 chunks deep); items of fewer than 6
+// chunks are never cut.  per = units / grid, rem = units % grid (host).
+__host__ __device__ inline int sk_boundary(int per, int rem, int nch, int w) {
+    const int b = w * per + (w < rem ? w : rem);
+    const int item = b / nch;
+    int c = b - item * nch;
     if (c != 0) {
         if (nch >= 6) c = c < 3 ? 3 : (c > nch - 3 ? nch - 3 : c);
         else c = (2 * c < nch) ? 0 : nch;
     }
     return item * nch + c;
 }
-
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: a process that drives a second GPU (or
 // launches from two threads) must not inherit a per-process "already configured" flag.  One bit per device ordinal, set

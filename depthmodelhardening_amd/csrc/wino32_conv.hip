@@ -52,6 +52,7 @@ struct W32Args {
     int nitems;                  // B * gy * gx * kg
     float* part;                 // SK: workspace of the partial items (2 * sk_grid slots of SK_SLOT floats), see K10
     int sk_units, sk_grid;       // SK: nitems * C/8 (item, chunk) units dealt to sk_grid workgroups in equal contiguous ranges
+    int sk_per, sk_rem;          // sk_units / sk_grid, sk_units % sk_grid
 };
 constexpr int SK_SLOT = 16 * NT * 4;      // floats of one partial item: [output channel v 16][thread 256] float4 (y00, y01, y10, y11)
 
@@ -80,8 +81,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 
     int item0, nmine, cb0 = 0, ce_last = nch;   // SK: the first piece starts at chunk cb0 of item0, the last ends before ce_last
     if (SK) {       // equal ranges of (item, chunk) units: a range may begin and end inside an item (K10, wino_conv.hip)
-        const int u0 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x);
-        const int u1 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x + 1);
+        const int u0 = sk_boundary(a.sk_per, a.sk_rem, nch, (int)blockIdx.x);
+        const int u1 = sk_boundary(a.sk_per, a.sk_rem, nch, (int)blockIdx.x + 1);
         if (u0 >= u1) return;
         item0 = u0 / nch;
         const int il = (u1 - 1) / nch;
@@ -314,28 +315,42 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     }
 }
 
-// Stream-K second stage (see wino_sk_fixup_kernel in wino_conv.hip): the workgroup of an item's FIRST cut adds the item's partial
-// pieces in chunk order, adds the bias and writes the outputs with the main kernel's thread -> (tile, channel) map.
+// Stream-K second stage (see wino_sk_fixup_kernel in wino_conv.hip): the workgroups (four per cut: four output channels of a
+// lane each) of an item's FIRST cut add the item's partial pieces in chunk order, add the bias and write the outputs with the
+// main kernel's thread -> (tile, channel) map.
 __global__ __launch_bounds__(NT) void wino32_sk_fixup_kernel(W32Args a) {
     const int nch = a.C / CK;
-    const int w = (int)blockIdx.x + 1;
-    const int b = sk_boundary(a.sk_units, a.sk_grid, nch, w);
+    const int w = (int)blockIdx.x + 1, v0 = 4 * (int)blockIdx.y;
+    const int b = sk_boundary(a.sk_per, a.sk_rem, nch, w);
     const int item = b / nch;
     if (b == item * nch) return;
-    const int bp = sk_boundary(a.sk_units, a.sk_grid, nch, w - 1);
+    const int bp = sk_boundary(a.sk_per, a.sk_rem, nch, w - 1);
     if (bp > item * nch) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const f32x4* part = reinterpret_cast<const f32x4*>(a.part);
-    f32x4 acc[16];
+    const f32x4* part = reinterpret_cast<const f32x4*>(a.part) + (size_t)v0 * NT + tid;
+    f32x4 acc[4], nx[4];
     {
-        const int slot = 2 * (w - 1) + (bp == item * nch ? 0 : 1);
+        const size_t s0 = (size_t)(2 * (w - 1) + (bp == item * nch ? 0 : 1)) * 16 * NT, s1 = (size_t)(2 * w) * 16 * NT;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = part[((size_t)slot * 16 + v) * NT + tid];
+        for (int v = 0; v < 4; ++v) {
+            acc[v] = part[s0 + (size_t)v * NT];
+            nx[v] = part[s1 + (size_t)v * NT];
+        }
     }
+    const int end = (item + 1) * nch;
     for (int ww = w;; ++ww) {
+        const bool last = sk_boundary(a.sk_per, a.sk_rem, nch, ww + 1) >= end;
+        f32x4 n2[4];
+        if (!last) {
+            const size_t s2 = (size_t)(2 * (ww + 1)) * 16 * NT;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] += part[((size_t)(2 * ww) * 16 + v) * NT + tid];
-        if (sk_boundary(a.sk_units, a.sk_grid, nch, ww + 1) >= (item + 1) * nch) break;
+            for (int v = 0; v < 4; ++v) n2[v] = part[s2 + (size_t)v * NT];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += nx[v];
+        if (last) break;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) nx[v] = n2[v];
     }
     const Item it = decode_item(a, item);
     const int oy = 2 * (it.ty0 + wv), ox = 2 * (it.tx0 + (lane & 31));
@@ -343,8 +358,8 @@ __global__ __launch_bounds__(NT) void wino32_sk_fixup_kernel(W32Args a) {
     float* yb = a.y + (size_t)it.b * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
     const int kbase = it.k0 + 4 * (lane >> 5);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int ko = kbase + (v & 3) + 8 * (v >> 2);
+    for (int v = 0; v < 4; ++v) {
+        const int ko = kbase + v + 8 * (int)blockIdx.y;
         if (inside && ko < a.K) {
             const float bs = a.bias ? a.bias[ko] : 0.f;
             float* yp = yb + (size_t)ko * a.Ho * a.Wo;
@@ -459,13 +474,13 @@ static int wino32_common(const float* x, const float* U, const float* bias, int 
             const double per = (double)units / G;
             const double t_sk = per * 3.4 + 4.0 * (per / nch + 1.5) + 6.0;
             if (t_sk < 0.92 * t_cur) {
-                a.part = ws; a.sk_units = (int)units; a.sk_grid = G;
+                a.part = ws; a.sk_units = (int)units; a.sk_grid = G; a.sk_per = (int)(units / G); a.sk_rem = (int)(units % G);
                 static std::atomic<uint64_t> configured_sk{0};
                 if (configure_dynamic_lds(wino32_conv_kernel<true>, smem, configured_sk) != hipSuccess)
                     return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino32_conv3x3");
                 hipLaunchKernelGGL(wino32_conv_kernel<true>, dim3((unsigned)G), dim3(NT), smem, (hipStream_t)stream, a);
                 if (int rc = check_launch("dmh_wino32_conv3x3 (stream-K)")) return rc;
-                hipLaunchKernelGGL(wino32_sk_fixup_kernel, dim3((unsigned)(G - 1)), dim3(NT), 0, (hipStream_t)stream, a);
+                hipLaunchKernelGGL(wino32_sk_fixup_kernel, dim3((unsigned)(G - 1), 4), dim3(NT), 0, (hipStream_t)stream, a);
                 return check_launch("dmh_wino32_conv3x3 (stream-K fix-up)");
             }
         }

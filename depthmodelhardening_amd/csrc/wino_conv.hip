@@ -64,7 +64,7 @@ struct WArgs {
     // to the sk_grid workgroups in contiguous, equal ranges; a range that starts or ends inside an item leaves a PARTIAL item,
     // whose sums go to slot 2 * wg (the workgroup's first piece) / 2 * wg + 1 (its last) of `part` (SK_SLOT floats each) and are
     // added in chunk order by wino_sk_fixup_kernel
-    int sk_units, sk_grid;
+    int sk_units, sk_grid, sk_per, sk_rem;   // sk_per = sk_units / sk_grid, sk_rem = sk_units % sk_grid
 };
 constexpr int SK_SLOT = 16 * NT * 4;      // floats of one partial item: [output channel v 16][thread 256] float4 (y00, y01, y10, y11)
 
@@ -174,8 +174,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // ---- this workgroup's contiguous item range, flattened with the channel chunks into one iteration space
     int item0, nmine, cb0 = 0, ce_last = nch;   // SK: the first piece starts at chunk cb0 of item0, the last ends before ce_last
     if (SK) {       // equal ranges of (item, chunk) units: a range may begin and end inside an item (see WArgs)
-        const int u0 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x);
-        const int u1 = sk_boundary(a.sk_units, a.sk_grid, nch, (int)blockIdx.x + 1);
+        const int u0 = sk_boundary(a.sk_per, a.sk_rem, nch, (int)blockIdx.x);
+        const int u1 = sk_boundary(a.sk_per, a.sk_rem, nch, (int)blockIdx.x + 1);
         if (u0 >= u1) return;
         item0 = u0 / nch;
         const int il = (u1 - 1) / nch;
@@ -551,33 +551,48 @@ __global__ __launch_bounds__(NT) void zero_fill_kernel(f32x4* __restrict__ p, si
     if (i < n4) p[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-// Stream-K second stage: one workgroup per range boundary that cuts an item.  The workgroup of the FIRST cut of an item adds the
-// item's partial pieces in chunk order (fixed: deterministic, no atomics), applies the bias and writes the item's outputs with
-// the main kernel's own thread -> (tile, channel) map.
+// Stream-K second stage: four workgroups (blockIdx.y: four of the sixteen output channels of a lane each) per range boundary
+// that cuts an item.  The workgroups of the FIRST cut of an item add the item's partial pieces in chunk order (fixed:
+// deterministic, no atomics), apply the bias and write the item's outputs with the main kernel's own thread -> (tile, channel)
+// map.  The next piece is requested before the current one is added (the pieces of an item cut five times would otherwise cost
+// five dependent round trips to memory).
 template <int TRW, bool FLAT>
 __global__ __launch_bounds__(NT) void wino_sk_fixup_kernel(WArgs a) {
     constexpr int TRH = 64 / TRW;
     const int nch = a.C / CK;
-    const int w = (int)blockIdx.x + 1;
-    const int b = sk_boundary(a.sk_units, a.sk_grid, nch, w);
+    const int w = (int)blockIdx.x + 1, v0 = 4 * (int)blockIdx.y;
+    const int b = sk_boundary(a.sk_per, a.sk_rem, nch, w);
     const int item = b / nch;
     if (b == item * nch) return;                                 // the boundary falls between two items
-    const int bp = sk_boundary(a.sk_units, a.sk_grid, nch, w - 1);
-    if (bp > item * nch) return;                                 // an earlier boundary cuts this item: its workgroup sums
+    const int bp = sk_boundary(a.sk_per, a.sk_rem, nch, w - 1);
+    if (bp > item * nch) return;                                 // an earlier boundary cuts this item: its workgroups sum
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, kb = wv & 1, tb = wv >> 1;
-    const f32x4* part = reinterpret_cast<const f32x4*>(a.part);
+    const f32x4* part = reinterpret_cast<const f32x4*>(a.part) + (size_t)v0 * NT + tid;
     // the pieces in chunk order: the last piece of workgroup w-1 (its only one if it starts exactly at the item), then the first
     // piece of every workgroup whose range starts inside the item
-    f32x4 acc[16];
+    f32x4 acc[4], nx[4];
     {
-        const int slot = 2 * (w - 1) + (bp == item * nch ? 0 : 1);
+        const size_t s0 = (size_t)(2 * (w - 1) + (bp == item * nch ? 0 : 1)) * 16 * NT, s1 = (size_t)(2 * w) * 16 * NT;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] = part[((size_t)slot * 16 + v) * NT + tid];
+        for (int v = 0; v < 4; ++v) {
+            acc[v] = part[s0 + (size_t)v * NT];
+            nx[v] = part[s1 + (size_t)v * NT];
+        }
     }
+    const int end = (item + 1) * nch;
     for (int ww = w;; ++ww) {
+        const bool last = sk_boundary(a.sk_per, a.sk_rem, nch, ww + 1) >= end;
+        f32x4 n2[4];
+        if (!last) {
+            const size_t s2 = (size_t)(2 * (ww + 1)) * 16 * NT;
 #pragma unroll
-        for (int v = 0; v < 16; ++v) acc[v] += part[((size_t)(2 * ww) * 16 + v) * NT + tid];
-        if (sk_boundary(a.sk_units, a.sk_grid, nch, ww + 1) >= (item + 1) * nch) break;
+            for (int v = 0; v < 4; ++v) n2[v] = part[s2 + (size_t)v * NT];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc[v] += nx[v];
+        if (last) break;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) nx[v] = n2[v];
     }
     const Item it = decode_item<TRW>(a, item);
     const int Ht = a.Ho >> 1, NR = a.B * Ht;
@@ -589,8 +604,8 @@ __global__ __launch_bounds__(NT) void wino_sk_fixup_kernel(WArgs a) {
     float* yb = a.y + (size_t)ob * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
     const int kbase = it.k0 + kb * 32 + 4 * (lane >> 5);
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int ko = kbase + (v & 3) + 8 * (v >> 2);
+    for (int v = 0; v < 4; ++v) {
+        const int ko = kbase + v + 8 * (int)blockIdx.y;          // channel v0 + v of the lane: (vv & 3) + 8 (vv >> 2), vv = v0 + v
         if (inside && ko < a.K) {
             const float bs = a.bias ? a.bias[ko] : 0.f;
             float* yp = yb + (size_t)ko * a.Ho * a.Wo;
@@ -654,7 +669,7 @@ int launch_split(WArgs& a, hipStream_t st, bool epi, float* ws, int64_t ws_float
             const double per = (double)units / G;
             const double t_sk = per * 3.05 + 4.0 * (per / nch + 1.5) + 6.0;
             if (t_sk < 0.92 * t_cur) {
-                a.csplit = 1; a.nitems = (int)regions; a.part = ws; a.sk_units = (int)units; a.sk_grid = G;
+                a.csplit = 1; a.nitems = (int)regions; a.part = ws; a.sk_units = (int)units; a.sk_grid = G; a.sk_per = (int)(units / G); a.sk_rem = (int)(units % G);
                 static std::atomic<uint64_t> configured{0};
                 constexpr int TRH = 64 / TRW;
                 constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);
@@ -663,7 +678,7 @@ int launch_split(WArgs& a, hipStream_t st, bool epi, float* ws, int64_t ws_float
                     return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
                 hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, false, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
                 if (int rc = check_launch("dmh_wino_conv3x3 (stream-K)")) return rc;
-                hipLaunchKernelGGL((wino_sk_fixup_kernel<TRW, FLAT>), dim3((unsigned)(G - 1)), dim3(NT), 0, st, a);
+                hipLaunchKernelGGL((wino_sk_fixup_kernel<TRW, FLAT>), dim3((unsigned)(G - 1), 4), dim3(NT), 0, st, a);
                 return check_launch("dmh_wino_conv3x3 (stream-K fix-up)");
             }
         }
