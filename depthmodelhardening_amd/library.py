@@ -10,6 +10,7 @@ to the same bits.  There is no CPU kernel behind any of them: the CUDA implement
 
     dmh::eot_paste            physicalTrans.py:156-165 + phy_obj_atk.py:88-90   (K3)   + dmh::eot_paste_bwd
     dmh::masked_sq_mean       phy_obj_atk.py:94, pgd_depth.py:68-70             (K6)   + dmh::masked_sq_mean_bwd
+    dmh::gt_depth_mse         MD2/trainer.py:551-557 (--supervised_adv --gt_depth) (K6b)  + dmh::gt_depth_mse_bwd
     dmh::pgd_linf_step        phy_obj_atk.py:98-101, pgd_depth.py:76-78         (K4)
     dmh::l0_compose           phy_obj_atk_l0.py:94-99,43-52                     (K5)   + dmh::l0_compose_bwd
     dmh::l0_mask_cost         phy_obj_atk_l0.py:130-132                         (K5)   + dmh::l0_mask_cost_bwd
@@ -128,6 +129,53 @@ def _msm_backward(ctx, g):
 
 
 masked_sq_mean.register_autograd(_msm_backward, setup_context=_msm_setup)
+
+
+# ---------------------------------------------------------------------------------------------------------------- K6b
+@custom_op("dmh::gt_depth_mse", mutates_args=())
+def gt_depth_mse(disp: torch.Tensor, disp_gt: torch.Tensor, objmask: torch.Tensor, objdepth: torch.Tensor, min_depth: float,
+                 max_depth: float) -> torch.Tensor:
+    disp, disp_gt, objmask, bstride, objdepth, B, HW = ops._gt_depth_operands(disp, disp_gt, objmask, objdepth)
+    lib = N.lib()
+    part = torch.empty(lib.dmh_sq_mean_partials_size(B * HW), device=disp.device, dtype=torch.float32)
+    cost = torch.empty((), device=disp.device, dtype=torch.float32)
+    N.check(lib.dmh_gt_depth_mse_fwd(N.ptr(disp), N.ptr(disp_gt), C.c_void_p(objmask.data_ptr()), bstride, N.ptr(objdepth), B, HW,
+                                     float(min_depth), float(max_depth), N.ptr(part), N.ptr(cost), N.stream()))
+    return cost
+
+
+@gt_depth_mse.register_fake
+def _(disp, disp_gt, objmask, objdepth, min_depth, max_depth):
+    return disp.new_empty(())
+
+
+@custom_op("dmh::gt_depth_mse_bwd", mutates_args=())
+def gt_depth_mse_bwd(disp: torch.Tensor, disp_gt: torch.Tensor, objmask: torch.Tensor, objdepth: torch.Tensor, min_depth: float,
+                     max_depth: float, g: torch.Tensor) -> torch.Tensor:
+    disp, disp_gt, objmask, bstride, objdepth, B, HW = ops._gt_depth_operands(disp, disp_gt, objmask, objdepth)
+    g_disp = torch.empty_like(disp)
+    N.check(N.lib().dmh_gt_depth_mse_bwd(N.ptr(disp), N.ptr(disp_gt), C.c_void_p(objmask.data_ptr()), bstride, N.ptr(objdepth), B, HW,
+                                         float(min_depth), float(max_depth), N.ptr(_cu(g.to(torch.float32))), N.ptr(g_disp),
+                                         N.stream()))
+    return g_disp
+
+
+@gt_depth_mse_bwd.register_fake
+def _(disp, disp_gt, objmask, objdepth, min_depth, max_depth, g):
+    return torch.empty_like(disp)
+
+
+def _gtd_setup(ctx, inputs, output):
+    ctx.save_for_backward(inputs[0], inputs[1], inputs[2], inputs[3])
+    ctx.depths = (inputs[4], inputs[5])
+
+
+def _gtd_backward(ctx, g):
+    disp, disp_gt, objmask, objdepth = ctx.saved_tensors
+    return torch.ops.dmh.gt_depth_mse_bwd(disp, disp_gt, objmask, objdepth, ctx.depths[0], ctx.depths[1], g), None, None, None, None, None
+
+
+gt_depth_mse.register_autograd(_gtd_backward, setup_context=_gtd_setup)
 
 
 # ----------------------------------------------------------------------------------------------------------------- K4
@@ -428,5 +476,5 @@ def _smooth_backward(ctx, g):
 smooth_loss.register_autograd(_smooth_backward, setup_context=_smooth_setup)
 
 
-OPS = ("eot_paste", "eot_paste_bwd", "masked_sq_mean", "masked_sq_mean_bwd", "pgd_linf_step", "l0_compose", "l0_compose_bwd",
+OPS = ("eot_paste", "eot_paste_bwd", "masked_sq_mean", "masked_sq_mean_bwd", "gt_depth_mse", "gt_depth_mse_bwd", "pgd_linf_step", "l0_compose", "l0_compose_bwd",
        "l0_mask_cost", "l0_mask_cost_bwd", "photo_smooth_loss", "photo_smooth_loss_bwd", "ssim_map", "ssim_map_bwd", "smooth_loss", "smooth_loss_bwd")

@@ -105,6 +105,17 @@ def test_opcheck_of_the_small_operators():
     torch.library.opcheck(torch.ops.dmh.smooth_loss, (d.clone().requires_grad_(True), x), test_utils=tests)
     torch.library.opcheck(torch.ops.dmh.masked_sq_mean, (d.clone().requires_grad_(True), (d > 0.5).float()), test_utils=tests)
     torch.library.opcheck(torch.ops.dmh.pgd_linf_step, (x, y, x - y, 0.02, 0.1), test_utils=tests)
+    # --gt_depth term (K6b): same bits as ops.gt_depth_mse, mask passed as the dataset passes it (one channel expanded to three)
+    m3 = (torch.rand(2, 1, 16, 24, generator=g) > 0.6).float().to(dev).expand(-1, 3, -1, -1)
+    od = torch.tensor([[6.2], [8.4]], device=dev)
+    d2 = (d * 0.3 + 0.01)
+    torch.library.opcheck(torch.ops.dmh.gt_depth_mse, (d2.clone().requires_grad_(True), (d2 * 0.9).contiguous(), m3, od, 0.1, 100.0),
+                          test_utils=tests)
+    a, b = d2.clone().requires_grad_(True), d2.clone().requires_grad_(True)
+    la, lb = torch.ops.dmh.gt_depth_mse(a, (d2 * 0.9).contiguous(), m3, od, 0.1, 100.0), ops.gt_depth_mse(b, d2 * 0.9, m3, od, 0.1, 100.0)
+    la.backward()
+    lb.backward()
+    assert torch.equal(la, lb) and torch.equal(a.grad, b.grad)
     assert set(library.OPS) <= set(dir(torch.ops.dmh)) or all(hasattr(torch.ops.dmh, n) for n in library.OPS)
 
 

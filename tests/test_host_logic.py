@@ -133,7 +133,12 @@ def test_conv_dispatch_rule_mirrors_the_launcher():
     assert ops._wino_ok(B, 64, 64, 80, 256)             # encoder layer1
     assert ops._wino_ok(B, 512, 512, 10, 32)            # layer4: 4x16 regions over the flattened batch + channel split
     assert not ops._wino_ok(B, 512, 512, 10, 32, allow_split=False) or ops._wino_ok(B, 512, 512, 10, 32)
-    assert not ops._wino_ok(B, 512, 256, 10, 32)        # upconv4_0 forward: too few work items
+    assert ops.WINO_SK and ops._wino_ok(B, 512, 256, 10, 32)   # upconv4_0 forward, 60 regions: stream-K deals its 3,840 (item,
+    ops.WINO_SK = False                                         # chunk) units to 256 workgroups (round 5) ...
+    try:
+        assert not ops._wino_ok(B, 512, 256, 10, 32)            # ... whole items: too few of them (MIOpen, as until round 4)
+    finally:
+        ops.WINO_SK = True
     assert not ops._wino_ok(B, 256, 512, 12, 34)        # its backward: 17 tile columns in a 32-wide region
     assert not ops._wino_ok(B, 96, 32, 160, 512)        # 32 output channels half-fill an item
     assert not ops._wino_ok(B, 32, 96, 162, 514)        # few chunks and a half-empty channel group
