@@ -249,8 +249,7 @@ def _twin_of_trainer(tr, dtype):
     return UNetRef.twin_of(tr.models["DepthModelWrapper"], dtype)
 
 
-@pytest.mark.parametrize("H,W,variant,weights", [(64, 192, "md2", "natural"), (320, 1024, "md2", "natural"),
-                                                  (320, 1024, "md2", "margin"), (64, 192, "dh", "margin")])
+@pytest.mark.parametrize("H,W,variant,weights", [(64, 192, "md2", "natural"), (320, 1024, "md2", "margin"), (64, 192, "dh", "margin")])
 def test_train_step_on_the_unet_vs_cpu_oracle(tmp_path, H, W, variant, weights):
     """ONE Trainer.train_step (attack -> synthesis -> U-Net in train mode -> fused loss -> backward through GradBucket.release /
     collect -> Adam) against oracle.train_step_ref.train_step on the CPU twin fed the SAME batch and the same tie-break noise.

@@ -68,6 +68,8 @@ def test_gradients_within_fp32_conditioning_of_the_fp64_oracle(variant, shape):
     gradient then also carries the proxy term log(|hint - depth| + 1) differentiated through depth = 1/(a + b disp)."""
     N, ops, loss_ref, synth = _mods()
     B, H, W = shape
+    if shape == (2, 320, 1024) and variant == "dh":
+        pytest.skip("headline resolution: md2 and dh_hints cover both normalisations (three float64 oracle runs each)")
     hints = variant == "dh_hints"
     var = "dh" if hints else variant
     pool = GradPool(count_floor=0.0 if variant == "md2" else 2.0 / (H * W))
