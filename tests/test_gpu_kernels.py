@@ -67,6 +67,8 @@ def _pool_seeds(B, H, W, seed):
 @pytest.mark.parametrize("shape", [(2, 32, 96, 21), (2, 192, 640, 22), (1, 48, 80, 5), (3, 64, 200, 9)])
 @pytest.mark.parametrize("with_noise", [False, True])
 def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
+    if not with_noise and shape[1:3] in ((48, 80), (64, 200)):
+        pytest.skip("the noise-free form is covered at two shapes; with the tie-break noise at all four (suite time)")
     N, ops, loss_ref, _, synth, _ = _mods()
     B, H, W, seed0 = shape
     pool = GradPool(count_floor=2.0 / (H * W) if variant == "dh" else 0.0)
