@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-rank workloads of the strong-scaling point (global batch 32 on 8 GPUs) measured on ONE MI355X, and the
+convolutions that still reach the library at those batches -- single-GPU measurements, any multi-GPU figure built from them is a
+PREDICTION (no collective runs here):
+
+    python3 tools/strong_scaling_point.py profiles/r05_strong_scaling_point.json
+
+Runs `bench.py --batch_size B --atk_scenes A --steps 10 --warmup 3 --no_cpu_baseline` and `tools/conv_census.py` as child
+processes for (32, 12) [the headline config], (4, 12) [every rank attacks its own 12 scenes] and (4, 2) [--shared_patch: 12 scenes
+over 8 ranks]."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/strong_scaling_point.json"
+runs = []
+for (B, A, label) in ((32, 12, "weak-scaling rank (the headline config)"),
+                      (4, 12, "strong-scaling rank, global batch 32 on 8 GPUs, every rank attacks its own 12 scenes"),
+                      (4, 2, "strong-scaling rank with --shared_patch: 12 scenes over 8 ranks = 2 scenes on the busiest ranks")):
+    tries = []
+    for _ in range(2):      # launch-bound at two scenes: the first process of a shape also pays MIOpen's kernel search
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--batch_size", str(B), "--atk_scenes", str(A), "--steps",
+                            "10", "--warmup", "3", "--no_cpu_baseline"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True,
+                           cwd=REPO)
+        tries.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    j = min(tries, key=lambda t: t["ms_per_step"])
+    with tempfile.NamedTemporaryFile(suffix=".json", delete=False) as f:
+        tmp = f.name
+    subprocess.run([sys.executable, os.path.join(REPO, "tools", "conv_census.py"), "--batch_size", str(B), "--atk_batch_size", str(A),
+                    "--json", tmp], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=REPO)
+    census = json.load(open(tmp))
+    os.remove(tmp)
+    runs.append({"train_batch": B, "attack_scenes": A, "label": label, "ms_per_step": j["ms_per_step"],
+                 "images_per_s_one_rank": j["value"],
+                 "predicted_8_rank_images_per_s_without_communication": round(8 * j["value"], 1) if B == 4 else None,
+                 "k10_dispatch_falls_to_library": [d for d in census["k10_dispatch"] if not d["takes_K10"]],
+                 "library_forward_calls": sum(d["calls"] for d in census["library_forward"]),
+                 "library_backward_calls": sum(d["calls"] for d in census["library_backward"]),
+                 "library_forward": census["library_forward"], "library_backward": census["library_backward"]})
+    print("%-100s %.2f ms/step, %.1f images/s on this rank; library convolutions: %d forward, %d backward calls" % (
+        label, j["ms_per_step"], j["value"], runs[-1]["library_forward_calls"], runs[-1]["library_backward_calls"]), flush=True)
+json.dump({"what": "per-rank workloads of SURVEY 8d's strong-scaling point measured on ONE MI355X (no collective runs here): bench.py "
+                   "--batch_size B --atk_scenes A, 10 timed steps; tools/conv_census.py lists the convolutions that still reach "
+                   "MIOpen at that batch",
+           "note": "single-GPU measurements of the work ONE rank would do; any multi-GPU figure derived from them is a PREDICTION (it "
+                   "leaves out the 57.3 MB gradient all-reduce and, with --shared_patch, 10 all-reduces of 0.94 MB per step) -- no "
+                   "scaling curve has been measured", "runs": runs}, open(out_path, "w"), indent=1)
