@@ -122,6 +122,7 @@ _SIGNATURES = {
     "dmh_wino_conv3x3_ws": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp, C.c_int64, _fp]),
     "dmh_wino_weight_transform_scaled": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "dmh_wino_conv3x3_act": (C.c_int, [_fp] * 4 + [C.c_int] * 7 + [_fp, _fp]),
+    "dmh_wino_conv3x3_act_ws": (C.c_int, [_fp] * 4 + [C.c_int] * 7 + [_fp, _fp, C.c_int64, _fp]),
     "dmh_wino32_weight_size": (C.c_int64, [C.c_int, C.c_int]),
     "dmh_wino32_weight_transform": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "dmh_wino32_conv3x3": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp]),

@@ -609,8 +609,22 @@ __global__ __launch_bounds__(NT) void wino_sk_fixup_kernel(WArgs a) {
         if (inside && ko < a.K) {
             const float bs = a.bias ? a.bias[ko] : 0.f;
             float* yp = yb + (size_t)ko * a.Ho * a.Wo;
-            *reinterpret_cast<float2*>(yp) = make_float2(acc[v][0] + bs, acc[v][1] + bs);
-            *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(acc[v][2] + bs, acc[v][3] + bs);
+            float y00 = acc[v][0] + bs, y01 = acc[v][1] + bs, y10 = acc[v][2] + bs, y11 = acc[v][3] + bs;
+            if (a.res) {        // the fused epilogue of the main kernel (eval-mode BatchNorm shift = bias, identity / ReLU mask, ReLU)
+                const float* rp = a.res + (yp - a.y);
+                const float2 r0 = *reinterpret_cast<const float2*>(rp), r1 = *reinterpret_cast<const float2*>(rp + a.Wo);
+                if (a.relu & 2) {
+                    y00 = r0.x > 0.f ? y00 : 0.f; y01 = r0.y > 0.f ? y01 : 0.f;
+                    y10 = r1.x > 0.f ? y10 : 0.f; y11 = r1.y > 0.f ? y11 : 0.f;
+                } else {
+                    y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+                }
+            }
+            if (a.relu & 1) {
+                y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+            }
+            *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
+            *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
         }
     }
 }
@@ -658,12 +672,15 @@ int launch_split(WArgs& a, hipStream_t st, bool epi, float* ws, int64_t ws_float
     // with whole items that is ceil(items / CUs) x (one item's channel loop); here every workgroup gets the same number of
     // (item, chunk) units and at most two partial items, whose sums meet in wino_sk_fixup_kernel.  Taken when the model below
     // (3.05 us per chunk, ~4 us per item epilogue, ~6 us for the second launch: profiles/README.md) says it is >= 8 % faster.
-    if (!epi && ws) {
+    // With the fused epilogue only launches of FEW regions take it (< 200: the ones the no-split rule of ops.py turned away,
+    // layer4 at the attack batch): the fix-up kernel then applies shift / identity / ReLU.  The windowed encoder launches have
+    // more regions and keep whole items, bit-identical to their whole-frame twins.
+    if (ws && (!epi || regions < 200)) {
         const int cus = num_cus();
         const long long units = regions * nch;
         const int G = (int)(units / 8 < cus ? units / 8 : cus);
         if (G >= 2 && units < ((long long)1 << 30) && (long long)2 * G * SK_SLOT <= ws_floats) {
-            const int cs = (regions < (3 * cus) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;      // what the legacy path would do
+            const int cs = (!epi && regions < (3 * cus) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;   // what the legacy path would do
             const long long items = regions * cs;
             const double t_cur = (double)((items + cus - 1) / cus) * ((nch / cs) * 3.05 + 4.0) + (cs > 1 ? 6.0 : 0.0);
             const double per = (double)units / G;
@@ -674,9 +691,12 @@ int launch_split(WArgs& a, hipStream_t st, bool epi, float* ws, int64_t ws_float
                 constexpr int TRH = 64 / TRW;
                 constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);
                 constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
-                if (configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, false, true>, smem, configured) != hipSuccess)
+                static std::atomic<uint64_t> configured_epi{0};
+                if ((epi ? configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, true, true>, smem, configured_epi)
+                         : configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, false, true>, smem, configured)) != hipSuccess)
                     return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
-                hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, false, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
+                if (epi) hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, true, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
+                else hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, false, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
                 if (int rc = check_launch("dmh_wino_conv3x3 (stream-K)")) return rc;
                 hipLaunchKernelGGL((wino_sk_fixup_kernel<TRW, FLAT>), dim3((unsigned)(G - 1), 4), dim3(NT), 0, st, a);
                 return check_launch("dmh_wino_conv3x3 (stream-K fix-up)");
@@ -769,6 +789,13 @@ int dmh_wino_conv3x3_ws(const float* x, const float* U, const float* bias, int B
 int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,
                          int K, int H, int W, int pad, float* y, void* stream) {
     return wino_conv_common(x, U, bias, residual, relu, true, B, C, K, H, W, pad, y, stream);
+}
+
+int dmh_wino_conv3x3_act_ws(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,
+                            int K, int H, int W, int pad, float* y, float* workspace, int64_t workspace_floats, void* stream) {
+    DMH_REQUIRE(workspace == nullptr || workspace_floats > 0, "a workspace needs its size");
+    DMH_REQUIRE(workspace == nullptr || ((uintptr_t)workspace & 15) == 0, "the workspace must be 16-byte aligned");
+    return wino_conv_common(x, U, bias, residual, relu, true, B, C, K, H, W, pad, y, stream, workspace, workspace_floats);
 }
 
 }  // extern "C"

@@ -959,7 +959,7 @@ WINO_SK = os.environ.get("DMH_WINO_SK", "1") != "0"       # A/B switch: stream-K
 _WINO_MIN_ITEMS = int(os.environ.get("DMH_WINO_MIN_ITEMS", "200"))      # work items below which MIOpen is level or ahead (A/B switch)
 
 
-def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
+def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True, allow_sk=False):
     """Shapes the Winograd-MFMA kernel takes: channel counts it tiles without waste and enough 64-channel x 64-tile
     work items to fill the 256 CUs (measured crossover, tools/wino_bench.py)."""
     if not WINO_ENABLED or n_in % 8 or n_in < 24 or n_out < 64 or Ho % 2 or Wo % 2 or Ho < 2 or Wo < 2:
@@ -984,6 +984,8 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
     split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
     if allow_split and WINO_SK and regions * nch >= 8 * _WINO_MIN_ITEMS:
         return True     # stream-K (_wino_conv): >= 8 channel chunks for each of >= 200 workgroups, however few the regions
+    if allow_sk and WINO_SK and regions < _WINO_MIN_ITEMS and regions * nch >= 8 * _WINO_MIN_ITEMS:
+        return True     # the same under the fused epilogue (_k10_act): launches of few regions only, see launch_split()
     return regions * split >= _WINO_MIN_ITEMS
 
 
@@ -1061,6 +1063,15 @@ def _sk_workspace(device):
     if ws is None:
         ws = _sk_ws[device] = torch.empty(_SK_WS_FLOATS, device=device, dtype=torch.float32)
     return ws
+
+
+def _k10_act(lib, x, U, bias, res, relu, B, Cc, K, H, W, pad, y, stream):
+    """dmh_wino_conv3x3_act with the stream-K workspace of the current device (the library takes the decomposed form only for
+    launches of few tile regions: layer4 at the attack batch)."""
+    if not WINO_SK:
+        return lib.dmh_wino_conv3x3_act(x, U, bias, res, relu, B, Cc, K, H, W, pad, y, stream)
+    ws = _sk_workspace(torch.device("cuda", torch.cuda.current_device()))
+    return lib.dmh_wino_conv3x3_act_ws(x, U, bias, res, relu, B, Cc, K, H, W, pad, y, N.ptr(ws), ws.numel(), stream)
 
 
 def _wino_conv(x, U, bias, K, pad):
@@ -1202,7 +1213,7 @@ class _ConvBnAct(torch.autograd.Function):
         y = torch.empty((B, K, H + 2 * pad - 2, W + 2 * pad - 2), device=x.device, dtype=torch.float32)
         U = _wino_filter(weight, False, scale)
         nb = 4 * (x.numel() + y.numel() * (1 if residual is None else 2)) + 4 * U.numel()
-        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(N.ptr(x), N.ptr(U), N.ptr(shift), N.ptr(residual),
+        N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, N.ptr(x), N.ptr(U), N.ptr(shift), N.ptr(residual),
                                                                        int(relu), B, Cc, K, H, W, pad, N.ptr(y),
                                                                        N.stream()), nb, 18 * Cc * y.numel()))
         ctx.save_for_backward(x, weight, scale, y if relu else None)
@@ -1247,7 +1258,7 @@ def conv3x3_bn_act(x, weight, scale, shift, residual=None, relu=True, padding=1)
     fills the chip, otherwise conv3x3 followed by the K9 bn_act pass.  No gradient flows to scale / shift."""
     B, Cc, H, W = x.shape
     _reject_affine_grad("conv3x3_bn_act", scale, shift)
-    if x.is_cuda and _wino_ok(B, Cc, weight.shape[0], H + 2 * padding - 2, W + 2 * padding - 2, allow_split=False):
+    if x.is_cuda and _wino_ok(B, Cc, weight.shape[0], H + 2 * padding - 2, W + 2 * padding - 2, allow_split=False, allow_sk=True):
         return _ConvBnAct.apply(_c(x), weight, _c(scale.detach()), _c(shift.detach()),
                                 None if residual is None else _c(residual), bool(relu), int(padding))
     return bn_act(conv3x3(x, weight, None, padding), scale, shift, residual, relu)
@@ -1473,10 +1484,10 @@ class _BasicBlockEval(torch.autograd.Function):
         B, Cc, H, W = x.shape
         out1, y = torch.empty_like(x), torch.empty_like(x)
         nb = 4 * 2 * x.numel()
-        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+        N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, 
             N.ptr(x), N.ptr(_wino_filter(w1, False, s1)), N.ptr(b1), None, 1, B, Cc, Cc, H, W, 1, N.ptr(out1), N.stream()),
             nb, 18 * Cc * x.numel()))
-        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+        N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, 
             N.ptr(out1), N.ptr(_wino_filter(w2, False, s2)), N.ptr(b2), N.ptr(x), 1, B, Cc, Cc, H, W, 1, N.ptr(y), N.stream()),
             nb + 4 * x.numel(), 18 * Cc * x.numel()))
         ctx.save_for_backward(out1, y, w1, s1, w2, s2)
@@ -1495,11 +1506,11 @@ class _BasicBlockEval(torch.autograd.Function):
         g1, g_x = torch.empty_like(g), torch.empty_like(g)
         nb = 4 * 3 * g.numel()
         # conv2's backward-data, masked by [out1 > 0] in the epilogue (flag 2)
-        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+        N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, 
             N.ptr(g2), N.ptr(_wino_filter(w2, True, s2)), None, N.ptr(out1), 2, B, Cc, Cc, H, W, 1, N.ptr(g1), N.stream()),
             nb, 18 * Cc * g.numel()))
         # conv1's backward-data + the identity branch's gradient in the epilogue
-        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+        N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, 
             N.ptr(g1), N.ptr(_wino_filter(w1, True, s1)), None, N.ptr(g2), 0, B, Cc, Cc, H, W, 1, N.ptr(g_x), N.stream()),
             nb, 18 * Cc * g.numel()))
         return g_x, None, None, None, None, None, None
@@ -1512,7 +1523,7 @@ def basic_block_eval_ok(x, w1, w2):
         return False
     B, Cc, H, W = x.shape
     return (tuple(w1.shape) == (Cc, Cc, 3, 3) and tuple(w2.shape) == (Cc, Cc, 3, 3)
-            and _wino_ok(B, Cc, Cc, H, W, allow_split=False))
+            and _wino_ok(B, Cc, Cc, H, W, allow_split=False, allow_sk=True))
 
 
 def basic_block_eval(x, w1, scale1, shift1, w2, scale2, shift2):
@@ -1549,7 +1560,7 @@ class _DownBlockEval(torch.autograd.Function):
         N.check(_timed("down_conv_fwd", lambda: lib.dmh_down_conv_fwd_act(
             N.ptr(x), N.ptr(w3s), N.ptr(wds), N.ptr(b1), N.ptr(bd), 1, B, Cin, Co, H, W, N.ptr(out1), N.ptr(idt), N.stream()),
             4 * (x.numel() + 2 * out1.numel() + w3.numel() + wd.numel()), 20 * Cin * out1.numel()))
-        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+        N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, 
             N.ptr(out1), N.ptr(_wino_filter(w2, False, s2)), N.ptr(b2), N.ptr(idt), 1, B, Co, Co, H // 2, W // 2, 1, N.ptr(y),
             N.stream()), 4 * 3 * out1.numel(), 18 * Co * out1.numel()))
         ctx.save_for_backward(out1, y, w3, s1, wd, sd, w2, s2)
@@ -1575,7 +1586,7 @@ class _DownBlockEval(torch.autograd.Function):
         N.check(_timed("bn_act_bwd", lambda: lib.dmh_bn_act_bwd(N.ptr(y), N.ptr(g), N.ptr(ones), B, Co, (H // 2) * (W // 2), 1,
                                                                N.ptr(g2), None, N.stream()), 12 * g.numel()))
         g1 = torch.empty_like(g)            # gradient of bn1's output: conv2's backward-data masked by [out1 > 0]
-        N.check(_timed("wino_conv3x3", lambda: lib.dmh_wino_conv3x3_act(
+        N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, 
             N.ptr(g2), N.ptr(_wino_filter(w2, True, s2)), None, N.ptr(out1), 2, B, Co, Co, H // 2, W // 2, 1, N.ptr(g1),
             N.stream()), 4 * 3 * g.numel(), 18 * Co * g.numel()))
         w3ts = frozen_memo(("down_w3ts", w3.data_ptr(), w3._version, s1.data_ptr()),
@@ -1597,7 +1608,8 @@ def down_block_eval_ok(x, w3, wd, w2):
     if not (_wino_frozen > 0 and DOWN_NODE_ENABLED and down_convs_ok(x, w3, wd)):
         return False
     Co = w3.shape[0]
-    return tuple(w2.shape) == (Co, Co, 3, 3) and _wino_ok(x.shape[0], Co, Co, x.shape[2] // 2, x.shape[3] // 2, allow_split=False)
+    return tuple(w2.shape) == (Co, Co, 3, 3) and _wino_ok(x.shape[0], Co, Co, x.shape[2] // 2, x.shape[3] // 2, allow_split=False,
+                                                         allow_sk=True)
 
 
 def down_block_eval(x, w3, scale1, shift1, wd, scale_d, shift_d, w2, scale2, shift2, return_skip=False):

@@ -462,6 +462,10 @@ int dmh_wino_weight_transform_scaled(const float* w, int K, int C, int backward,
                                      void* stream);
 int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,
                          int K, int H, int W, int pad, float* y, void* stream);
+/* The same with a caller-owned stream-K workspace (see dmh_wino_conv3x3_ws).  With the fused epilogue only launches of fewer
+ * than 200 tile regions are decomposed (layer4 at the attack batch: 120); the second kernel applies shift / residual / ReLU. */
+int dmh_wino_conv3x3_act_ws(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,
+                            int K, int H, int W, int pad, float* y, float* workspace, int64_t workspace_floats, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * K17 the 32-output-channel form of K10 (work item 32 channels x 128 tiles): the decoder layers whose output channel
