@@ -7,7 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from tests.util import assert_close_frac  # noqa: E402
+from tests.util import assert_close_frac, rel_l2  # noqa: E402
 
 
 def _trainer(tmp_path, extra=()):
@@ -1115,8 +1115,11 @@ def test_basic_block_eval_node_vs_module_path():
                 assert torch.equal(got, again)         # bitwise reproducible (stream-K adds its pieces in a fixed order)
             ggot = torch.autograd.grad(got, x, gy)[0]
         assert_close_frac(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()), name="block out")
-        # ReLU kinks: elements whose pre-activation is within rounding of zero may take the other branch
-        assert_close_frac(ggot, gref, rtol=1e-3, atol=1e-4 * float(gref.abs().max()), max_bad_frac=2e-4, name="block grad")
+        # ReLU kinks: elements whose pre-activation is within rounding of zero may take the other branch.  ONE flipped unit of
+        # the inner activation reaches 9 x C input-gradient elements: 4,608 of layer4's 1.97 M = 0.23 % (measured there: 0.21 %)
+        assert_close_frac(ggot, gref, rtol=1e-3, atol=1e-4 * float(gref.abs().max()), max_bad_frac=2e-4 if C < 512 else 1e-2,
+                          name="block grad")
+        assert rel_l2(ggot, gref) <= 2e-3
 
 
 def test_head_weight_gradient_vs_aten():
