@@ -48,6 +48,7 @@ wrap("dmh_wino32_conv3x3", lambda a: (a[3], a[4], a[5], a[6], a[7], a[8], "k17")
 # the entry points with a stream-K workspace (round 5: ops.py calls these; the library decides per launch)
 wrap("dmh_wino_conv3x3_ws", lambda a: (a[3], a[4], a[5], a[6], a[7], a[8], "plain"))
 wrap("dmh_wino32_conv3x3_ws", lambda a: (a[3], a[4], a[5], a[6], a[7], a[8], "k17"))
+wrap("dmh_wino_conv3x3_act_ws", lambda a: (a[5], a[6], a[7], a[8], a[9], a[10], "epi relu=%d res=%d" % (a[4], a[3] is not None and bool(a[3]))))
 
 from depthmodelhardening_amd.options import MonodepthOptions  # noqa: E402
 from depthmodelhardening_amd.trainer import Trainer  # noqa: E402
