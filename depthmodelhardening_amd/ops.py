@@ -957,6 +957,7 @@ def _wino_filter(weight, backward, scale=None):
 
 WINO_SK = os.environ.get("DMH_WINO_SK", "1") != "0"       # A/B switch: stream-K decomposition of the plain K10 launches
 _WINO_MIN_ITEMS = int(os.environ.get("DMH_WINO_MIN_ITEMS", "200"))      # work items below which MIOpen is level or ahead (A/B switch)
+_WINO_MIN_FILL = float(os.environ.get("DMH_WINO_MIN_FILL", "0.5"))      # real tiles / tiles of the regions below which MIOpen is ahead (A/B switch)
 
 
 def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True, allow_sk=False):
@@ -976,7 +977,7 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True, allow_sk=False):
         cols = -(-wt // 16) * 16
     else:
         rows, cols = B * -(-ht // 2) * 2, -(-wt // 32) * 32
-    if B * ht * wt < 0.6 * rows * cols:     # ragged image: too many empty tiles (e.g. 17 tile columns in a 32-wide region)
+    if B * ht * wt < _WINO_MIN_FILL * rows * cols:     # ragged image: too many empty tiles (e.g. 17 tile columns in a 32-wide region)
         return False
     regions = (rows // (4 if narrow else 2)) * (cols // (16 if narrow else 32))
     regions *= -(-n_out // 64)

@@ -139,7 +139,8 @@ def test_conv_dispatch_rule_mirrors_the_launcher():
         assert not ops._wino_ok(B, 512, 256, 10, 32)            # ... whole items: too few of them (MIOpen, as until round 4)
     finally:
         ops.WINO_SK = True
-    assert not ops._wino_ok(B, 256, 512, 12, 34)        # its backward: 17 tile columns in a 32-wide region
+    assert ops._wino_ok(B, 256, 512, 12, 34)            # its backward: 17 tile columns in a 32-wide region fill 53 % of the
+    assert not ops._wino_ok(B, 256, 512, 10, 34)        # tiles (taken since round 5, 120 against MIOpen's 138 us); 44 %: MIOpen
     assert not ops._wino_ok(B, 96, 32, 160, 512)        # 32 output channels half-fill an item
     assert not ops._wino_ok(B, 32, 96, 162, 514)        # few chunks and a half-empty channel group
     assert not ops._wino_ok(B, 64, 64, 81, 256)         # odd output height
