@@ -70,6 +70,13 @@ def test_convolution_entry_points_reject_bad_shapes_without_gpu():
     assert b"multiple of 8" in lib.dmh_last_error()
     assert lib.dmh_wino_conv3x3(one, one, None, 1, 32, 64, 9, 8, 1, one, None) != 0          # odd output height
     assert lib.dmh_wino_conv3x3_act(one, one, None, None, 1, 1, 32, 64, 8, 8, 3, one, None) != 0   # pad
+    # the workspace forms check their shapes before anything else (a NULL workspace is legal: whole items)
+    assert lib.dmh_wino_conv3x3_ws(one, one, None, 1, 16, 64, 8, 8, 1, one, None, 0, None) != 0
+    assert lib.dmh_wino_conv3x3_ws(one, one, None, 1, 32, 64, 9, 8, 1, one, one, 1 << 23, None) != 0
+    assert lib.dmh_wino_conv3x3_act_ws(one, one, None, None, 1, 1, 32, 64, 8, 8, 3, one, one, 1 << 23, None) != 0
+    assert lib.dmh_wino32_conv3x3_ws(one, one, None, 1, 16, 32, 8, 8, 1, one, one, 1 << 23, None) != 0
+    assert lib.dmh_avg_pyramid(one, 3, 321, 1024, one, one, one, None) != 0                 # sizes must be multiples of 8
+    assert lib.dmh_gt_depth_mse_fwd(one, one, one, 0, one, 0, 64, 0.1, 100.0, one, one, None) != 0   # empty batch
     assert lib.dmh_conv3x3_small(one, one, None, 1, 64, 64, 8, 8, 1, 0, one, None) != 0
     assert b"channel counts" in lib.dmh_last_error()
     assert lib.dmh_conv3x3_head(one, one, None, 1, 24, 8, 8, 1, one, None) != 0
