@@ -31,6 +31,76 @@ from .layers import SSIM, get_smooth_loss
 from .my_utils import ori_H, ori_W
 
 
+class StepLog:
+    """JSONL step log (metrics / logging; the reference prints examples/s from time.time() around a step,
+    MD2/trainer.py:309-317,706-716).  mark(name) records a HIP event on the current stream at a phase boundary; the line of
+    iteration i is written when iteration i + 1 ends -- its events have long completed by then, so reading them (and the
+    loss) does not stall the host.  Off (no events, no file) unless a path is given."""
+
+    def __init__(self, path, images_per_step):
+        self.file = None
+        self.images = images_per_step
+        self.marks, self.pending, self.t0, self.host = [], None, None, None
+        if path:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            self.file = open(path, "a")
+        self.cuda = torch.cuda.is_available()
+
+    def mark(self, name):
+        if self.file is None:
+            return
+        if self.cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+        else:
+            ev = time.perf_counter()
+        self.marks.append((name, ev))
+
+    def end_step(self, step, epoch, loss):
+        """Close iteration ``step``: its marks and loss are parked, the previous iteration's line is written.  The loss travels
+        to a pinned host slot by an asynchronous copy (float(tensor) would wait for everything enqueued so far, i.e. drain the
+        queue once per iteration: measured 91.8 instead of 86.6 ms per step at the headline configuration)."""
+        if self.file is None:
+            return
+        now = time.perf_counter()
+        self._flush()
+        done = None
+        if torch.is_tensor(loss) and loss.is_cuda:
+            if self.host is None:
+                self.host = torch.empty(2, dtype=torch.float32, pin_memory=True)
+            slot = self.host[step & 1:(step & 1) + 1]
+            slot.copy_(loss.detach().reshape(1), non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            loss = slot
+        self.pending = (step, epoch, loss, done, self.marks, self.t0, now)
+        self.marks, self.t0 = [], now
+
+    def _flush(self):
+        if self.pending is None:
+            return
+        step, epoch, loss, done, marks, t0, now = self.pending
+        if done is not None:
+            done.synchronize()      # recorded an iteration ago
+        phases = {}
+        for (_, a), (name, b) in zip(marks[:-1], marks[1:]):
+            ms = a.elapsed_time(b) if self.cuda else (b - a) * 1e3
+            phases[name] = round(phases.get(name, 0.0) + ms, 3)
+        line = {"step": step, "epoch": epoch, "loss": float(loss), "phase_ms": phases}
+        if t0 is not None:      # host time from the end of the previous iteration's enqueue to the end of this one's
+            line["images_per_s"] = round(self.images / max(now - t0, 1e-9), 2)
+            line["wall_ms"] = round((now - t0) * 1e3, 3)
+        self.file.write(json.dumps(line) + "\n")
+        self.file.flush()
+        self.pending = None
+
+    def close(self):
+        if self.file is not None:
+            self._flush()
+            self.file.close()
+            self.file = None
+
+
 class LazyOutputs(dict):
     """The ``outputs`` dict of process_batch.  Entries registered with ``lazy(key, fn)`` are produced on first access:
     the fused loss keeps its per-scale selection maps as one packed byte per pixel, and the float maps the reference
@@ -172,6 +242,8 @@ class Trainer:
         self.tie_break_noise = None     # test hook: four [B,1,H,W] tensors (already x 1e-5) instead of the in-kernel Philox draw
         self.timings = {}
         self.val_eval_count = 10   # evaluate_attacks(..., eval_count=10), MD2/trainer.py:465
+        self.step_log = StepLog(getattr(self.opt, "step_log", "") if self.rank == 0 else "",
+                                self.opt.batch_size * self.world_size)
         if self.rank == 0:
             self.save_opts()
 
@@ -189,12 +261,15 @@ class Trainer:
         self.epoch = 0
         self.step = 0
         self.start_time = time.time()
-        for self.epoch in range(self.opt.num_epochs):
-            self.run_epoch()
-            if (self.epoch + 1) % self.opt.save_frequency == 0 and self.rank == 0:
-                self.save_model()
-            if self.opt.max_steps and self.step >= self.opt.max_steps:
-                break
+        try:
+            for self.epoch in range(self.opt.num_epochs):
+                self.run_epoch()
+                if (self.epoch + 1) % self.opt.save_frequency == 0 and self.rank == 0:
+                    self.save_model()
+                if self.opt.max_steps and self.step >= self.opt.max_steps:
+                    break
+        finally:
+            self.step_log.close()       # writes the last iteration's line
 
     def update_adv_obj(self):
         """dataset.update_adv_obj on this iteration's attack scenes (MD2/trainer.py:300-307): --atk_batch_size scenes per
@@ -209,24 +284,33 @@ class Trainer:
         """One iteration of run_epoch's loop body (MD2/trainer.py:297-315): attack -> forward -> loss ->
         backward -> gradient all-reduce -> Adam.  Returns the losses dict."""
         overlap = self.world_size > 1 and not self.opt.sync_attack
+        log = self.step_log
+        log.mark("start")
         if overlap:
             # the previous iteration left its all-reduce in flight: enqueue this iteration's attack first
             # (it reads weights one optimiser step old), then apply the averaged gradients
             if self.opt.adv_train:
                 self.update_adv_obj()
+                log.mark("attack")
             self._apply_pending_update()
+            log.mark("all_reduce_wait+adam")
         else:
             self._apply_pending_update()
             if self.opt.adv_train:
                 self.update_adv_obj()
+                log.mark("attack")
         inputs = self.dataset.next_batch(self.opt.batch_size)
         outputs, losses = self.process_batch(inputs)
+        log.mark("forward+loss")
         with self.bucket.released():             # model_optimizer.zero_grad(); gradients land in the flat bucket afterwards
             losses["loss"].backward()
+        log.mark("backward")
         self.bucket.start_all_reduce()
         self._pending = True
         if not overlap:
             self._apply_pending_update()
+            log.mark("all_reduce+adam")
+        log.end_step(getattr(self, "step", 0), getattr(self, "epoch", 0), losses["loss"])
         return losses
 
     def warm_kernels(self):

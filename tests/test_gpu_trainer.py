@@ -61,13 +61,25 @@ def test_generate_images_pred_materialized(tmp_path):
 
 @pytest.mark.parametrize("norm_type", ["l_inf", "l_0"])
 def test_adversarial_train_steps(tmp_path, norm_type):
-    tr = _trainer(tmp_path, ["--adv_train", "--norm_type", norm_type, "--supervised_adv", "--contrastive_learning"])
+    import json
+    log_path = os.path.join(str(tmp_path), "steps.jsonl")
+    tr = _trainer(tmp_path, ["--adv_train", "--norm_type", norm_type, "--supervised_adv", "--contrastive_learning",
+                             "--step_log", log_path])
     tr.set_train()
     w0 = tr.models["depth"].decoder[0].conv.conv.weight.detach().clone()
     p0 = tr.dataset.obj_img_adv.clone()
+    seen = []
     for _ in range(2):
         losses = tr.train_step()
+        seen.append(losses["loss"])
     torch.cuda.synchronize()
+    tr.step_log.close()
+    lines = [json.loads(l) for l in open(log_path)]         # --step_log: one line per iteration, phases from HIP events
+    assert len(lines) == 2 and [l["loss"] for l in lines] == [float(v) for v in seen]
+    for l in lines:
+        assert list(l["phase_ms"]) == ["attack", "forward+loss", "backward", "all_reduce+adam"]
+        assert all(v > 0 for v in l["phase_ms"].values())
+    assert sum(lines[1]["phase_ms"].values()) <= 1.5 * lines[1]["wall_ms"] + 50     # GPU phases of a step vs its host time
     assert {"loss", "sup_loss", "contras_loss"} <= set(losses) and torch.isfinite(losses["loss"])
     assert not torch.equal(tr.models["depth"].decoder[0].conv.conv.weight, w0), "Adam did not update the weights"
     assert not torch.equal(tr.dataset.obj_img_adv, p0), "the attack did not update the object patch"

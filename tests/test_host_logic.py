@@ -230,3 +230,34 @@ def test_color_jitter_matches_the_torchvision_restatement():
     with __import__("pytest").raises(ValueError):
         cj._hue(x, 0.7)
 
+
+
+def test_step_log_writes_one_line_per_iteration_one_iteration_late(tmp_path):
+    """trainer.StepLog (metrics / logging): phases are the intervals between consecutive marks, named by
+    the mark that ends them; the line of iteration i is written at the end of iteration i + 1 (or by close()); no path = off."""
+    import json
+    import time
+
+    from depthmodelhardening_amd.trainer import StepLog
+    path = str(tmp_path / "sub" / "steps.jsonl")
+    log = StepLog(path, 32)
+    log.cuda = False                 # host clocks: this test has no GPU
+    for i in range(3):
+        log.mark("start")
+        time.sleep(0.004)
+        log.mark("attack")
+        time.sleep(0.002)
+        log.mark("forward+loss")
+        log.end_step(i, 0, torch.tensor(1.5 + i))
+        assert len(open(path).read().splitlines()) == i         # one iteration late
+    log.close()
+    lines = [json.loads(l) for l in open(path)]
+    assert [l["step"] for l in lines] == [0, 1, 2] and [l["loss"] for l in lines] == [1.5, 2.5, 3.5]
+    for l in lines:
+        assert set(l["phase_ms"]) == {"attack", "forward+loss"} and l["phase_ms"]["attack"] >= 3.9 > l["phase_ms"]["forward+loss"] >= 1.9
+    assert "images_per_s" not in lines[0] and all(6 <= l["wall_ms"] < 1000 and abs(l["images_per_s"] * l["wall_ms"] / 32e3 - 1) < 1e-2 for l in lines[1:])
+    off = StepLog("", 32)
+    off.mark("start")
+    off.end_step(0, 0, 1.0)
+    off.close()
+    assert not off.marks and off.file is None
