@@ -1052,17 +1052,19 @@ def _wino32_conv(x, U, bias, K, pad):
     return y
 
 
-_sk_ws = {}         # device -> workspace of the stream-K launches (caller-owned: the library keeps nothing)
+_sk_ws = {}         # (device, stream) -> workspace of the stream-K launches (caller-owned: the library keeps nothing)
 _SK_WS_FLOATS = 8 << 20         # 32 MB = 2 slots x 256 workgroups x 16,384 floats (one partial work item each)
 
 
 def _sk_workspace(device):
     """The library decides per launch (dmh_wino_conv3x3_ws / dmh_wino32_conv3x3_ws): stream-K where whole work items would leave
-    the chip idle for part of a round.  ONE buffer per device -- the launches of a stream are ordered, and the fix-up kernel
-    that reads the partial items is enqueued right behind the kernel that wrote them."""
-    ws = _sk_ws.get(device)
+    the chip idle for part of a round.  ONE buffer per device AND stream -- the launches of a stream are ordered, and the fix-up
+    kernel that reads the partial items is enqueued right behind the kernel that wrote them; two streams that run convolutions
+    side by side must not share the slots."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    ws = _sk_ws.get(key)
     if ws is None:
-        ws = _sk_ws[device] = torch.empty(_SK_WS_FLOATS, device=device, dtype=torch.float32)
+        ws = _sk_ws[key] = torch.empty(_SK_WS_FLOATS, device=device, dtype=torch.float32)
     return ws
 
 

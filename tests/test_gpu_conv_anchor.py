@@ -229,6 +229,29 @@ def test_stream_k_is_deterministic_and_equals_whole_items():
         assert e1 <= 1.5 * e0 + 1e-7, (e1, e0)
 
 
+def test_stream_k_on_two_streams_side_by_side():
+    """The partial work items of a stream-K launch live in a workspace the CALLER owns (ops._sk_workspace: one per device and
+    stream).  Two streams that run decomposed convolutions at the same time give, bit for bit, what each gives alone."""
+    from depthmodelhardening_amd import ops
+    shapes = ((12, 512, 256, 12, 34, 0), (12, 512, 256, 22, 30, 0))
+    data = [_data(*sh[:5], 31 + i) for i, sh in enumerate(shapes)]
+    with ops.frozen_weights():
+        alone = [ops.conv3x3(x, w, None, sh[5]) for (x, w), sh in zip(data, shapes)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        outs = [[], []]
+        for s in streams:
+            s.wait_stream(torch.cuda.current_stream())
+        for _ in range(6):
+            for i, s in enumerate(streams):
+                with torch.cuda.stream(s):
+                    outs[i].append(ops.conv3x3(data[i][0], data[i][1], None, shapes[i][5]))
+        torch.cuda.synchronize()
+    assert len({k[1] for k in ops._sk_ws}) >= 3         # the default stream's workspace and one per side stream
+    for i in range(2):
+        assert all(torch.equal(o, alone[i]) for o in outs[i]), i
+
+
 def test_stream_k_of_the_32_channel_kernel():
     """K17's stream-K form (csrc/wino32_conv.hip) through the C ABI at the attack's window shapes of upconv(1,1) / upconv(1,0): the
     same result as the whole-item launch up to fp32 re-association, against float64, run twice bit for bit."""
