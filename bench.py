@@ -343,6 +343,8 @@ def parse(argv=None):
     ap.add_argument("--loss_variant", type=str, default="md2", choices=["md2", "dh"])
     ap.add_argument("--harness", type=str, default="trainer", choices=["trainer", "physical"],
                     help="physical = BASELINE config 5: the physical_adv_training.py hardening loop (patch attack)")
+    ap.add_argument("--graph_attack", action="store_true",
+                    help="replay steps 2 .. n-1 of the L_inf attack from a HIP graph of step 1 (trainer --graph_attack)")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--device", type=str, default="cuda", choices=["cuda", "cpu"],
                     help="cpu: launcher / collective plumbing test only (gloo); no kernels run")
@@ -447,6 +449,8 @@ def run_rank(a):
         if a.shared_patch:
             argv.append("--shared_patch")
         argv += ["--atk_batch_size", str(a.atk_scenes)]
+        if a.graph_attack:
+            argv.append("--graph_attack")
         if a.supervised_adv:
             argv.append("--supervised_adv")
         if a.contrastive_learning:
@@ -649,7 +653,7 @@ def run_rank(a):
                           "global_batch": a.batch_size * world, "per_gpu_batch": a.batch_size, "parallelism": "dp%d" % world,
                           "attack_overlap": bool(world > 1 and not a.sync_attack and a.harness == "trainer"),
                           "attack_scenes": a.atk_scenes, "shared_patch": bool(a.shared_patch),
-                          "final_loss": round(loss_val, 6)},
+                          "graph_attack": bool(a.graph_attack), "final_loss": round(loss_val, 6)},
                "roofline": roof}
         if atk_iters is not None:
             out["config"]["attack_iterations_per_step"] = atk_iters

@@ -48,8 +48,16 @@ def profile_bytes():
             for k, v in _profile.items() if v}
 
 
+def profiling_every_launch():
+    """True while enable_profile(True) without ``only`` is in force: every instrumented launch carries an event pair (bench.py's
+    one fully instrumented step).  Events cannot be read back from a captured HIP graph, so the attack runs that step eagerly."""
+    return _profile is not None and _profile_only is None
+
+
 def _timed(name, launch, nbytes=0, flops=0):
     if _profile is None or (_profile_only is not None and not name.startswith(_profile_only)):
+        return launch()
+    if torch.cuda.is_current_stream_capturing():      # an event recorded into a graph has no time stamp to read
         return launch()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -1980,6 +1988,23 @@ class CleanHead(object):
         self.dirty = None           # (origin table [B,2], (rows, cols)) of the window written by the last step
         self.pristine2, self.work2 = f2, (None if f2 is None else f2.clone())     # the same for feature 2 (layer2's output)
         self.dirty2 = None
+        self._own = {}              # private copies of the origins of `dirty` / `dirty2` (mark(..., keep=True))
+
+    def mark(self, which, org, size, keep):
+        """Record the window step ``which`` (1: feature 1, 2: feature 2) has just written.  ``keep``: the origin table will be
+        OVERWRITTEN before restore() reads it (an attack replayed from a HIP graph keeps one table buffer and copies every
+        step's origins into it: torchattacks/attacks/phy_obj_atk.py, _graph_steps) -- the origins are then copied into a
+        buffer of this object, by a device copy that is part of the step."""
+        if keep:
+            own = self._own.get(which)
+            if own is None or own.shape != org.shape:
+                own = self._own[which] = torch.empty_like(org)
+            own.copy_(org)
+            org = own
+        if which == 1:
+            self.dirty = (org, size)
+        else:
+            self.dirty2 = (org, size)
 
     @staticmethod
     def _put_back(pristine, work, dirty):
@@ -2048,7 +2073,7 @@ class _EncHeadInc(torch.autograd.Function):
         N.check(_timed("roi_paste", lambda: lib.dmh_roi_paste(N.ptr(f1c), N.ptr(org["hl"]), hl, wl, N.ptr(org["f1s"]), B, 64,
                                                              H // 4, W // 4, hs_, ws_, N.ptr(clean.work), st),
                        8 * B * 64 * hs_ * ws_))
-        clean.dirty = (org["f1s"], (hs_, ws_))
+        clean.mark(1, org["f1s"], (hs_, ws_), getattr(plan, "table_rewritten", False))
         saved = [f0, arg, s0, o1a, ya, o1b, f1c, tab, w_stem, w1a, s1a, w2a, s2a, w1b, s1b, w2b, s2b]
         ctx.plan, ctx.img, ctx.l2 = plan, (H, W), bool(l2)
         ctx.set_materialize_grads(False)
@@ -2083,7 +2108,7 @@ class _EncHeadInc(torch.autograd.Function):
         hf, wf = plan.size["f2s"]
         N.check(_timed("roi_paste", lambda: lib.dmh_roi_paste(N.ptr(f2c), N.ptr(org["h3"]), h3, w3_, N.ptr(org["f2s"]), B, Co,
                                                              H // 8, W // 8, hf, wf, N.ptr(clean.work2), st), 8 * B * Co * hf * wf))
-        clean.dirty2 = (org["f2s"], (hf, wf))
+        clean.mark(2, org["f2s"], (hf, wf), getattr(plan, "table_rewritten", False))
         ctx.save_for_backward(*saved, q1, y2a, q2, f2c, w3, sc1, wd, scd, w2, sc2, v1, t1, v2, t2)
         return f0, clean.work.detach(), clean.work2.detach()
 

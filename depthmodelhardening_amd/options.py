@@ -105,6 +105,10 @@ class MonodepthOptions:
         p.add_argument("--no_flip_sides", action="store_true",
                        help="synthetic data: always camera side 'l' and no horizontal flips")
         p.add_argument("--max_steps", type=int, default=0, help="stop after this many iterations (0 = full epochs)")
+        p.add_argument("--graph_attack", action="store_true",
+                       help="L_inf attack: one set of window sizes for all steps, step 1 captured in a HIP graph and replayed "
+                            "for steps 2 .. n-1 (torchattacks/attacks/phy_obj_atk.py, use_graph): takes the step's ~130 launches "
+                            "off the host; for ranks whose GPU share is small (strong scaling)")
         p.add_argument("--step_log", type=str, default="",
                        help="JSONL step log written by rank 0 (SURVEY.md section 5): one line per iteration with the loss, "
                             "images/s and the GPU time of each phase (attack / forward + loss / backward / all-reduce + "

@@ -55,9 +55,10 @@ def _size_for(need, frame):
     return min(-(-(need + 1) // 2) * 2, frame)
 
 
-def _fit(lo, hi, frame):
-    """One axis: a common size and per-scene even origins with origin <= lo, origin + size >= hi, inside [0, frame]."""
-    size = _size_for(int((hi - lo).max()), frame)
+def _fit(lo, hi, frame, min_size=0):
+    """One axis: a common size (at least ``min_size``) and per-scene even origins with origin <= lo, origin + size >= hi,
+    inside [0, frame]."""
+    size = min(max(_size_for(int((hi - lo).max()), frame), int(min_size)), frame)
     if size >= frame:
         return frame, np.zeros_like(lo)
     org = np.minimum(lo, frame - size) & ~1
@@ -77,8 +78,12 @@ class RoiPlan(object):
     disparity.  ``size[name]`` = (rows, columns), ``org[name]`` = int32 [B, 2] for every name in TABLE; ``depth`` = level of
     the deepest windowed decoder stage (the windows above it are planned too, and simply unused)."""
 
-    def __init__(self, boxes, H, W, depth=3):
+    def __init__(self, boxes, H, W, depth=3, min_size=None):
+        """``min_size`` (a ``size`` dict of another plan, or None): no window comes out smaller than its entry there.  Windows
+        only have to COVER what is read, so a larger one is as exact as the smallest; common_size_plans() uses this to give all
+        steps of an attack the same tensor shapes (one captured HIP graph replays them all)."""
         boxes = np.asarray(boxes, dtype=np.int64).reshape(-1, 4)
+        self._min = dict(min_size) if min_size else {}
         if H % 32 or W % 32 or H < 64 or W < 64:
             raise RuntimeError("RoiPlan: frame must be a multiple of 32 and at least 64 x 64")
         if depth not in (2, 3, 4):
@@ -119,6 +124,7 @@ class RoiPlan(object):
         qx = np.maximum((os_[:, 1] >> 1) - _L1_RING, 0), np.minimum(((os_[:, 1] + ws) >> 1) + 1 + _L1_RING, W >> 2)
         hq = min(-(-(int((qy[1] - qy[0]).max()) + 1) // 8) * 8, H >> 2)      # same-size convolutions: whole 4 x 16-tile regions
         wq = min(-(-(int((qx[1] - qx[0]).max()) + 1) // 32) * 32, W >> 2)
+        hq, wq = max(hq, self._min.get("l1", (0, 0))[0]), max(wq, self._min.get("l1", (0, 0))[1])
         self.size["l1"] = (int(hq), int(wq))
         self.org["l1"] = np.stack([np.minimum(qy[0], (H >> 2) - hq) & ~1, np.minimum(qx[0], (W >> 2) - wq) & ~1], 1).astype(np.int32)
         # feature 0's gradient is read by the encoder head on "gz": the rectangle the tail writes holds both
@@ -134,10 +140,14 @@ class RoiPlan(object):
         # (exactly the changed cells, no alignment slack: one more cell would lie in the ring the compact window spoils)
         for ax, (lo, hi, frame) in enumerate(((np.maximum(py[0] - 4, 0), np.minimum(py[1] + 4, H >> 2), H >> 2),
                                               (np.maximum(px[0] - 4, 0), np.minimum(px[1] + 4, W >> 2), W >> 2))):
-            size = int((hi - lo).max())
+            size = min(max(int((hi - lo).max()), self._min.get("f1s", (0, 0))[ax]), frame)
             fs = (size, np.minimum(lo, frame - size)) if ax == 0 else fs + (size, np.minimum(lo, frame - size))
         self.size["f1s"] = (fs[0], fs[2])
         self.org["f1s"] = np.stack([fs[1], fs[3]], 1).astype(np.int32)
+        # a window that min_size made larger than the changed cells + 4 is written into the cached feature all the same: the
+        # compact window below must then hold valid values on all of it, i.e. treat "f1s" shrunk by layer1's reach as changed
+        py = np.minimum(py[0], fs[1] + 4), np.maximum(py[1], fs[1] + fs[0] - 4)
+        px = np.minimum(px[0], fs[3] + 4), np.maximum(px[1], fs[3] + fs[2] - 4)
         # one compact window serves forward and backward: it holds the changed cells and the cells the backward reads (the
         # pooling cells under "gz"), plus the rings the same-size convolutions and the pooling spoil at its edge
         by = np.minimum(py[0], os_[:, 0] >> 1), np.maximum(py[1], ((os_[:, 0] + hs) >> 1) + 1)
@@ -154,9 +164,9 @@ class RoiPlan(object):
         p3y = f1o[:, 0] >> 1, np.minimum(((f1o[:, 0] + f1h) >> 1) + 1, H >> 3)
         p3x = f1o[:, 1] >> 1, np.minimum(((f1o[:, 1] + f1w) >> 1) + 1, W >> 3)
         fs = ()
-        for lo, hi, frame in ((np.maximum(p3y[0] - 3, 0), np.minimum(p3y[1] + 3, H >> 3), H >> 3),
-                              (np.maximum(p3x[0] - 3, 0), np.minimum(p3x[1] + 3, W >> 3), W >> 3)):
-            size = int((hi - lo).max())
+        for ax, (lo, hi, frame) in enumerate(((np.maximum(p3y[0] - 3, 0), np.minimum(p3y[1] + 3, H >> 3), H >> 3),
+                                              (np.maximum(p3x[0] - 3, 0), np.minimum(p3x[1] + 3, W >> 3), W >> 3))):
+            size = min(max(int((hi - lo).max()), self._min.get("f2s", (0, 0))[ax]), frame)
             fs += (size, np.minimum(lo, frame - size))
         self.size["f2s"] = (fs[0], fs[2])
         self.org["f2s"] = np.stack([fs[1], fs[3]], 1).astype(np.int32)
@@ -183,8 +193,9 @@ class RoiPlan(object):
 
     def _put(self, name, ry, rx):
         lvl = LEVEL[name]
-        hc, oy = _fit(ry[0], ry[1], self.H >> lvl)
-        wc, ox = _fit(rx[0], rx[1], self.W >> lvl)
+        mh, mw = self._min.get(name, (0, 0))
+        hc, oy = _fit(ry[0], ry[1], self.H >> lvl, mh)
+        wc, ox = _fit(rx[0], rx[1], self.W >> lvl, mw)
         self.size[name] = (int(hc), int(wc))
         self.org[name] = np.stack([oy, ox], 1).astype(np.int32)
 
@@ -223,6 +234,23 @@ class RoiPlan(object):
     def area_fraction(self):
         """Window area / frame area per window (reporting)."""
         return {n: self.size[n][0] * self.size[n][1] / float((self.H >> LEVEL[n]) * (self.W >> LEVEL[n])) for n in TABLE}
+
+
+def common_size_plans(boxes_per_step, H, W, depth=3, max_rounds=8):
+    """One RoiPlan per entry of ``boxes_per_step`` (the steps of one attack), all with the SAME window sizes and the same
+    path flags, so that every step launches the same kernels on tensors of the same shapes: the element-wise maximum of the
+    steps' sizes is fed back as ``min_size`` until nothing grows any more (a larger window makes the windows derived from it
+    larger, hence the iteration; sizes are bounded by the frame).  Returns None when the steps cannot be brought to one shape
+    (flags that differ, no fixed point within ``max_rounds``): the caller then runs its steps one by one."""
+    mins = None
+    for _ in range(max_rounds):
+        plans = [RoiPlan(b, H, W, depth=depth, min_size=mins) for b in boxes_per_step]
+        top = {n: (max(p.size[n][0] for p in plans), max(p.size[n][1] for p in plans)) for n in TABLE}
+        if all(p.size == top for p in plans):
+            flags = {(p.layer2_incremental_ok, p.head_incremental_ok) for p in plans}
+            return plans if len(flags) == 1 else None
+        mins = top
+    return None
 
 
 def mask_box(quad, src_size, out_size, margin=2):

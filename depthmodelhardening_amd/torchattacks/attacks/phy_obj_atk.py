@@ -19,7 +19,7 @@ import torch
 from ... import ops
 from ...my_utils import object_dataset_root, ori_H, ori_W, to_device_async
 from ...physicalTrans import PhysicalTrans
-from ...roi import RoiPlan
+from ...roi import RoiPlan, common_size_plans
 from ..attack import Attack
 
 
@@ -56,6 +56,15 @@ class Phy_obj_atk(Attack):
         # None = the reference's behaviour.
         self.pose_group = None
         self.use_roi = True     # evaluate the cost on windows around the object when the model offers masked_sq_mean
+        # use_graph: give all steps of the attack the same window sizes (roi.common_size_plans), run step 0 eagerly, capture
+        # step 1 in a HIP graph and replay it for the others -- ~130 kernel launches per step leave the host as ONE graph
+        # launch (the step's Python + ctypes enqueue, ~2.5 ms, is what bounds a rank whose GPU share is small: DESIGN.md
+        # section 7).  Same arithmetic as the eager loop on the same windows, bit for bit.  Off by default: at the headline
+        # batch the GPU is the limiter and the common windows are a few per cent larger than each step's own.
+        self.use_graph = False
+        self.common_windows = False     # the common-size window plans without the graph (tests: the eager twin of use_graph)
+        self._graph_pool = None
+        self._graph = None      # (graph of the previous attack, event behind its last replay): destroyed once it has run
         # Data-parallel "shared patch" mode: shard = (rank, world, process group or None).  The
         # reference attacks ONE patch on batch_size scenes per iteration (MD2/trainer.py:300-307, mono_dataset.py:178-184);
         # with a shard every rank holds scenes rank, rank + world, ... of that batch (``images`` = its own scenes), the pose
@@ -135,18 +144,29 @@ class Phy_obj_atk(Attack):
         # the cost reads the disparity under the object only: a model that can evaluate mean((disp * mask)^2) on windows
         # around the object (DepthModelWrapper.masked_sq_mean: exact) gets the per-step boxes, all tables in one H2D copy
         plans = tabs = clean = None
+        graph = False
         if ops.ROI_ENABLED and self.use_roi and hasattr(self.model, "masked_sq_mean") and self.device.type == "cuda":
-            plans = [RoiPlan(pt.mask_boxes(z0, al, self.scene_size), *self.scene_size, depth=ops.ROI_DEPTH) for z0, al in draws]
+            boxes = [pt.mask_boxes(z0, al, self.scene_size) for z0, al in draws]
+            if self.use_graph or self.common_windows:
+                plans = common_size_plans(boxes, *self.scene_size, depth=ops.ROI_DEPTH)
+                # a graph holds no collective (shard), no host read (trace), and needs a step to replay
+                graph = bool(self.use_graph and plans is not None and mine is None and self.trace is None and self.steps >= 3
+                             and not ops.profiling_every_launch())
+            if plans is None:
+                plans = [RoiPlan(b, *self.scene_size, depth=ops.ROI_DEPTH) for b in boxes]
             tabs = to_device_async(np.stack([p.table() for p in plans], 0), self.device)
-            for p_, t_ in zip(plans, tabs):     # one H2D copy for all steps; each plan keeps ITS slice (RoiPlan.bind_table)
-                p_.bind_table(t_)
+            if not graph:
+                for p_, t_ in zip(plans, tabs):     # one H2D copy for all steps; each plan keeps ITS slice (RoiPlan.bind_table)
+                    p_.bind_table(t_)
             # the frames without the object (a paste with an all-zero mask: scene (1 - 0) + patch 0, then the same Resize):
             # every step's pasted frames equal them outside the step's boxes, so the model may start from their features
             with torch.no_grad():
                 clean, _ = ops.eot_paste(scene_imgs, self.obj_img, torch.zeros_like(mask), coeffs[0], l_pad, t_pad,
                                          self.scene_size)
 
-        for s in range(self.steps):
+        if graph:
+            obj_img_adv = self._graph_steps(scene_imgs, obj_img_adv, mask, coeffs, plans[0], tabs, clean, l_pad, t_pad)
+        for s in range(0 if not graph else self.steps, self.steps):
             obj_img_adv.requires_grad_()
             adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[s], l_pad, t_pad,
                                                       self.scene_size)
@@ -170,6 +190,68 @@ class Phy_obj_atk(Attack):
                                                       self.scene_size)
             ben_scenes, _ = ops.eot_paste(scene_imgs, self.obj_img, mask, coeffs[-1], l_pad, t_pad, self.scene_size)
         return adv_scenes, ben_scenes, obj_masks_out, obj_img_adv
+
+    def _graph_steps(self, scene_imgs, obj_img_adv, mask, coeffs, plan, tabs, clean, l_pad, t_pad):
+        """All steps of the attack with ONE captured step.  The step reads its pose (homography coefficients, window origins)
+        and its patch from fixed device buffers, so a replay after two small device copies IS the next step; every window plan
+        of the attack has the sizes of ``plan`` (roi.common_size_plans).  Step 0 runs eagerly: it fills the caches of the
+        frozen-weights scope (transformed filters, the clean frames' features), which must not be captured and replayed.
+        Capture goes through CUDAGraph.capture_begin / capture_end on a side stream -- ``with torch.cuda.graph()`` synchronises
+        the device and empties the allocator's cache on entry, once per attack here -- into a memory pool this attack object
+        keeps, so that the graph of the next attack reuses the blocks of this one."""
+        dev = self.device
+        patch_in, patch_out = obj_img_adv.detach().clone(), torch.empty_like(obj_img_adv)
+        coeff_cur, tab_cur = coeffs[0].clone(), tabs[0].clone()
+        plan.bind_table(tab_cur)
+        plan.table_rewritten = True     # consumers that keep origins for a later step must copy them (ops.CleanHead.mark)
+
+        def step():
+            p = patch_in.detach().requires_grad_(True)
+            adv, m = ops.eot_paste(scene_imgs, p, mask, coeff_cur, l_pad, t_pad, self.scene_size)
+            cost = -self.model.masked_sq_mean(adv, m, plan, tab_cur, clean)
+            (grad,) = torch.autograd.grad(cost, p)
+            ops.pgd_linf_step(p, self.obj_img, grad, self.alpha, self.eps, out=patch_out)
+            patch_in.copy_(patch_out)
+
+        if self._graph is not None:         # the previous attack's graph: let its last replay finish before it is destroyed
+            self._graph[1].synchronize()
+            self._graph = None
+        step()                                              # step 0, eager
+        coeff_cur.copy_(coeffs[1])
+        tab_cur.copy_(tabs[1])
+        main = torch.cuda.current_stream(dev)
+        if self._graph_pool is None:
+            # the allocator drops a pool with its last graph: a one-kernel graph that is never destroyed keeps this one
+            pool, side, keeper = torch.cuda.graph_pool_handle(), torch.cuda.Stream(device=dev), torch.cuda.CUDAGraph()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                keeper.capture_begin(pool=pool)
+                try:
+                    torch.zeros(8, device=dev)
+                finally:
+                    keeper.capture_end()
+            self._graph_pool = (pool, side, keeper)
+        pool, side, _ = self._graph_pool
+        side.wait_stream(main)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            ops._sk_workspace(dev)                          # this stream's stream-K workspace: allocated outside the capture
+            g.capture_begin(pool=pool)
+            try:
+                step()
+            finally:
+                g.capture_end()
+        main.wait_stream(side)
+        g.replay()                                          # step 1 (capturing executes nothing)
+        for s in range(2, self.steps):
+            coeff_cur.copy_(coeffs[s])
+            tab_cur.copy_(tabs[s])
+            g.replay()
+        out = patch_in.clone()
+        done = torch.cuda.Event()
+        done.record(main)
+        self._graph = (g, done)
+        return out
 
     def _shard_without_scenes(self, obj_img_adv, dist, group):
         """A rank whose share of the attack batch is empty (world > batch_size): it contributes a zero gradient to every

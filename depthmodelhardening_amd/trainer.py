@@ -233,6 +233,10 @@ class Trainer:
             self.adv_args = args
             if getattr(self.opt, "shared_patch", False) and self.world_size > 1:
                 self.dataset.depth_atk.shard = (self.rank, self.world_size, None)
+            if getattr(self.opt, "graph_attack", False):
+                if self.opt.norm_type != "l_inf":
+                    raise NotImplementedError("--graph_attack is the L_inf attack's option (Phy_obj_atk.use_graph)")
+                self.dataset.depth_atk.use_graph = True
             self.update_adv_obj()   # trainer.py:231-233
 
         # The reference builds SSIM() and per-scale BackprojectDepth / Project3D modules here (MD2/trainer.py:240-254);

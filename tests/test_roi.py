@@ -30,75 +30,106 @@ def _covers(org_in, size_in, org_out, size_out, frame, halve):
     return bool(np.all(org_in <= lo) and np.all(org_in + size_in >= hi))
 
 
+def _check_plan(plan, boxes, trial):
+    """every window of ``plan`` holds what its consumer reads (the invariants the kernels rely on)"""
+    for n in WINDOWS:
+        fh, fw = H >> LEVEL[n], W >> LEVEL[n]
+        hc, wc = plan.size[n]
+        o = plan.org[n]
+        assert hc % 2 == 0 and wc % 2 == 0 and 2 <= hc <= fh and 2 <= wc <= fw
+        assert (o % 2 == 0).all() and (o >= 0).all() and (o[:, 0] + hc <= fh).all() and (o[:, 1] + wc <= fw).all()
+    # the head's window holds the mask's box
+    d = plan.org["d"]
+    assert (d[:, 0] <= boxes[:, 0]).all() and (d[:, 0] + plan.size["d"][0] >= boxes[:, 1]).all()
+    assert (d[:, 1] <= boxes[:, 2]).all() and (d[:, 1] + plan.size["d"][1] >= boxes[:, 3]).all()
+    chain = [(STAGES[k + 1][0], STAGES[k][0], STAGES[k][2]) for k in range(len(STAGES) - 1)]
+    assert chain[:3] == [("z01", "d", False), ("y00", "z01", True), ("z11", "y00", False)] and len(chain) == 9
+    for src, dst, halve in chain:
+        for ax, frame in ((0, H >> LEVEL[dst]), (1, W >> LEVEL[dst])):
+            assert _covers(plan.org[src][:, ax], plan.size[src][ax], plan.org[dst][:, ax], plan.size[dst][ax], frame,
+                           halve), (trial, src, dst, ax)
+    assert plan.table().shape == (len(TABLE), len(boxes), 2) and plan.table().dtype == np.int32
+    # regions of the whole-frame sources hold what the tail reads of them; the encoder head's windows hold what it reads
+    for reg, dst, halve in (("r_y20", "z21", True), ("r_f1", "z21", False), ("r_f0", "z11", False), ("r_y30", "z31", True),
+                            ("r_f2", "z31", False), ("r_y40", "z41", True), ("r_f3", "z41", False)):
+        for ax, frame in ((0, H >> LEVEL[dst]), (1, W >> LEVEL[dst])):
+            assert _covers(plan.org[reg][:, ax], plan.size[reg][ax], plan.org[dst][:, ax], plan.size[dst][ax], frame, halve)
+    for ax, (fd, fs, fq) in enumerate(((H, H >> 1, H >> 2), (W, W >> 1, W >> 2))):
+        d0, dn = plan.org["d"][:, ax].astype(int), plan.size["d"][ax]
+        s0, sn = plan.org["gz"][:, ax].astype(int), plan.size["gz"][ax]
+        q0, qn = plan.org["l1"][:, ax].astype(int), plan.size["l1"][ax]
+        f0_, fn = plan.org["r_f0"][:, ax].astype(int), plan.size["r_f0"][ax]
+        # conv1's adjoint reads rows Y-1 .. Y+2 of its output gradient for image rows 2Y, 2Y+1
+        assert (s0 <= np.maximum((d0 >> 1) - 1, 0)).all() and (s0 + sn >= np.minimum(((d0 + dn) >> 1) + 2, fs)).all()
+        # the max-pool adjoint reads cells r >> 1 .. (r + 1) >> 1; layer1 spoils four rings of its window
+        assert (q0 <= np.maximum((s0 >> 1) - 4, 0)).all() and (q0 + qn >= np.minimum(((s0 + sn) >> 1) + 1 + 4, fq)).all()
+        # the encoder head reads feature 0's gradient on "gz": inside the rectangle the tail writes
+        assert (f0_ <= s0).all() and (f0_ + fn >= s0 + sn).all()
+        # incremental head: the cells written into feature 1 ("f1s") lie inside the compact window "hl" minus the rings its
+        # same-size stages spoil (pooling 1 + four convolutions: 5 at the top / left, 4 at the bottom / right; none at a
+        # frame edge); the cells layer1's backward must deliver (under "gz") lie 9 rings inside it; "hz" = 2 x "hl" holds
+        # "gz" and what the tail reads of feature 0
+        h0, hn = plan.org["hl"][:, ax].astype(int), plan.size["hl"][ax]
+        w0, wn = plan.org["f1s"][:, ax].astype(int), plan.size["f1s"][ax]
+        assert (((w0 - h0) >= 5) | (h0 == 0)).all() and ((((h0 + hn) - (w0 + wn)) >= 4) | (h0 + hn == fq)).all()
+        c0, c1 = s0 >> 1, ((s0 + sn) >> 1) + 1
+        assert (((c0 - h0) >= 9) | (h0 == 0)).all() and ((((h0 + hn) - np.minimum(c1, fq)) >= 9) | (h0 + hn == fq)).all()
+        z0_, zn = plan.org["hz"][:, ax].astype(int), plan.size["hz"][ax]
+        assert (z0_ == 2 * h0).all() and zn == 2 * hn
+        assert (z0_ <= s0).all() and (z0_ + zn >= s0 + sn).all() and (z0_ <= f0_).all() and (z0_ + zn >= f0_ + fn).all()
+    assert plan.head_incremental_ok and plan.layer2_incremental_ok
+    # layer2 on "h3": the cells written into feature 2 ("f2s") lie inside it minus the rings its stages spoil (stride-2
+    # entry + three convolutions: 4 top / left, 3 bottom / right); the cells whose gradient the stride-2 adjoint reads to
+    # cover "hl" lie 7 rings inside; "h3in" = 2 x "h3" holds "hl" at the even origin "hl_rel"
+    for ax, (f8, f4) in enumerate(((H >> 3, H >> 2), (W >> 3, W >> 2))):
+        c0, cn = plan.org["h3"][:, ax].astype(int), plan.size["h3"][ax]
+        w0, wn = plan.org["f2s"][:, ax].astype(int), plan.size["f2s"][ax]
+        assert (((w0 - c0) >= 4) | (c0 == 0)).all() and ((((c0 + cn) - (w0 + wn)) >= 3) | (c0 + cn == f8)).all()
+        l0, ln = plan.org["hl"][:, ax].astype(int), plan.size["hl"][ax]
+        q0, q1 = l0 >> 1, np.minimum(((l0 + ln) >> 1) + 1, f8)
+        assert (((q0 - c0) >= 7) | (c0 == 0)).all() and ((((c0 + cn) - q1) >= 7) | (c0 + cn == f8)).all()
+        r0 = plan.org["hl_rel"][:, ax].astype(int)
+        assert (r0 == l0 - 2 * c0).all() and (r0 >= 0).all() and (r0 + ln <= 2 * cn).all() and (r0 % 2 == 0).all()
+        assert (plan.org["h3in"][:, ax] == 2 * c0).all() and plan.size["h3in"][ax] == 2 * cn
+
+
 def test_plan_covers_every_read_for_all_training_poses():
     pt, grid = _pose_grid()
     rng = np.random.RandomState(0)
     for trial in range(40):
         idx = rng.choice(len(grid), 12, replace=False)
         boxes = pt.mask_boxes([grid[i][0] for i in idx], [grid[i][1] for i in idx], (H, W))
-        plan = RoiPlan(boxes, H, W)
-        for n in WINDOWS:
-            fh, fw = H >> LEVEL[n], W >> LEVEL[n]
-            hc, wc = plan.size[n]
-            o = plan.org[n]
-            assert hc % 2 == 0 and wc % 2 == 0 and 2 <= hc <= fh and 2 <= wc <= fw
-            assert (o % 2 == 0).all() and (o >= 0).all() and (o[:, 0] + hc <= fh).all() and (o[:, 1] + wc <= fw).all()
-        # the head's window holds the mask's box
-        d = plan.org["d"]
-        assert (d[:, 0] <= boxes[:, 0]).all() and (d[:, 0] + plan.size["d"][0] >= boxes[:, 1]).all()
-        assert (d[:, 1] <= boxes[:, 2]).all() and (d[:, 1] + plan.size["d"][1] >= boxes[:, 3]).all()
-        chain = [(STAGES[k + 1][0], STAGES[k][0], STAGES[k][2]) for k in range(len(STAGES) - 1)]
-        assert chain[:3] == [("z01", "d", False), ("y00", "z01", True), ("z11", "y00", False)] and len(chain) == 9
-        for src, dst, halve in chain:
-            for ax, frame in ((0, H >> LEVEL[dst]), (1, W >> LEVEL[dst])):
-                assert _covers(plan.org[src][:, ax], plan.size[src][ax], plan.org[dst][:, ax], plan.size[dst][ax], frame,
-                               halve), (trial, src, dst, ax)
-        assert plan.table().shape == (len(TABLE), 12, 2) and plan.table().dtype == np.int32
-        # regions of the whole-frame sources hold what the tail reads of them; the encoder head's windows hold what it reads
-        for reg, dst, halve in (("r_y20", "z21", True), ("r_f1", "z21", False), ("r_f0", "z11", False), ("r_y30", "z31", True),
-                                ("r_f2", "z31", False), ("r_y40", "z41", True), ("r_f3", "z41", False)):
-            for ax, frame in ((0, H >> LEVEL[dst]), (1, W >> LEVEL[dst])):
-                assert _covers(plan.org[reg][:, ax], plan.size[reg][ax], plan.org[dst][:, ax], plan.size[dst][ax], frame, halve)
-        for ax, (fd, fs, fq) in enumerate(((H, H >> 1, H >> 2), (W, W >> 1, W >> 2))):
-            d0, dn = plan.org["d"][:, ax].astype(int), plan.size["d"][ax]
-            s0, sn = plan.org["gz"][:, ax].astype(int), plan.size["gz"][ax]
-            q0, qn = plan.org["l1"][:, ax].astype(int), plan.size["l1"][ax]
-            f0_, fn = plan.org["r_f0"][:, ax].astype(int), plan.size["r_f0"][ax]
-            # conv1's adjoint reads rows Y-1 .. Y+2 of its output gradient for image rows 2Y, 2Y+1
-            assert (s0 <= np.maximum((d0 >> 1) - 1, 0)).all() and (s0 + sn >= np.minimum(((d0 + dn) >> 1) + 2, fs)).all()
-            # the max-pool adjoint reads cells r >> 1 .. (r + 1) >> 1; layer1 spoils four rings of its window
-            assert (q0 <= np.maximum((s0 >> 1) - 4, 0)).all() and (q0 + qn >= np.minimum(((s0 + sn) >> 1) + 1 + 4, fq)).all()
-            # the encoder head reads feature 0's gradient on "gz": inside the rectangle the tail writes
-            assert (f0_ <= s0).all() and (f0_ + fn >= s0 + sn).all()
-            # incremental head: the cells written into feature 1 ("f1s") lie inside the compact window "hl" minus the rings its
-            # same-size stages spoil (pooling 1 + four convolutions: 5 at the top / left, 4 at the bottom / right; none at a
-            # frame edge); the cells layer1's backward must deliver (under "gz") lie 9 rings inside it; "hz" = 2 x "hl" holds
-            # "gz" and what the tail reads of feature 0
-            h0, hn = plan.org["hl"][:, ax].astype(int), plan.size["hl"][ax]
-            w0, wn = plan.org["f1s"][:, ax].astype(int), plan.size["f1s"][ax]
-            assert (((w0 - h0) >= 5) | (h0 == 0)).all() and ((((h0 + hn) - (w0 + wn)) >= 4) | (h0 + hn == fq)).all()
-            c0, c1 = s0 >> 1, ((s0 + sn) >> 1) + 1
-            assert (((c0 - h0) >= 9) | (h0 == 0)).all() and ((((h0 + hn) - np.minimum(c1, fq)) >= 9) | (h0 + hn == fq)).all()
-            z0_, zn = plan.org["hz"][:, ax].astype(int), plan.size["hz"][ax]
-            assert (z0_ == 2 * h0).all() and zn == 2 * hn
-            assert (z0_ <= s0).all() and (z0_ + zn >= s0 + sn).all() and (z0_ <= f0_).all() and (z0_ + zn >= f0_ + fn).all()
-        assert plan.head_incremental_ok and plan.layer2_incremental_ok
-        # layer2 on "h3": the cells written into feature 2 ("f2s") lie inside it minus the rings its stages spoil (stride-2
-        # entry + three convolutions: 4 top / left, 3 bottom / right); the cells whose gradient the stride-2 adjoint reads to
-        # cover "hl" lie 7 rings inside; "h3in" = 2 x "h3" holds "hl" at the even origin "hl_rel"
-        for ax, (f8, f4) in enumerate(((H >> 3, H >> 2), (W >> 3, W >> 2))):
-            c0, cn = plan.org["h3"][:, ax].astype(int), plan.size["h3"][ax]
-            w0, wn = plan.org["f2s"][:, ax].astype(int), plan.size["f2s"][ax]
-            assert (((w0 - c0) >= 4) | (c0 == 0)).all() and ((((c0 + cn) - (w0 + wn)) >= 3) | (c0 + cn == f8)).all()
-            l0, ln = plan.org["hl"][:, ax].astype(int), plan.size["hl"][ax]
-            q0, q1 = l0 >> 1, np.minimum(((l0 + ln) >> 1) + 1, f8)
-            assert (((q0 - c0) >= 7) | (c0 == 0)).all() and ((((c0 + cn) - q1) >= 7) | (c0 + cn == f8)).all()
-            r0 = plan.org["hl_rel"][:, ax].astype(int)
-            assert (r0 == l0 - 2 * c0).all() and (r0 >= 0).all() and (r0 + ln <= 2 * cn).all() and (r0 % 2 == 0).all()
-            assert (plan.org["h3in"][:, ax] == 2 * c0).all() and plan.size["h3in"][ax] == 2 * cn
+        _check_plan(RoiPlan(boxes, H, W), boxes, trial)
     # the windows are a small part of the frame even for the nearest object
     near = RoiPlan(pt.mask_boxes([5.0], [0], (H, W)), H, W)
     assert near.area_fraction()["z01"] < 0.25 and near.area_fraction()["l1"] < 0.35
+
+
+def test_common_size_plans_give_every_step_the_same_shapes_and_still_cover():
+    """roi.common_size_plans: the steps of an attack (new poses at every step) get ONE set of window sizes -- the condition for
+    replaying a captured HIP graph -- and every plan keeps every coverage invariant; the sizes are the element-wise maximum of
+    the steps' own sizes or slightly above (a larger window makes the windows derived from it larger), never below."""
+    from depthmodelhardening_amd.roi import common_size_plans
+    pt, grid = _pose_grid()
+    rng = np.random.RandomState(1)
+    for trial, (nsteps, nscenes, depth) in enumerate(((10, 12, 4), (10, 2, 4), (20, 12, 3), (3, 1, 2), (10, 12, 4))):
+        steps = []
+        for _ in range(nsteps):
+            idx = rng.choice(len(grid), nscenes, replace=False)
+            steps.append(pt.mask_boxes([grid[i][0] for i in idx], [grid[i][1] for i in idx], (H, W)))
+        plans = common_size_plans(steps, H, W, depth=depth)
+        assert plans is not None and len(plans) == nsteps
+        own = [RoiPlan(b, H, W, depth=depth) for b in steps]
+        for n in TABLE:
+            assert len({p.size[n] for p in plans}) == 1
+            top = (max(p.size[n][0] for p in own), max(p.size[n][1] for p in own))
+            assert plans[0].size[n][0] >= top[0] and plans[0].size[n][1] >= top[1]
+            assert plans[0].size[n][0] <= top[0] + 16 and plans[0].size[n][1] <= top[1] + 16, (n, plans[0].size[n], top)
+        for p, b in zip(plans, steps):
+            _check_plan(p, b, trial)
+    # one step: its own plan
+    one = common_size_plans(steps[:1], H, W, depth=2)
+    assert one[0].size == RoiPlan(steps[0], H, W, depth=2).size
 
 
 def test_mask_box_clips_and_is_conservative():
@@ -299,6 +330,39 @@ def test_attack_with_windows_equals_attack_without():
     agree = (out[0][2] == out[1][2]).float().mean().item()
     print("patch texels identical with / without windows: %.5f" % agree)
     assert agree > 0.999        # a sign() step on a ~0 gradient may flip a texel by 2 alpha
+
+
+@pytest.mark.gpu
+def test_attack_replayed_from_a_hip_graph_equals_the_eager_attack():
+    """Phy_obj_atk.use_graph: common window sizes for all steps, step 0 eager, step 1 captured, steps 2 .. n-1 replayed.
+    Bit for bit the eager attack on the same (common-size) windows -- the replays launch the very kernels of the eager loop --
+    and, to the sign() flips of ~0 gradients, the default attack on each step's own windows.  A second attack (new graph, the
+    first one's memory pool) with a different random start shows that nothing of the first is baked in."""
+    import random
+
+    from depthmodelhardening_amd.torchattacks import Phy_obj_atk
+    from oracle import synth
+    dev = torch.device("cuda")
+    model = _unet(dev, seed=5)
+    obj, pmask = synth.make_object()
+    scenes = synth.kitti_like(12, 3, 375, 1242, torch.Generator().manual_seed(28)).to(dev)
+    noises = [(torch.rand(obj.shape, generator=torch.Generator().manual_seed(29 + k)) * 2 - 1) * 0.1 for k in range(2)]
+    out = {}
+    for mode in ("own", "common", "graph"):
+        atk = Phy_obj_atk(model, obj.to(dev), pmask.to(dev), eps=0.1, alpha=0.02, steps=5, dist_range=list(np.arange(5, 10, 0.2)))
+        atk.common_windows, atk.use_graph = mode == "common", mode == "graph"
+        for k, noise in enumerate(noises):
+            atk.random_start_noise = noise
+            random.seed(33 + k)
+            adv, ben, m, patch = atk(scenes, 12)
+            out[mode, k] = (adv.cpu(), patch.cpu())
+        assert (atk._graph is not None) == (mode == "graph")
+    for k in range(2):
+        assert torch.equal(out["graph", k][1], out["common", k][1]) and torch.equal(out["graph", k][0], out["common", k][0])
+        agree = (out["graph", k][1] == out["own", k][1]).float().mean().item()
+        print("attack %d: patch texels identical, graph on common windows / eager on each step's own: %.5f" % (k, agree))
+        assert agree > 0.999
+    assert not torch.equal(out["graph", 0][1], out["graph", 1][1])
 
 
 @pytest.mark.gpu

@@ -26,8 +26,8 @@ census = collections.Counter()
 real_ok = ops._wino_ok
 
 
-def counting_ok(B, n_in, n_out, Ho, Wo, allow_split=True):
-    r = real_ok(B, n_in, n_out, Ho, Wo, allow_split)
+def counting_ok(B, n_in, n_out, Ho, Wo, allow_split=True, **kw):
+    r = real_ok(B, n_in, n_out, Ho, Wo, allow_split, **kw)
     census[(B, n_in, n_out, Ho, Wo, bool(allow_split), bool(r))] += 1
     return r
 

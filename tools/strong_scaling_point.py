@@ -27,6 +27,14 @@ for (B, A, label) in ((32, 12, "weak-scaling rank (the headline config)"),
                            cwd=REPO)
         tries.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
     j = min(tries, key=lambda t: t["ms_per_step"])
+    # the same rank with the attack's steps 2 .. 9 replayed from a HIP graph of step 1 (bench.py --graph_attack)
+    gtries = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--batch_size", str(B), "--atk_scenes", str(A), "--steps",
+                            "10", "--warmup", "3", "--no_cpu_baseline", "--graph_attack"], stdout=subprocess.PIPE,
+                           stderr=subprocess.DEVNULL, text=True, cwd=REPO)
+        gtries.append(json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1]))
+    jg = min(gtries, key=lambda t: t["ms_per_step"])
     with tempfile.NamedTemporaryFile(suffix=".json", delete=False) as f:
         tmp = f.name
     subprocess.run([sys.executable, os.path.join(REPO, "tools", "conv_census.py"), "--batch_size", str(B), "--atk_batch_size", str(A),
@@ -35,13 +43,15 @@ for (B, A, label) in ((32, 12, "weak-scaling rank (the headline config)"),
     os.remove(tmp)
     runs.append({"train_batch": B, "attack_scenes": A, "label": label, "ms_per_step": j["ms_per_step"],
                  "images_per_s_one_rank": j["value"],
+                 "ms_per_step_graph_attack": jg["ms_per_step"], "images_per_s_one_rank_graph_attack": jg["value"],
                  "predicted_8_rank_images_per_s_without_communication": round(8 * j["value"], 1) if B == 4 else None,
                  "k10_dispatch_falls_to_library": [d for d in census["k10_dispatch"] if not d["takes_K10"]],
                  "library_forward_calls": sum(d["calls"] for d in census["library_forward"]),
                  "library_backward_calls": sum(d["calls"] for d in census["library_backward"]),
                  "library_forward": census["library_forward"], "library_backward": census["library_backward"]})
-    print("%-100s %.2f ms/step, %.1f images/s on this rank; library convolutions: %d forward, %d backward calls" % (
-        label, j["ms_per_step"], j["value"], runs[-1]["library_forward_calls"], runs[-1]["library_backward_calls"]), flush=True)
+    print("%-100s %.2f ms/step, %.1f images/s on this rank (attack replayed from a HIP graph: %.2f ms/step); library convolutions: "
+          "%d forward, %d backward calls" % (label, j["ms_per_step"], j["value"], jg["ms_per_step"],
+                                             runs[-1]["library_forward_calls"], runs[-1]["library_backward_calls"]), flush=True)
 json.dump({"what": "per-rank workloads of SURVEY 8d's strong-scaling point measured on ONE MI355X (no collective runs here): bench.py "
                    "--batch_size B --atk_scenes A, 10 timed steps; tools/conv_census.py lists the convolutions that still reach "
                    "MIOpen at that batch",
