@@ -964,7 +964,11 @@ def _wino_filter(weight, backward, scale=None):
 
 
 WINO_SK = os.environ.get("DMH_WINO_SK", "1") != "0"       # A/B switch: stream-K decomposition of the plain K10 launches
-_WINO_MIN_ITEMS = int(os.environ.get("DMH_WINO_MIN_ITEMS", "200"))      # work items below which MIOpen is level or ahead (A/B switch)
+# work items below which MIOpen is level or ahead (A/B switch).  200 until round 5: measured with whole items only.  With the
+# stream-K forms a launch of 64 items (or 512 (item, chunk) units) already beats the library's fixed costs: the strong-scaling
+# share (train batch 4, 2 attack scenes) 50.2 -> 38.5 ms per step at 75 / 50 / 35 alike, batch 4 + 12 scenes and the headline
+# batch unchanged (tools/ab_min_items.sh)
+_WINO_MIN_ITEMS = int(os.environ.get("DMH_WINO_MIN_ITEMS", "64"))
 _WINO_MIN_FILL = float(os.environ.get("DMH_WINO_MIN_FILL", "0.5"))      # real tiles / tiles of the regions below which MIOpen is ahead (A/B switch)
 
 
@@ -993,9 +997,9 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True, allow_sk=False):
     split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
     if allow_split and WINO_SK and regions * nch >= 8 * _WINO_MIN_ITEMS:
         return True     # stream-K (_wino_conv): >= 8 channel chunks for each of >= 200 workgroups, however few the regions
-    if allow_sk and WINO_SK and regions < _WINO_MIN_ITEMS and regions * nch >= 8 * _WINO_MIN_ITEMS:
+    if allow_sk and WINO_SK and regions < 200 and regions * nch >= 8 * _WINO_MIN_ITEMS:
         return True     # the same under the fused epilogue (_k10_act): launches of few regions only, see launch_split()
-    return regions * split >= _WINO_MIN_ITEMS
+    return regions * split >= (_WINO_MIN_ITEMS if WINO_SK else max(_WINO_MIN_ITEMS, 200))     # whole items only: round 4's threshold
 
 
 def _wrw_ok(x, g, K, Cc):
