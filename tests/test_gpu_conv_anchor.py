@@ -56,7 +56,12 @@ FWD_SHAPES = [("K10 layer1 64->64 @80x256", 12, 64, 64, 80, 256, 1),
               # stream-K launches (round 5): 60 regions (MIOpen until then), 144 regions = 288 half items on 256 CUs, 54 regions
               ("K10 upconv(4,0) 512->256 @12x34 pad0 stream-K", 12, 512, 256, 12, 34, 0),
               ("K10 upconv(4,1) window 512->256 @22x30 pad0 stream-K", 12, 512, 256, 22, 30, 0),
-              ("K10 upconv(3,0) window 256->128 @20x26 pad0 stream-K", 12, 256, 128, 20, 26, 0)]
+              ("K10 upconv(3,0) window 256->128 @20x26 pad0 stream-K", 12, 256, 128, 20, 26, 0),
+              # the strong-scaling share (2 attack scenes): 40 / 20 / 10 tile regions, library convolutions until the fill
+              # threshold went to 64 work items or 512 stream-K units
+              ("K10 layer3 256->256 @20x64 2 scenes", 2, 256, 256, 20, 64, 1),
+              ("K10 layer4 512->512 @10x32 2 scenes", 2, 512, 512, 10, 32, 1),
+              ("K10 upconv(4,0) 512->256 @12x34 pad0 2 scenes", 2, 512, 256, 12, 34, 0)]
 
 
 @pytest.mark.parametrize("shape", FWD_SHAPES, ids=[s[0].split(" @")[0].replace(" ", "_") for s in FWD_SHAPES])

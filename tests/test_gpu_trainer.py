@@ -1099,7 +1099,10 @@ def test_basic_block_eval_node_vs_module_path():
     torch.manual_seed(5)
     # (12, 512, 10, 32) = layer4 at the attack batch: 120 tile regions, fused since round 5 through the stream-K form of the
     # epilogue kernel (the fix-up kernel applies shift / identity / ReLU and the backward's ReLU mask)
-    for (B, C, H, W) in [(12, 64, 80, 256), (12, 128, 40, 128), (12, 512, 10, 32), (3, 64, 22, 70)]:
+    # (2, ...) = the strong-scaling share of the attack (12 scenes over 8 ranks): 20 / 40 tile regions, on K10 since the fill
+    # threshold went from 200 to 64 work items (512 stream-K units)
+    for (B, C, H, W) in [(12, 64, 80, 256), (12, 128, 40, 128), (12, 512, 10, 32), (3, 64, 22, 70), (2, 256, 20, 64),
+                         (2, 512, 10, 32)]:
         blk = BasicBlock(C, C).cuda().eval()
         with torch.no_grad():
             for bn in (blk.bn1, blk.bn2):
@@ -1129,8 +1132,8 @@ def test_basic_block_eval_node_vs_module_path():
         assert_close_frac(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()), name="block out")
         # ReLU kinks: elements whose pre-activation is within rounding of zero may take the other branch.  ONE flipped unit of
         # the inner activation reaches 9 x C input-gradient elements: 4,608 of layer4's 1.97 M = 0.23 % (measured there: 0.21 %)
-        assert_close_frac(ggot, gref, rtol=1e-3, atol=1e-4 * float(gref.abs().max()), max_bad_frac=2e-4 if C < 512 else 1e-2,
-                          name="block grad")
+        assert_close_frac(ggot, gref, rtol=1e-3, atol=1e-4 * float(gref.abs().max()),
+                          max_bad_frac=2e-4 if C < 256 else (1e-2 if B > 2 or C < 512 else 6e-2), name="block grad")
         assert rel_l2(ggot, gref) <= 2e-3
 
 
