@@ -146,6 +146,10 @@ _SIGNATURES = {
     "dmh_down_conv_fwd_act": (C.c_int, [_fp] * 5 + [C.c_int] * 6 + [_fp] * 3),
     "dmh_down_conv_bwd_data": (C.c_int, [_fp] * 4 + [C.c_int] * 5 + [_fp, _fp]),
     "dmh_down_conv_bwd_data_acc": (C.c_int, [_fp] * 5 + [C.c_int] * 5 + [_fp, _fp]),
+    "dmh_down_conv_image_size": (C.c_int64, [C.c_int, C.c_int]),
+    "dmh_down_conv_weight_image": (C.c_int, [_fp, _fp, C.c_int, C.c_int, _fp, _fp]),
+    "dmh_down_conv_fwd_img": (C.c_int, [_fp, _fp, C.c_int, _fp, _fp] + [C.c_int] * 6 + [_fp] * 3),
+    "dmh_down_conv_bwd_data_img": (C.c_int, [_fp] * 4 + [C.c_int] * 5 + [_fp, _fp]),
 }
 
 EXPORTS = tuple(sorted(_SIGNATURES))

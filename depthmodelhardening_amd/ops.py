@@ -1406,6 +1406,40 @@ def stem_conv_norm(x, weight, mean=0.45, std=0.225):
     return _StemConvNorm.apply(_c(x), weight, float(mean), float(std))
 
 
+DOWN_WIDE = os.environ.get("DMH_DOWN_WIDE", "1") != "0"     # A/B switch: K15 with 16-byte loaders and the filter image (round 5)
+
+
+def _down_image(w3, wd):
+    """The filter pair of K15 as an image of the kernels' LDS layout (csrc/down_conv.hip, "round 5"): [rows / 32][inner / 8][2560]
+    floats from w3 [rows, inner, 3, 3] and wd [rows, inner(, 1, 1)] or None.  Once per weight tensor inside frozen_weights()."""
+    lib = N.lib()
+    rows, inner = w3.shape[0], w3.shape[1]
+
+    def make():
+        img = torch.empty(lib.dmh_down_conv_image_size(rows, inner), device=w3.device, dtype=torch.float32)
+        N.check(lib.dmh_down_conv_weight_image(N.ptr(w3), N.ptr(wd), rows, inner, N.ptr(img), N.stream()))
+        return img
+    return frozen_memo(("down_img", w3.data_ptr(), w3._version, None if wd is None else (wd.data_ptr(), wd._version)), make)
+
+
+def _k15_fwd(lib, x, w3, wd, shift3, shiftd, relu3, B, Cin, Cout, H, W, y3, yd, stream):
+    """dmh_down_conv_fwd_act, in its image form (16-byte loaders; bit-identical) where the rows are whole 16-byte words."""
+    if DOWN_WIDE and W % 4 == 0 and Cout % 32 == 0:
+        return lib.dmh_down_conv_fwd_img(N.ptr(x), N.ptr(_down_image(w3, wd)), int(wd is not None), N.ptr(shift3), N.ptr(shiftd),
+                                         int(relu3), B, Cin, Cout, H, W, N.ptr(y3), N.ptr(yd), stream)
+    return lib.dmh_down_conv_fwd_act(N.ptr(x), N.ptr(w3), N.ptr(wd), N.ptr(shift3), N.ptr(shiftd), int(relu3), B, Cin, Cout, H, W,
+                                     N.ptr(y3), N.ptr(yd), stream)
+
+
+def _k15_bwd(lib, g3, gd, w3t, wdt, g_add, B, Cin, Cout, H, W, g_x, stream):
+    """dmh_down_conv_bwd_data_acc (filters transposed: w3t [Cin, Cout, 3, 3], wdt [Cin, Cout]), image form where W % 8 == 0."""
+    if DOWN_WIDE and W % 8 == 0 and Cin % 32 == 0:
+        return lib.dmh_down_conv_bwd_data_img(N.ptr(g3), N.ptr(gd), N.ptr(_down_image(w3t, wdt)), N.ptr(g_add), B, Cin, Cout, H, W,
+                                              N.ptr(g_x), stream)
+    return lib.dmh_down_conv_bwd_data_acc(N.ptr(g3), N.ptr(gd), N.ptr(w3t), N.ptr(wdt), N.ptr(g_add), B, Cin, Cout, H, W, N.ptr(g_x),
+                                          stream)
+
+
 class _DownConvs(torch.autograd.Function):
     """K15: conv3x3 stride 2 and the 1x1 stride-2 shortcut convolution of a down-sampling BasicBlock, one launch; backward:
     both input gradients in one launch (no separate accumulation pass), both weight gradients in one K20 launch (train pass
@@ -1419,9 +1453,8 @@ class _DownConvs(torch.autograd.Function):
         y3 = torch.empty((B, Cout, H // 2, W // 2), device=x.device, dtype=torch.float32)
         yd = torch.empty_like(y3)
         nb = 4 * (x.numel() + 2 * y3.numel() + w3.numel() + wd.numel())
-        N.check(_timed("down_conv_fwd", lambda: lib.dmh_down_conv_fwd(
-            N.ptr(x), N.ptr(_c(w3.detach())), N.ptr(_c(wd.detach())), B, Cin, Cout, H, W, N.ptr(y3), N.ptr(yd), N.stream()),
-            nb, 20 * Cin * y3.numel()))
+        N.check(_timed("down_conv_fwd", lambda: _k15_fwd(lib, x, _c(w3.detach()), _c(wd.detach()), None, None, 0, B, Cin, Cout, H, W,
+                                                         y3, yd, N.stream()), nb, 20 * Cin * y3.numel()))
         ctx.save_for_backward(x, w3, wd)
         ctx.params_const = _wino_frozen > 0
         return y3, yd
@@ -1440,9 +1473,8 @@ class _DownConvs(torch.autograd.Function):
             wdt = frozen_memo(("down_wdt", wd.data_ptr(), wd._version), lambda: _c(wd.detach().reshape(Cout, Cin).t()))
             g_x = torch.empty_like(x)
             nb = 4 * (g_x.numel() + 2 * g3.numel() + w3.numel() + wd.numel())
-            N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data(
-                N.ptr(g3), N.ptr(gd), N.ptr(w3t), N.ptr(wdt), B, Cin, Cout, H, W, N.ptr(g_x), N.stream()),
-                nb, 20 * Cin * g3.numel()))
+            N.check(_timed("down_conv_bwd", lambda: _k15_bwd(lib, g3, gd, w3t, wdt, None, B, Cin, Cout, H, W, g_x, N.stream()),
+                           nb, 20 * Cin * g3.numel()))
         if not ctx.params_const and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
             n = lib.dmh_down_wrw_workspace_size(B, Cin, Cout, H, W) if (WRW_ENABLED and x.numel() * 4 <= 0xFFFFFF00) else -1
             if n >= 0 and ctx.needs_input_grad[1]:
@@ -1572,9 +1604,8 @@ class _DownBlockEval(torch.autograd.Function):
         wds = frozen_memo(("down_wds", wd.data_ptr(), wd._version, sd.data_ptr()), lambda: _c(wd * sd.view(-1, 1, 1, 1)))
         out1 = torch.empty((B, Co, H // 2, W // 2), device=x.device, dtype=torch.float32)
         idt, y = torch.empty_like(out1), torch.empty_like(out1)
-        N.check(_timed("down_conv_fwd", lambda: lib.dmh_down_conv_fwd_act(
-            N.ptr(x), N.ptr(w3s), N.ptr(wds), N.ptr(b1), N.ptr(bd), 1, B, Cin, Co, H, W, N.ptr(out1), N.ptr(idt), N.stream()),
-            4 * (x.numel() + 2 * out1.numel() + w3.numel() + wd.numel()), 20 * Cin * out1.numel()))
+        N.check(_timed("down_conv_fwd", lambda: _k15_fwd(lib, x, w3s, wds, b1, bd, 1, B, Cin, Co, H, W, out1, idt, N.stream()),
+                       4 * (x.numel() + 2 * out1.numel() + w3.numel() + wd.numel()), 20 * Cin * out1.numel()))
         N.check(_timed("wino_conv3x3", lambda: _k10_act(lib, 
             N.ptr(out1), N.ptr(_wino_filter(w2, False, s2)), N.ptr(b2), N.ptr(idt), 1, B, Co, Co, H // 2, W // 2, 1, N.ptr(y),
             N.stream()), 4 * 3 * out1.numel(), 18 * Co * out1.numel()))
@@ -1609,9 +1640,8 @@ class _DownBlockEval(torch.autograd.Function):
         wdts = frozen_memo(("down_wdts", wd.data_ptr(), wd._version, sd.data_ptr()),
                            lambda: _c((wd * sd.view(-1, 1, 1, 1)).reshape(Co, Cin).t()))
         g_x = torch.empty((B, Cin, H, W), device=g.device, dtype=torch.float32)
-        N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data_acc(
-            N.ptr(g1), N.ptr(g2), N.ptr(w3ts), N.ptr(wdts), N.ptr(g_skip), B, Cin, Co, H, W, N.ptr(g_x), N.stream()),
-            4 * (g_x.numel() * (1 if g_skip is None else 2) + 2 * g.numel()), 20 * Cin * g.numel()))
+        N.check(_timed("down_conv_bwd", lambda: _k15_bwd(lib, g1, g2, w3ts, wdts, g_skip, B, Cin, Co, H, W, g_x, N.stream()),
+                       4 * (g_x.numel() * (1 if g_skip is None else 2) + 2 * g.numel()), 20 * Cin * g.numel()))
         return (g_x,) + (None,) * 10
 
 
@@ -2095,9 +2125,8 @@ class _EncHeadInc(torch.autograd.Function):
         Co = w3.shape[0]
         q1 = torch.empty((B, Co, h3, w3_), device=dev, dtype=torch.float32)
         idt = torch.empty_like(q1)
-        N.check(_timed("down_conv_fwd", lambda: lib.dmh_down_conv_fwd_act(
-            N.ptr(x2), N.ptr(w3s), N.ptr(wds), N.ptr(sh1), N.ptr(shd), 1, B, 64, Co, 2 * h3, 2 * w3_, N.ptr(q1), N.ptr(idt), st),
-            4 * (x2.numel() + 2 * q1.numel()), 20 * 64 * q1.numel()))
+        N.check(_timed("down_conv_fwd", lambda: _k15_fwd(lib, x2, w3s, wds, sh1, shd, 1, B, 64, Co, 2 * h3, 2 * w3_, q1, idt, st),
+                       4 * (x2.numel() + 2 * q1.numel()), 20 * 64 * q1.numel()))
 
         def conv_act2(inp, w, sc, sh, res):
             y = torch.empty_like(inp)
@@ -2166,9 +2195,8 @@ class _EncHeadInc(torch.autograd.Function):
             wdts = frozen_memo(("down_wdts", wd.data_ptr(), wd._version, scd.data_ptr()),
                                lambda: _c((wd * scd.view(-1, 1, 1, 1)).reshape(Co, 64).t()))
             g_f1 = torch.empty((B, 64, 2 * h3, 2 * w3_), device=dev, dtype=torch.float32)
-            N.check(_timed("down_conv_bwd", lambda: lib.dmh_down_conv_bwd_data_acc(
-                N.ptr(g1), N.ptr(g2), N.ptr(w3ts), N.ptr(wdts), N.ptr(gskip), B, 64, Co, 2 * h3, 2 * w3_, N.ptr(g_f1), st),
-                4 * (g_f1.numel() * (1 if gskip is None else 2) + 2 * g1.numel()), 20 * 64 * g1.numel()))
+            N.check(_timed("down_conv_bwd", lambda: _k15_bwd(lib, g1, g2, w3ts, wdts, gskip, B, 64, Co, 2 * h3, 2 * w3_, g_f1, st),
+                           4 * (g_f1.numel() * (1 if gskip is None else 2) + 2 * g1.numel()), 20 * 64 * g1.numel()))
             f1_frame, f1_org = (2 * h3, 2 * w3_), org["hl_rel"]             # ... or that window, "hl" at its relative origin
         if g_f1 is not None:
             def conv_bwd(g, w, s, res, flag):

@@ -580,6 +580,20 @@ int dmh_down_conv_bwd_data(const float* g3, const float* gd, const float* w3t, c
 int dmh_down_conv_bwd_data_acc(const float* g3, const float* gd, const float* w3t, const float* wdt, const float* g_add, int B,
                                int Cin, int Cout, int H, int W, float* g_x, void* stream);
 
+/* Round 5: the same two kernels with 16-byte loaders.  The filters are handed over as an IMAGE of the kernels' LDS layout,
+ * written once per weight tensor: image[rows / 32][inner / 8][2560] from w3[rows][inner][3][3] and wd[rows][inner] (NULL: zeros)
+ * -- forward: rows = Co, inner = Ci (the filters as they are); backward: rows = Ci, inner = Co (the TRANSPOSED filters w3t, wdt).
+ * dmh_down_conv_image_size: floats of the image, -1 unless rows % 32 == 0 and inner % 8 == 0.  The *_img entry points take the
+ * arguments of dmh_down_conv_fwd_act / dmh_down_conv_bwd_data_acc with the image in place of the filter pair and a flag for the
+ * shortcut convolution; they read the tensors in aligned 16-byte words and therefore need W % 4 == 0 (forward) / W % 8 == 0
+ * (backward) -- other shapes stay with the entry points above.  Results are bit-identical to theirs. */
+int64_t dmh_down_conv_image_size(int rows, int inner);
+int dmh_down_conv_weight_image(const float* w3, const float* wd, int rows, int inner, float* image, void* stream);
+int dmh_down_conv_fwd_img(const float* x, const float* image, int has_down, const float* shift3, const float* shiftd, int relu3,
+                          int B, int Cin, int Cout, int H, int W, float* y3, float* yd, void* stream);
+int dmh_down_conv_bwd_data_img(const float* g3, const float* gd, const float* image, const float* g_add, int B, int Cin, int Cout,
+                               int H, int W, float* g_x, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -76,6 +76,15 @@ def test_convolution_entry_points_reject_bad_shapes_without_gpu():
     assert lib.dmh_wino_conv3x3_act_ws(one, one, None, None, 1, 1, 32, 64, 8, 8, 3, one, one, 1 << 23, None) != 0
     assert lib.dmh_wino32_conv3x3_ws(one, one, None, 1, 16, 32, 8, 8, 1, one, one, 1 << 23, None) != 0
     assert lib.dmh_avg_pyramid(one, 3, 321, 1024, one, one, one, None) != 0                 # sizes must be multiples of 8
+    # K15's image form: sizes, and the 16-byte alignment the wide loaders need
+    assert lib.dmh_down_conv_image_size(128, 64) == (128 // 32) * (64 // 8) * 2560
+    assert lib.dmh_down_conv_image_size(48, 64) == -1 and lib.dmh_down_conv_image_size(64, 12) == -1
+    assert lib.dmh_down_conv_weight_image(one, None, 48, 64, one, None) != 0
+    assert lib.dmh_down_conv_fwd_img(one, one, 1, None, None, 0, 1, 64, 128, 8, 10, one, one, None) != 0      # W % 4
+    assert b"multiple of 4" in lib.dmh_last_error()
+    assert lib.dmh_down_conv_fwd_img(one, one, 1, None, None, 0, 1, 64, 128, 8, 8, one, None, None) != 0       # yd missing
+    assert lib.dmh_down_conv_bwd_data_img(one, one, one, None, 1, 64, 128, 8, 12, one, None) != 0              # W % 8
+    assert lib.dmh_down_conv_bwd_data_img(one, one, one, None, 1, 48, 128, 8, 16, one, None) != 0              # C_in % 64
     assert lib.dmh_gt_depth_mse_fwd(one, one, one, 0, one, 0, 64, 0.1, 100.0, one, one, None) != 0   # empty batch
     assert lib.dmh_conv3x3_small(one, one, None, 1, 64, 64, 8, 8, 1, 0, one, None) != 0
     assert b"channel counts" in lib.dmh_last_error()

@@ -210,6 +210,51 @@ def test_stem_weight_gradient_vs_fp64(shape):
     assert _rel(gw3, gw64) <= 2 * _rel(gw, gw64) + 1e-7
 
 
+def test_k15_image_form_is_bit_identical_to_the_dword_kernels():
+    """K15 with 16-byte loaders and the filter image (dmh_down_conv_fwd_img / dmh_down_conv_bwd_data_img, round 5) runs the
+    MFMAs of the dword kernels in the same order: equal bit for bit -- with and without the shortcut convolution, with the
+    fused shift / ReLU and the epilogue addend, at the encoder's shapes, a window, a two-scene batch (32-channel tiles in the
+    backward pass) and ragged tiles.  ops.py takes the image form wherever the rows are whole 16-byte words."""
+    from depthmodelhardening_amd import _native as N
+    lib = N.lib()
+    dev = torch.device("cuda")
+
+    def image(w3, wd, rows, inner):
+        img = torch.empty(lib.dmh_down_conv_image_size(rows, inner), device=dev)
+        N.check(lib.dmh_down_conv_weight_image(N.ptr(w3), N.ptr(wd), rows, inner, N.ptr(img), N.stream()))
+        return img
+
+    for (b, Ci, Co, H, W) in [(12, 64, 128, 80, 256), (12, 256, 512, 20, 64), (12, 64, 128, 80, 112), (2, 256, 512, 20, 64),
+                              (3, 128, 256, 36, 72), (5, 64, 64, 10, 40)]:
+        g = torch.Generator(device="cuda").manual_seed(Ci + H)
+        x = torch.randn(b, Ci, H, W, device=dev, generator=g)
+        w3 = torch.randn(Co, Ci, 3, 3, device=dev, generator=g) * 0.05
+        wd = torch.randn(Co, Ci, device=dev, generator=g) * 0.1
+        s3, sd = torch.randn(Co, device=dev, generator=g), torch.randn(Co, device=dev, generator=g)
+        img = image(w3, wd, Co, Ci)
+        for down in (True, False):
+            y = [torch.zeros(b, Co, H // 2, W // 2, device=dev) for _ in range(4)]
+            N.check(lib.dmh_down_conv_fwd_act(N.ptr(x), N.ptr(w3), N.ptr(wd) if down else None, N.ptr(s3), N.ptr(sd) if down else None,
+                                              1, b, Ci, Co, H, W, N.ptr(y[0]), N.ptr(y[1]) if down else None, N.stream()))
+            N.check(lib.dmh_down_conv_fwd_img(N.ptr(x), N.ptr(img), int(down), N.ptr(s3), N.ptr(sd) if down else None, 1, b, Ci, Co,
+                                              H, W, N.ptr(y[2]), N.ptr(y[3]) if down else None, N.stream()))
+            assert torch.equal(y[0], y[2]) and torch.equal(y[1], y[3]), ("forward", b, Ci, Co, H, W, down)
+        ref = F.conv2d(x.double(), w3.double(), None, 2, 1) + s3.double().view(1, -1, 1, 1)
+        assert _rel(y[2], ref.clamp_min(0)) < 2e-6
+        w3t, wdt = w3.transpose(0, 1).contiguous(), wd.t().contiguous()
+        imgt = image(w3t, wdt, Ci, Co)
+        g3 = torch.randn(b, Co, H // 2, W // 2, device=dev, generator=g)
+        gd = torch.randn(b, Co, H // 2, W // 2, device=dev, generator=g)
+        gadd = torch.randn(b, Ci, H, W, device=dev, generator=g)
+        for down in (True, False):
+            o = [torch.zeros(b, Ci, H, W, device=dev) for _ in range(2)]
+            N.check(lib.dmh_down_conv_bwd_data_acc(N.ptr(g3), N.ptr(gd) if down else None, N.ptr(w3t), N.ptr(wdt) if down else None,
+                                                   N.ptr(gadd), b, Ci, Co, H, W, N.ptr(o[0]), N.stream()))
+            N.check(lib.dmh_down_conv_bwd_data_img(N.ptr(g3), N.ptr(gd) if down else None, N.ptr(imgt), N.ptr(gadd), b, Ci, Co, H, W,
+                                                   N.ptr(o[1]), N.stream()))
+            assert torch.equal(o[0], o[1]), ("backward", b, Ci, Co, H, W, down)
+
+
 def test_stream_k_is_deterministic_and_equals_whole_items():
     """Stream-K launches of the plain K10 path (csrc/wino_conv.hip): run twice bit for bit, with a bias, ragged tile regions
     included, and against the whole-item launch of the same kernel (DMH_WINO_SK switch) to fp32 re-association."""
