@@ -164,7 +164,7 @@ if bs and bt:
                          ("wino32", "K17 wino32_conv"), ("wino_wrw", "K18 wino_wrw"), ("down_wrw", "K20 / K21 strided + stem weight gradients"),
                          ("stem_wrw", "K20 / K21 strided + stem weight gradients"), ("wino_", "K10 wino_conv (+ filter transforms)"),
                          ("small_conv", "K11 small_conv"), ("small_wrw", "K16 small_wrw"), ("head_wrw", "K13 head weight gradient"),
-                         ("down_conv", "K15 down_conv"), ("elu_pad", "K7 decoder glue"), ("up_cat_pad", "K7 decoder glue"),
+                         ("down_conv", "K15 down_conv"), ("down_weight_image", "K15 down_conv"), ("elu_pad", "K7 decoder glue"), ("up_cat_pad", "K7 decoder glue"),
                          ("bn_", "K9 encoder glue / BatchNorm"), ("channel_sum", "K9 encoder glue / BatchNorm"),
                          ("stem", "stem (K14 / K12 / K9 stem glue)"), ("head_", "K13 disparity heads"),
                          ("photo_", "K1-K6 loss + attack"), ("smooth_", "K1-K6 loss + attack"), ("finalize", "K1-K6 loss + attack"),
