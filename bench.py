@@ -494,6 +494,14 @@ def run_rank(a):
     if world > 1:       # start-up (rendezvous, MIOpen's first-run compiles) is over: a collective stuck for minutes is a hang
         from depthmodelhardening_amd.ddp import shorten_timeout
         shorten_timeout()
+        # test hooks (tests/test_gpu_bench_ranks.py): "exit:R" rank R dies here, "hang:R" rank R stops taking part -- the
+        # others then sit in the next collective until the shortened timeout fails them
+        hook = os.environ.get("DMH_BENCH_AFTER_WARMUP", "")
+        if hook == "exit:%d" % rank:
+            os._exit(3)
+        if hook == "hang:%d" % rank:
+            while True:
+                time.sleep(1.0)
     # Inside the timed region only the K1 launches (the kernels of the roofline entry) carry HIP events: an event pair costs
     # ~10 us of dispatch latency around a launch, and a step has ~1,300 instrumented launches (timing all of them cost
     # 8.5 ms of a 174 ms step).  The other kernels' durations (roofline.others) come from ONE extra, untimed, fully
@@ -514,6 +522,9 @@ def run_rank(a):
     ops.enable_profile(True, only=hot)
     atk = getattr(getattr(job, "dataset", None), "depth_atk", None) or getattr(job, "depth_atk", None)
     it0 = (getattr(atk, "total_iterations", 0), getattr(atk, "total_calls", 0))
+    bucket = getattr(job, "bucket", None)
+    if world > 1 and bucket is not None:
+        bucket.timing = True
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = job.train_step()
@@ -528,6 +539,21 @@ def run_rank(a):
     kb_timed = ops.profile_bytes()
     ops.enable_profile(False)
     other_mode = None
+    ar_times = None
+    if world > 1 and bucket is not None:
+        # the side-stream all-reduce of every timed step by HIP events (this rank's; the device is idle: sync() above)
+        tm = bucket.timings()
+        bucket.timing = False
+        if tm["all_reduce_ms"]:
+            n_ar = len(tm["all_reduce_ms"])
+            ar_times = {"launches": n_ar, "all_reduce_ms_per_step": round(sum(tm["all_reduce_ms"]) / n_ar, 4),
+                        "all_reduce_ms_max": round(max(tm["all_reduce_ms"]), 4),
+                        "optimizer_wait_ms_per_step": round(sum(tm["wait_ms"]) / n_ar, 4),
+                        "optimizer_wait_ms_max": round(max(tm["wait_ms"]), 4), "bucket_mb": round(bucket.numel * 4 / 1e6, 1),
+                        "backend": dist.get_backend(),
+                        "note": "HIP events on rank 0: all_reduce = the collective + 1/N scaling on the side stream, from its "
+                                "first instruction to its last (stretched when it shares the CUs with the attack); optimizer_wait "
+                                "= how long the compute stream stood at the collective's event before Adam (0 = fully hidden)"}
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -659,6 +685,8 @@ def run_rank(a):
             out["config"]["attack_iterations_per_step"] = atk_iters
         if other_mode is not None:
             out["config"]["other_order"] = other_mode
+        if ar_times is not None:
+            out["config"]["all_reduce"] = ar_times
         if world == 1 and not a.no_cpu_baseline:
             gpu_loss_ms = round(sum(kms.values()), 4) if kms else None
             out["cpu_baseline"] = cpu_baseline(a.height, a.width, a.atk_steps, a.batch_size,

@@ -48,7 +48,7 @@ def shorten_timeout(minutes=None):
     if not dist.is_initialized():
         return False
     import datetime
-    minutes = int(os.environ.get("DMH_DIST_STEADY_TIMEOUT_MIN", "10")) if minutes is None else minutes
+    minutes = float(os.environ.get("DMH_DIST_STEADY_TIMEOUT_MIN", "10")) if minutes is None else minutes     # fractions: tests
     setter = getattr(torch.distributed.distributed_c10d, "_set_pg_timeout", None)
     why = "this torch build has no distributed_c10d._set_pg_timeout"
     if setter is not None:
@@ -59,7 +59,7 @@ def shorten_timeout(minutes=None):
             why = "%s: %s" % (type(e).__name__, e)
     if dist.get_rank() == 0:
         import sys
-        print("[ddp] note: the process group keeps its start-up timeout (a stuck rank fails the job later than %d min): %s"
+        print("[ddp] note: the process group keeps its start-up timeout (a stuck rank fails the job later than %g min): %s"
               % (minutes, why), file=sys.stderr, flush=True)
     return False
 
@@ -92,6 +92,25 @@ class GradBucket(object):
         self.stream = torch.cuda.Stream(device=dev) if dev.type == "cuda" else None
         self._work = None
         self._event = None
+        # timing=True: HIP events around the collective on the side stream and around the consumer's wait for it, read by
+        # timings() after a synchronize (bench.py, N > 1: overlap evidence without a profiler)
+        self.timing = False
+        self._timed = []
+
+    def timings(self, clear=True):
+        """Per all-reduce since the last call: ``all_reduce_ms`` = first to last instruction of the collective (+ the 1/N
+        scaling) on the side stream -- stretched when its kernels wait for CUs beside the attack; ``wait_ms`` = how long
+        the consuming stream (the optimiser's) stood at the event: ~0 when the collective had finished behind the attack.
+        The caller synchronises first."""
+        out = {"all_reduce_ms": [], "wait_ms": []}
+        for e0, e1, w0, w1 in self._timed:
+            if w1 is None:
+                continue
+            out["all_reduce_ms"].append(e0.elapsed_time(e1))
+            out["wait_ms"].append(w0.elapsed_time(w1))
+        if clear:
+            self._timed = [t for t in self._timed if t[3] is None]
+        return out
 
     def attach(self):
         """(Re-)point every parameter's ``.grad`` at its slice of the flat buffer."""
@@ -139,13 +158,20 @@ class GradBucket(object):
 
     @contextlib.contextmanager
     def released(self):
-        """``with bucket.released(): loss.backward()`` -- release() before, collect() after, and collect() ALSO when backward
-        raises: otherwise every ``.grad`` stays detached and the next zero() / check_attached() fails with a message about
-        zero_grad(set_to_none=True) that hides the real error."""
+        """``with bucket.released(): loss.backward()`` -- release() before, collect() after; when backward raises the
+        views are re-attached (attach(): pointer work only) so that every ``.grad`` aliases its slice again -- otherwise the
+        next zero() / check_attached() fails with a message about zero_grad(set_to_none=True) that hides the real error --
+        and the ORIGINAL exception propagates."""
         self.release()
         try:
             yield self
-        finally:
+        except BaseException:
+            # backward failed -- possibly with a device error, after which collect()'s own device work (zero_, the
+            # multi-tensor copy) would raise too and REPLACE the error that matters.  Re-point the views only (no device
+            # work): whatever gradients were produced are dropped, the bucket is structurally whole again.
+            self.attach()
+            raise
+        else:
             self.collect()
 
     def start_all_reduce(self):
@@ -155,11 +181,17 @@ class GradBucket(object):
         if self.stream is not None:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
+                e0 = None
+                if self.timing:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self.stream)
                 self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                 self._work.wait()           # orders the side stream after the collective (no host block)
                 self.flat.div_(self.world)
-                self._event = torch.cuda.Event()
+                self._event = torch.cuda.Event(enable_timing=self.timing)
                 self._event.record(self.stream)
+                if e0 is not None:
+                    self._timed.append([e0, self._event, None, None])
         else:
             self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
@@ -169,7 +201,15 @@ class GradBucket(object):
             return
         if self.stream is not None:
             if self._event is not None:
-                torch.cuda.current_stream().wait_event(self._event)
+                cur = torch.cuda.current_stream()
+                rec = self._timed[-1] if (self._timed and self._timed[-1][1] is self._event) else None
+                if rec is not None:
+                    rec[2] = torch.cuda.Event(enable_timing=True)
+                    rec[2].record(cur)
+                cur.wait_event(self._event)
+                if rec is not None:
+                    rec[3] = torch.cuda.Event(enable_timing=True)
+                    rec[3].record(cur)
                 self._event = None
         elif self._work is not None:
             self._work.wait()

@@ -32,7 +32,9 @@ class MonodepthOptions:
         p.add_argument("--adv_train", action="store_true", help="do adversarial training")
         p.add_argument("--fine_tune", action="store_true", help="do finetune on an existing model")
         p.add_argument("--supervised_adv", action="store_true", help="add the supervised loss on the adversarial view")
-        p.add_argument("--norm_type", type=str, choices=["l_inf", "l_0"], default="l_inf")
+        # no default, as in the reference (MD2/options.py:94-96); Trainer.__init__ asks for it under --adv_train, where the
+        # reference would run into a NameError at MD2/trainer.py:224 (neither branch assigns ``args``)
+        p.add_argument("--norm_type", type=str, choices=["l_inf", "l_0"])
         # OPTIMIZATION
         p.add_argument("--batch_size", type=int, default=12)
         p.add_argument("--learning_rate", type=float, default=1e-4)

@@ -9,16 +9,13 @@ from ..attack import Attack
 
 
 class PGD_depth(Attack):
-    r"""
-    Distance Measure : Linf
+    """L_inf projected gradient ascent on whole frames (resized to ``scene_size`` first).
 
-    Arguments:
-        model (nn.Module): model to attack.
-        eps (float): maximum perturbation. (Default: 0.3)
-        alpha (float): step size. (Default: 2/255)
-        steps (int): number of steps. (Default: 40)
-        random_start (bool): using random initialization of delta. (Default: True)
-    Callers select the targeted (push disparity to zero) cost with ``atk._targeted = True``.
+    ``eps`` bounds |adv - image| per element, ``alpha`` is the size of one sign step, ``steps`` the number of them, and
+    ``random_start`` begins from the image plus uniform noise in [-eps, eps] clipped to [0, 1].  The untargeted cost is
+    MSE(model(adv), model(image)); with ``atk._targeted = True`` (how the reference's callers select it,
+    physical_adv_training.py:78) the cost is -MSE(model(adv), 0), i.e. the disparity is pushed to zero.
+    Constructor signature and defaults: pgd_depth.py:29-36 of the reference.
     """
 
     def __init__(self, model, eps=0.3, alpha=2 / 255, steps=40, random_start=True):

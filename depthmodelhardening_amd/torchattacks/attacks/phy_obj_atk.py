@@ -64,6 +64,8 @@ class Phy_obj_atk(Attack):
         self.use_graph = False
         self.common_windows = False     # the common-size window plans without the graph (tests: the eager twin of use_graph)
         self._graph_pool = None
+        self._capture_fault = False     # test hook: make the capture of _graph_steps fail after its first launch
+        self.graph_failure = None       # why use_graph switched itself off (a failed capture), else None
         self._graph = None      # (graph of the previous attack, event behind its last replay): destroyed once it has run
         # Data-parallel "shared patch" mode: shard = (rank, world, process group or None).  The
         # reference attacks ONE patch on batch_size scenes per iteration (MD2/trainer.py:300-307, mono_dataset.py:178-184);
@@ -164,9 +166,14 @@ class Phy_obj_atk(Attack):
                 clean, _ = ops.eot_paste(scene_imgs, self.obj_img, torch.zeros_like(mask), coeffs[0], l_pad, t_pad,
                                          self.scene_size)
 
+        first = 0
         if graph:
-            obj_img_adv = self._graph_steps(scene_imgs, obj_img_adv, mask, coeffs, plans[0], tabs, clean, l_pad, t_pad)
-        for s in range(0 if not graph else self.steps, self.steps):
+            obj_img_adv, first = self._graph_steps(scene_imgs, obj_img_adv, mask, coeffs, plans[0], tabs, clean, l_pad, t_pad)
+            if first < self.steps:      # the capture failed: the eager loop takes over on the same common-size plans
+                plans[0].table_rewritten = False
+                for p_, t_ in zip(plans, tabs):
+                    p_.bind_table(t_)
+        for s in range(first, self.steps):
             obj_img_adv.requires_grad_()
             adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[s], l_pad, t_pad,
                                                       self.scene_size)
@@ -234,13 +241,35 @@ class Phy_obj_atk(Attack):
         pool, side, _ = self._graph_pool
         side.wait_stream(main)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.stream(side):
-            ops._sk_workspace(dev)                          # this stream's stream-K workspace: allocated outside the capture
-            g.capture_begin(pool=pool)
-            try:
-                step()
-            finally:
+        try:
+            with torch.cuda.stream(side):
+                ops._sk_workspace(dev)                      # this stream's stream-K workspace: allocated outside the capture
+                # thread_local: a HIP call of ANOTHER thread (the process group's watchdog, the all-reduce still in flight on the
+                # bucket's stream in the trainer's overlap mode) must not invalidate this thread's capture
+                g.capture_begin(pool=pool, capture_error_mode="thread_local")
+                try:
+                    if self._capture_fault:                 # test hook: a capture that dies half way
+                        ops.eot_paste(scene_imgs, patch_in, mask, coeff_cur, l_pad, t_pad, self.scene_size)
+                        raise RuntimeError("injected capture fault")
+                    step()
+                except BaseException:
+                    try:
+                        g.capture_end()                     # ends the (invalidated) capture; its own error adds nothing
+                    except Exception:
+                        pass
+                    raise
                 g.capture_end()
+        except RuntimeError as e:
+            # Nothing of the captured step has executed: the device holds the state step 0 left (patch_in = the patch after
+            # step 0, the encoder head's bookkeeping copies of step 0's origins).  Hand the attack back to the eager loop and
+            # stop trying: a stack that cannot capture this step will not capture the next attack's either.
+            main.wait_stream(side)
+            self.use_graph = False
+            self.graph_failure = "%s: %s" % (type(e).__name__, str(e).splitlines()[0] if str(e) else "")
+            import warnings
+            warnings.warn("Phy_obj_atk: HIP-graph capture of the attack step failed (%s); continuing with eager launches"
+                          % self.graph_failure)
+            return patch_in.clone(), 1
         main.wait_stream(side)
         g.replay()                                          # step 1 (capturing executes nothing)
         for s in range(2, self.steps):
@@ -251,7 +280,7 @@ class Phy_obj_atk(Attack):
         done = torch.cuda.Event()
         done.record(main)
         self._graph = (g, done)
-        return out
+        return out, self.steps
 
     def _shard_without_scenes(self, obj_img_adv, dist, group):
         """A rank whose share of the attack batch is empty (world > batch_size): it contributes a zero gradient to every

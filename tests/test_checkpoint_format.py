@@ -56,7 +56,7 @@ def _trainer(tmp_path, extra=()):
     opts = MonodepthOptions().parse(["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "64",
                                      "--width", "192", "--batch_size", "2", "--weights_init", "scratch", "--no_cuda",
                                      "--log_dir", str(tmp_path), "--model_name", "ck", "--synthetic_len", "4"] + list(extra))
-    return Trainer(opts, device=torch.device("cpu"))
+    return Trainer(opts, device=torch.device("cpu"), host_only=True)
 
 
 def test_saved_files_and_keys_equal_the_reference_layout(tmp_path):

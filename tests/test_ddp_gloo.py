@@ -156,3 +156,30 @@ def test_release_collect_equals_in_place_accumulation():
     b.zero()                                                # the in-place path still works afterwards
     (m(x) ** 2).mean().backward()
     assert torch.equal(b.flat, want)
+
+
+def test_released_keeps_the_original_error_and_reattaches():
+    """``with bucket.released(): backward()`` where backward raises: the ORIGINAL exception comes out (collect()'s device work
+    is not attempted -- after a device error it would raise too and replace it) and every .grad aliases its slice again."""
+    from depthmodelhardening_amd.ddp import GradBucket
+    m = _model()
+    b = GradBucket(list(m.parameters()), 1)
+    calls = []
+    b.collect = lambda: calls.append("collect")
+
+    class Boom(RuntimeError):
+        pass
+
+    try:
+        with b.released():
+            assert all(p.grad is None for p in b.params)
+            raise Boom("backward died")
+    except Boom as e:
+        assert e.__context__ is None and str(e) == "backward died"
+    else:
+        assert False, "the error was swallowed"
+    assert not calls
+    b.check_attached()
+    with b.released():
+        pass
+    assert calls == ["collect"]

@@ -8,7 +8,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+# one xdist group: these tests start rank processes of their own, and the box allows six processes on the GPU
+pytestmark = [pytest.mark.gpu, pytest.mark.xdist_group("ranks")]
 
 
 def _free_port():

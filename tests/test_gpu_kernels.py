@@ -58,15 +58,19 @@ def _oracle_loss(loss_ref, inputs, disps, noise, variant, frame_ids=(0, "s")):
 
 
 def _pool_seeds(B, H, W, seed):
-    """Seeds to pool so that the gradient bound is decided by >= ~2e5 pixels, not by a handful of flips."""
-    n = int(min(24, max(3, -(-200000 // (B * H * W)))))
+    """Seeds to pool so that the gradient bound is decided by >= ~2e5 pixels, not by a handful of flips -- and no more than
+    that: every seed is one float32 and one float64 oracle pass on the CPU (the suite's time budget, profiles/
+    r06_gpu_suite_durations.txt)."""
+    n = int(min(24, max(1, -(-200000 // (B * H * W)))))
     return [seed + 1000 * i for i in range(n)]
 
 
 @pytest.mark.parametrize("variant", ["md2", "dh"])
-@pytest.mark.parametrize("shape", [(2, 32, 96, 21), (2, 192, 640, 22), (1, 48, 80, 5), (3, 64, 200, 9)])
+@pytest.mark.parametrize("shape", [(8, 32, 96, 21), (2, 192, 640, 22), (5, 48, 80, 5), (3, 64, 200, 9)])
 @pytest.mark.parametrize("with_noise", [False, True])
 def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
+    # (the two small image sizes run at batch 8 / 5: the pooled pixel count is what decides the gradient bound, and a seed
+    # costs two oracle passes whose time at these sizes is all per-call overhead; batch 2 / 1 at those sizes: the goldens)
     if not with_noise and shape[1:3] in ((48, 80), (64, 200)):
         pytest.skip("the noise-free form is covered at two shapes; with the tie-break noise at all four (suite time)")
     N, ops, loss_ref, _, synth, _ = _mods()

@@ -63,18 +63,18 @@ def _hip(ops, inputs, disps, variant, noise=None, **kw):
 @pytest.mark.parametrize("shape", [(2, 192, 640), (3, 64, 200), (2, 320, 1024)])
 def test_gradients_within_fp32_conditioning_of_the_fp64_oracle(variant, shape):
     """err(HIP vs fp64) <= 1.5 x err(fp32 oracle vs fp64) + 1e-6: rel-L2 over all elements, and the count of elements
-    beyond 1e-4 of the tensor's scale (tests.util.GradPool).  Pooled over three seeds so that a handful of flips on
-    either side cannot decide it.  "dh_hints" = DepthHints with --use_depth_hints (DH/trainer.py:541-555,700-725): the
+    beyond 1e-4 of the tensor's scale (tests.util.GradPool).  Pooled over seeds until >= 2e5 pixels decide, so that a
+    handful of flips on either side cannot.  (2, 320, 1024) with "dh" is BASELINE config 4's own loss at its resolution.  "dh_hints" = DepthHints with --use_depth_hints (DH/trainer.py:541-555,700-725): the
     gradient then also carries the proxy term log(|hint - depth| + 1) differentiated through depth = 1/(a + b disp)."""
     N, ops, loss_ref, synth = _mods()
     B, H, W = shape
-    if shape == (2, 320, 1024) and variant == "dh":
-        pytest.skip("headline resolution: md2 and dh_hints cover both normalisations (three float64 oracle runs each)")
     hints = variant == "dh_hints"
     var = "dh" if hints else variant
     pool = GradPool(count_floor=0.0 if variant == "md2" else 2.0 / (H * W))
     loss_err_h = loss_err_o = 0.0
-    for seed in (22, 23, 24):
+    # as many seeds as it takes to let >= 2e5 pixels decide (at least one, at most three): one 2 x 320 x 1024 case is 655k
+    # pixels by itself, and each seed is a float64 + a float32 oracle pass on the CPU
+    for seed in (22, 23, 24)[:max(1, min(3, -(-200000 // (B * H * W))))]:
         i64, d64, o64, l64, _ = _oracle(loss_ref, synth, B, H, W, seed, torch.float64, var, hints=hints)
         i32, d32, o32, l32, _ = _oracle(loss_ref, synth, B, H, W, seed, torch.float32, var, hints=hints)
         out, dd = _hip(ops, i32, d32, var)

@@ -14,7 +14,8 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+# one xdist group: these tests start rank processes of their own, and the box allows six processes on the GPU
+pytestmark = [pytest.mark.gpu, pytest.mark.xdist_group("ranks")]
 
 STEPS, SCENES = 3, 12
 
@@ -42,12 +43,7 @@ def _attack(model, obj, pmask):
     return Phy_obj_atk(model, obj, pmask, eps=0.1, alpha=0.02, steps=STEPS, dist_range=list(np.arange(5, 10, 0.2)))
 
 
-def _worker(rank, world, port, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", DMH_DIST_BACKEND="gloo")
-    import torch.distributed as dist
-    from depthmodelhardening_amd.ddp import init_distributed
-    _, _, dev = init_distributed("cuda")
+def _linf_body(rank, world, dev, ret):
     model, obj, pmask, scenes, noise = _setup(dev)
     atk = _attack(model, obj, pmask)
     atk.shard = (rank, world, None)
@@ -57,15 +53,32 @@ def _worker(rank, world, port, ret):
     mine = scenes[rank::world].contiguous()
     adv, ben, m, patch = atk(mine, SCENES)
     torch.cuda.synchronize()
-    ret[rank] = (patch.cpu(), tuple(adv.shape), float(m.sum()))
+    ret[("linf", rank)] = (patch.cpu(), tuple(adv.shape), float(m.sum()))
+
+
+def _both_worker(rank, world, port, ret):
+    """ONE pair of rank processes for both sharded attacks (a spawned rank costs ~10 s of imports and HIP start-up)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0", DMH_DIST_BACKEND="gloo")
+    import torch.distributed as dist
+    from depthmodelhardening_amd.ddp import init_distributed
+    _, _, dev = init_distributed("cuda")
+    _linf_body(rank, world, dev, ret)
+    dist.barrier()
+    _l0_body(rank, world, dev, ret)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_sharded_attack_equals_the_one_process_attack_on_all_scenes():
+@pytest.fixture(scope="module")
+def sharded():
     ret = mp.Manager().dict()
-    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
-    (p0, shape0, m0), (p1, shape1, m1) = ret[0], ret[1]
+    mp.spawn(_both_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    return dict(ret)
+
+
+def test_sharded_attack_equals_the_one_process_attack_on_all_scenes(sharded):
+    (p0, shape0, m0), (p1, shape1, m1) = sharded[("linf", 0)], sharded[("linf", 1)]
     assert torch.equal(p0, p1), "the ranks must end with ONE patch"
     assert shape0 == shape1 == (SCENES // 2, 3, 320, 1024) and m0 > 0 and m1 > 0
     # the one-process attack on the twelve scenes, same start noise, same draws
@@ -128,12 +141,7 @@ def _l0_attack(model, obj, pmask):
     return Phy_obj_atk_l0(model, obj, pmask, adam_lr=0.5, steps=2, mask_wt=0.1, l0_thresh=0.1, dist_range=list(np.arange(5, 10, 0.2)))
 
 
-def _l0_worker(rank, world, port, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK="0", DMH_DIST_BACKEND="gloo")
-    import torch.distributed as dist
-    from depthmodelhardening_amd.ddp import init_distributed
-    _, _, dev = init_distributed("cuda")
+def _l0_body(rank, world, dev, ret):
     model, obj, pmask, scenes, _ = _setup(dev)
     atk = _l0_attack(model, obj, pmask)
     atk.shard = (rank, world, None)
@@ -147,16 +155,12 @@ def _l0_worker(rank, world, port, ret):
     # it, and the eval override (6.1 m, 0 degrees) belongs to global scene 0 -- rank 0's first scene and nobody else's
     _, _, m2, _ = atk(mine, SCENES, eval=True)
     torch.cuda.synchronize()
-    ret[rank] = first + (m.sum((1, 2, 3)).cpu(), m2.sum((1, 2, 3)).cpu(), random.random())
-    dist.barrier()
-    dist.destroy_process_group()
+    ret[("l0", rank)] = first + (m.sum((1, 2, 3)).cpu(), m2.sum((1, 2, 3)).cpu(), random.random())
 
 
-def test_sharded_l0_attack_equals_the_one_process_attack():
+def test_sharded_l0_attack_equals_the_one_process_attack(sharded):
     """Phy_obj_atk_l0 under a shard: Adam on the two pattern tensors with their gradients summed over the ranks."""
-    ret = mp.Manager().dict()
-    mp.spawn(_l0_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
-    (p0, m0, g0, ma0, mb0, r0), (p1, m1, g1, ma1, mb1, _) = ret[0], ret[1]
+    (p0, m0, g0, ma0, mb0, r0), (p1, m1, g1, ma1, mb1, _) = sharded[("l0", 0)], sharded[("l0", 1)]
     assert torch.equal(p0, p1) and m0 > 0 and m1 > 0 and all(torch.equal(a, b) for a, b in zip(g0, g1))
     dev = torch.device("cuda")
     model, obj, pmask, scenes, _ = _setup(dev)
