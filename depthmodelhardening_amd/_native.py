@@ -50,6 +50,10 @@ class RoiGlueArgs(C.Structure):
                 ("elu", C.c_int)]
 
 
+class WinoWtJob(C.Structure):
+    _fields_ = [("w", _fp), ("scale", _fp), ("U", _fp), ("K", C.c_int), ("C", C.c_int), ("backward", C.c_int)]
+
+
 _PtrArr = _fp * MAX_SCALES
 
 _SIGNATURES = {
@@ -106,10 +110,13 @@ _SIGNATURES = {
     "dmh_roi_cost_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dmh_roi_cost_fwd": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 5 + [_fp] * 4),
     "dmh_roi_cost_bwd": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 5 + [_fp] * 3),
+    "dmh_roi_cost_fwd_scaled": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 5 + [C.c_float] + [_fp] * 4),
+    "dmh_roi_cost_bwd_scaled": (C.c_int, [_fp, _fp, _fp] + [C.c_int] * 5 + [C.c_float] + [_fp] * 3),
     "dmh_bn_act_fwd": (C.c_int, [_fp] * 4 + [C.c_int] * 4 + [_fp, _fp]),
     "dmh_bn_act_bwd": (C.c_int, [_fp] * 3 + [C.c_int] * 4 + [_fp, _fp, _fp]),
     "dmh_bn_stats_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dmh_bn_train_stats": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float] + [_fp] * 8),
+    "dmh_bn_train_stats_tracked": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_float, C.c_float] + [_fp] * 9),
     "dmh_channel_sum_partials_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
     "dmh_channel_sum": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, C.c_void_p]),
     "dmh_bn_train_bwd_workspace_size": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
@@ -122,6 +129,7 @@ _SIGNATURES = {
     "dmh_wino_conv3x3_ws": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp, C.c_int64, _fp]),
     "dmh_wino_weight_transform_scaled": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "dmh_wino_conv3x3_act": (C.c_int, [_fp] * 4 + [C.c_int] * 7 + [_fp, _fp]),
+    "dmh_wino_weight_transform_batch": (C.c_int, [C.POINTER(WinoWtJob), C.c_int, _fp]),
     "dmh_wino_conv3x3_act_ws": (C.c_int, [_fp] * 4 + [C.c_int] * 7 + [_fp, _fp, C.c_int64, _fp]),
     "dmh_wino32_weight_size": (C.c_int64, [C.c_int, C.c_int]),
     "dmh_wino32_weight_transform": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),

@@ -326,9 +326,11 @@ __global__ __launch_bounds__(NT) void bn_stats_finalize_kernel(const float* __re
                                                                float* __restrict__ running_mean,
                                                                float* __restrict__ running_var, float* __restrict__ scale,
                                                                float* __restrict__ shift, float* __restrict__ save_mean,
-                                                               float* __restrict__ save_invstd) {
+                                                               float* __restrict__ save_invstd,
+                                                               long long* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * NT + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && num_batches_tracked) num_batches_tracked[0] += 1;     // nn.BatchNorm2d.forward's counter: one thread, one launch
     Wf t{0.f, 0.f, 0.f};
     for (int s = 0; s < S; ++s) {
         const float* p = part + ((size_t)c * S + s) * 3;
@@ -621,14 +623,23 @@ int64_t dmh_bn_stats_partials_size(int B, int C, int HW) {
 int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
                        float eps, float* running_mean, float* running_var, float* partials, float* scale, float* shift,
                        float* save_mean, float* save_invstd, void* stream) {
+    return dmh_bn_train_stats_tracked(x, B, C, HW, weight, bias, momentum, eps, running_mean, running_var, nullptr, partials,
+                                      scale, shift, save_mean, save_invstd, stream);
+}
+
+int dmh_bn_train_stats_tracked(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
+                               float eps, float* running_mean, float* running_var, long long* num_batches_tracked,
+                               float* partials, float* scale, float* shift, float* save_mean, float* save_invstd,
+                               void* stream) {
     DMH_REQUIRE(x && partials && scale && shift && save_mean && save_invstd, "null pointer");
+    DMH_REQUIRE((reinterpret_cast<uintptr_t>(num_batches_tracked) & 7) == 0, "num_batches_tracked must be an aligned int64");
     DMH_REQUIRE(B > 0 && C > 0 && HW > 0 && C <= 65535, "bad sizes");
     int64_t S = ((int64_t)HW + 4 * NT - 1) / (4 * NT);     // slabs per plane
     if (S > 64) S = 64;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(bn_stats_partial_kernel, dim3((unsigned)S, C), dim3(NT), 0, st, x, B, C, HW, (int)S, partials);
     hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(blocks_for(C)), dim3(NT), 0, st, partials, C, (int)S, weight, bias,
-                       momentum, eps, running_mean, running_var, scale, shift, save_mean, save_invstd);
+                       momentum, eps, running_mean, running_var, scale, shift, save_mean, save_invstd, num_batches_tracked);
     return check_launch("dmh_bn_train_stats");
 }
 

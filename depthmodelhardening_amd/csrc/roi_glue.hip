@@ -16,6 +16,8 @@
 // Backward = a gather over the same index map (deterministic, no atomics); positions no window entry reads get 0.
 //
 //   roi_cost : cost = sum_b sum_window (sigmoid(d_pre) * mask)^2 / (B H W)        (mask is the full-frame K3 output)
+#include <stdlib.h>
+
 #include "common.hpp"
 
 using namespace dmh;
@@ -27,12 +29,29 @@ constexpr int NT = 256;
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : expf(x) - 1.f; }
 __device__ __forceinline__ float elu_grad(float x) { return x > 0.f ? 1.f : expf(x); }
 
-__global__ __launch_bounds__(NT) void roi_glue_fwd_kernel(const dmh_roi_glue_args a, float* __restrict__ out) {
+// row / column pair of a flat pair index by a reciprocal multiplication (magic = 2^32 / w2 rounded up, from the host): the
+// 32-bit integer division it replaces is ~25 vector instructions per thread in kernels that move 8-16 bytes per thread
+__device__ __forceinline__ void split_rc(int t, int w2, unsigned magic, int& row, int& col2) {
+    if (w2 == 1) {
+        row = t;
+        col2 = 0;
+        return;
+    }
+    int r = (int)__umulhi((unsigned)t, magic);
+    if (r * w2 > t) --r;                        // (magic is rounded up: at most one too large)
+    row = r;
+    col2 = t - r * w2;
+}
+
+__global__ __launch_bounds__(NT) void roi_glue_fwd_kernel(const dmh_roi_glue_args a, unsigned magic, float* __restrict__ out) {
     const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
-    const int idx = (blockIdx.x * NT + threadIdx.x) * 2;        // PW is even: a pair never straddles two rows
-    if (idx >= PH * PW) return;
+    const int t = blockIdx.x * NT + threadIdx.x;                // PW is even: a pair never straddles two rows
+    if (2 * t >= PH * PW) return;
     const int plane = blockIdx.y, b = plane / C, c = plane - b * C;
-    const int i = idx / PW, j = idx - i * PW;
+    int i, j;
+    split_rc(t, PW >> 1, magic, i, j);
+    j *= 2;
+    const int idx = 2 * t;
     const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
     const int Y = reflect_idx(oy + i - 1, a.H);
     const int X0 = reflect_idx(ox + j - 1, a.W), X1 = reflect_idx(ox + j, a.W);
@@ -161,6 +180,126 @@ __global__ __launch_bounds__(NT) void roi_glue_bwd_kernel(const dmh_roi_glue_arg
     }
 }
 
+// One gathered element of g_y / g_skip, exactly as roi_glue_bwd_kernel forms it (the general path of the two-wide kernel).
+__device__ __forceinline__ float glue_bwd_y_elem(const dmh_roi_glue_args& a, const float* __restrict__ gp, int Ys, int Xs, int oy,
+                                                 int ox, int PH, int PW) {
+    if (a.up) {
+        const int Y0 = 2 * Ys, X0 = 2 * Xs;
+        if (Y0 > 1 && Y0 + 1 < a.H - 2 && X0 > 1 && X0 + 1 < a.W - 2) {
+            const int r = Y0 + 1 - oy, q = X0 + 1 - ox;
+            if (r >= 0 && r + 1 < PH && q >= 0 && q + 1 < PW) {
+                const float* p0 = gp + r * PW + q;
+                return p0[0] + p0[1] + p0[PW] + p0[PW + 1];
+            }
+            if (r + 1 < 0 || r >= PH || q + 1 < 0 || q >= PW) return 0.f;
+            return gather_interior(gp, Y0, X0, oy, ox, PH, PW) + gather_interior(gp, Y0, X0 + 1, oy, ox, PH, PW) +
+                   gather_interior(gp, Y0 + 1, X0, oy, ox, PH, PW) + gather_interior(gp, Y0 + 1, X0 + 1, oy, ox, PH, PW);
+        }
+        return gather_pad(gp, Y0, X0, a.H, a.W, oy, ox, PH, PW) + gather_pad(gp, Y0, X0 + 1, a.H, a.W, oy, ox, PH, PW) +
+               gather_pad(gp, Y0 + 1, X0, a.H, a.W, oy, ox, PH, PW) + gather_pad(gp, Y0 + 1, X0 + 1, a.H, a.W, oy, ox, PH, PW);
+    }
+    if (Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs < a.W - 2) return gather_interior(gp, Ys, Xs, oy, ox, PH, PW);
+    return gather_pad(gp, Ys, Xs, a.H, a.W, oy, ox, PH, PW);
+}
+
+// Round 6: two adjacent source elements per thread (every region and plane width of the window plan is even, roi.py), the
+// row / column of a thread by a reciprocal multiplication instead of an integer division, exact grids per part (grid.z: the
+// g_y planes and the g_skip planes have their own block counts) -- the one-element kernel spent as many cycles on index
+// arithmetic as on its loads.  Same arithmetic per element (same order of additions): bit-identical results.
+struct Region2 {
+    Region rg;
+    unsigned ymagic, kmagic;    // ceil(2^32 / (width / 2)) of the two parts
+    int yblocks, kblocks;       // blocks along x of the two parts
+};
+__global__ __launch_bounds__(NT) void roi_glue_bwd2_kernel(const dmh_roi_glue_args a, const Region2 r2,
+                                                           const float* __restrict__ g_out, float* __restrict__ g_y,
+                                                           float* __restrict__ g_skip) {
+    const Region& rg = r2.rg;
+    const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
+    // flat grid: the blocks of the g_y planes, then those of the g_skip planes (uniform decode: scalar divisions)
+    const int ytotal = r2.yblocks * a.B * a.C1;
+    const bool ypart = (int)blockIdx.x < ytotal;
+    const int bid = ypart ? (int)blockIdx.x : (int)blockIdx.x - ytotal;
+    const int per = ypart ? r2.yblocks : r2.kblocks;
+    const int pl = bid / per;
+    const int t = (bid - pl * per) * NT + (int)threadIdx.x;
+    if (ypart) {
+        const int plane = pl;
+        const int w2 = rg.yw >> 1;
+        if (t >= rg.yh * w2) return;
+        const int b = plane / a.C1, c = plane - b * a.C1;
+        const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
+        const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
+        int yy, xx;
+        split_rc(t, w2, r2.ymagic, yy, xx);
+        xx *= 2;
+        if (rg.y_org) {
+            yy += rg.y_org[2 * b];
+            xx += rg.y_org[2 * b + 1];
+        }
+        const int Ys = sy0 + yy, Xs = sx0 + xx;
+        const float* gp = g_out + (size_t)(b * C + c) * PH * PW;
+        float v0, v1;
+        bool fast = false;
+        if (a.up) {
+            const int Y0 = 2 * Ys, X0 = 2 * Xs, r = Y0 + 1 - oy, q = X0 + 1 - ox;
+            // both elements away from the frame's border and all eight entries inside the window
+            if (Y0 > 1 && Y0 + 1 < a.H - 2 && X0 > 1 && X0 + 3 < a.W - 2 && r >= 0 && r + 1 < PH && q >= 0 && q + 3 < PW) {
+                const float* p0 = gp + r * PW + q;
+                v0 = p0[0] + p0[1] + p0[PW] + p0[PW + 1];
+                v1 = p0[2] + p0[3] + p0[PW + 2] + p0[PW + 3];
+                fast = true;
+            }
+        } else {
+            const int r = Ys + 1 - oy, q = Xs + 1 - ox;
+            if (Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs + 1 < a.W - 2 && r >= 0 && r < PH && q >= 0 && q + 1 < PW) {
+                v0 = gp[r * PW + q];
+                v1 = gp[r * PW + q + 1];
+                fast = true;
+            }
+        }
+        if (!fast) {
+            v0 = glue_bwd_y_elem(a, gp, Ys, Xs, oy, ox, PH, PW);
+            v1 = glue_bwd_y_elem(a, gp, Ys, Xs + 1, oy, ox, PH, PW);
+        }
+        const size_t o = ((size_t)plane * a.sh + yy) * a.sw + xx;
+        if (a.elu) {
+            const float2 yv = *reinterpret_cast<const float2*>(a.y + o);
+            v0 = v0 != 0.f ? v0 * elu_grad(yv.x) : v0;
+            v1 = v1 != 0.f ? v1 * elu_grad(yv.y) : v1;
+        }
+        *reinterpret_cast<float2*>(g_y + o) = make_float2(v0, v1);
+    } else {
+        const int q = pl;
+        const int w2 = rg.kw >> 1;
+        if (t >= rg.kh * w2) return;
+        const int b = q / a.C2, c = q - b * a.C2;
+        const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
+        const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
+        int yy, xx;
+        split_rc(t, w2, r2.kmagic, yy, xx);
+        xx *= 2;
+        if (rg.skip_org) {
+            yy += rg.skip_org[2 * b];
+            xx += rg.skip_org[2 * b + 1];
+        }
+        const float* gp = g_out + (size_t)(b * C + a.C1 + c) * PH * PW;
+        const int Ys = ky0 + yy, Xs = kx0 + xx;
+        const int r = Ys + 1 - oy, qq = Xs + 1 - ox;
+        float v0, v1;
+        if (Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs + 1 < a.W - 2 && r >= 0 && r < PH && qq >= 0 && qq + 1 < PW) {
+            v0 = gp[r * PW + qq];
+            v1 = gp[r * PW + qq + 1];
+        } else {
+            v0 = (Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs < a.W - 2) ? gather_interior(gp, Ys, Xs, oy, ox, PH, PW)
+                                                                     : gather_pad(gp, Ys, Xs, a.H, a.W, oy, ox, PH, PW);
+            v1 = (Ys > 1 && Ys < a.H - 2 && Xs + 1 > 1 && Xs + 1 < a.W - 2) ? gather_interior(gp, Ys, Xs + 1, oy, ox, PH, PW)
+                                                                             : gather_pad(gp, Ys, Xs + 1, a.H, a.W, oy, ox, PH, PW);
+        }
+        *reinterpret_cast<float2*>(g_skip + ((size_t)q * a.kh + yy) * a.kw + xx) = make_float2(v0, v1);
+    }
+}
+
 // ---- windowed attack cost ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void roi_cost_fwd_kernel(const float* __restrict__ d_pre, const float* __restrict__ mask,
                                                           const int* __restrict__ org, int hd, int wd, int H, int W,
@@ -232,8 +371,9 @@ extern "C" {
 int dmh_roi_glue_fwd(const dmh_roi_glue_args* a, float* out, void* stream) {
     if (int rc = check_glue(a)) return rc;
     DMH_REQUIRE(out, "null pointer");
+    const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)((a->wc + 2) >> 1)) + 1u;
     hipLaunchKernelGGL(roi_glue_fwd_kernel, dim3(blocks_for((int64_t)(a->hc + 2) * (a->wc + 2) / 2), a->B * (a->C1 + a->C2)),
-                       dim3(NT), 0, (hipStream_t)stream, *a, out);
+                       dim3(NT), 0, (hipStream_t)stream, *a, magic, out);
     return check_launch("dmh_roi_glue_fwd");
 }
 
@@ -255,6 +395,25 @@ int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y,
     const bool skip = g_skip && a->C2 > 0;
     const int planes = a->B * a->C1 + (skip ? a->B * a->C2 : 0);
     const int64_t ny = (int64_t)rg.yh * rg.yw, nk = skip ? (int64_t)rg.kh * rg.kw : 0;
+    // two elements per thread where every width involved is even and every base 8-byte aligned (the window plan's sizes and
+    // origins all are; DMH_ROI_GLUE2=0: the one-element kernel, A/B switch)
+    static const bool wide_ok = !(getenv("DMH_ROI_GLUE2") && atoi(getenv("DMH_ROI_GLUE2")) == 0);
+    bool wide = wide_ok && !(rg.yw & 1) && !(a->sw & 1) && !(((uintptr_t)g_y | (uintptr_t)a->y) & 7) &&
+                (!skip || (!(rg.kw & 1) && !(a->kw & 1) && !((uintptr_t)g_skip & 7)));
+    if (wide) {
+        Region2 r2;
+        r2.rg = rg;
+        const unsigned yw2 = (unsigned)(rg.yw >> 1), kw2 = skip ? (unsigned)(rg.kw >> 1) : 1u;
+        r2.ymagic = (unsigned)(((uint64_t)1 << 32) / yw2) + 1u;      // >= 2^32 / w2: split_rc corrects the one-off case
+        r2.kmagic = (unsigned)(((uint64_t)1 << 32) / kw2) + 1u;
+        r2.yblocks = (int)blocks_for(ny / 2);
+        r2.kblocks = skip ? (int)blocks_for(nk / 2) : 1;
+        const int64_t total = (int64_t)r2.yblocks * a->B * a->C1 + (skip ? (int64_t)r2.kblocks * a->B * a->C2 : 0);
+        DMH_REQUIRE(total < ((int64_t)1 << 31), "too many blocks");
+        hipLaunchKernelGGL(roi_glue_bwd2_kernel, dim3((unsigned)total), dim3(NT), 0, (hipStream_t)stream, *a, r2, g_out, g_y,
+                           g_skip);
+        return check_launch("dmh_roi_glue_bwd");
+    }
     hipLaunchKernelGGL(roi_glue_bwd_kernel, dim3(blocks_for(ny > nk ? ny : nk), planes), dim3(NT), 0, (hipStream_t)stream, *a,
                        rg, g_out, g_y, g_skip);
     return check_launch("dmh_roi_glue_bwd");
@@ -264,22 +423,34 @@ int64_t dmh_roi_cost_partials_size(int B, int hd, int wd) { return (int64_t)B * 
 
 int dmh_roi_cost_fwd(const float* d_pre, const float* mask, const int* org, int B, int hd, int wd, int H, int W, float* sig,
                      float* partials, float* cost, void* stream) {
+    return dmh_roi_cost_fwd_scaled(d_pre, mask, org, B, hd, wd, H, W, 1.f, sig, partials, cost, stream);
+}
+
+int dmh_roi_cost_fwd_scaled(const float* d_pre, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
+                            float scale, float* sig, float* partials, float* cost, void* stream) {
     DMH_REQUIRE(d_pre && mask && org && sig && partials && cost, "null pointer");
+    DMH_REQUIRE(scale == 1.f || scale == -1.f, "scale must be +1 or -1 (a sign: the result stays bit-identical to -cost)");
     DMH_REQUIRE(B > 0 && B <= 65535 && hd >= 1 && wd >= 1 && hd <= H && wd <= W && (int64_t)hd * wd < (1 << 30), "bad sizes");
     const int nb = cost_blocks(hd * wd);
     hipLaunchKernelGGL(roi_cost_fwd_kernel, dim3(nb, B), dim3(NT), 0, (hipStream_t)stream, d_pre, mask, org, hd, wd, H, W, sig,
                        partials);
     hipLaunchKernelGGL(roi_cost_finalize_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, partials, nb * B,
-                       (double)B * (double)H * (double)W, cost);
+                       (double)scale * (double)B * (double)H * (double)W, cost);
     return check_launch("dmh_roi_cost_fwd");
 }
 
 int dmh_roi_cost_bwd(const float* sig, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
                      const float* gscale, float* g_pre, void* stream) {
+    return dmh_roi_cost_bwd_scaled(sig, mask, org, B, hd, wd, H, W, 1.f, gscale, g_pre, stream);
+}
+
+int dmh_roi_cost_bwd_scaled(const float* sig, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
+                            float scale, const float* gscale, float* g_pre, void* stream) {
     DMH_REQUIRE(sig && mask && org && gscale && g_pre, "null pointer");
+    DMH_REQUIRE(scale == 1.f || scale == -1.f, "scale must be +1 or -1");
     DMH_REQUIRE(B > 0 && B <= 65535 && hd >= 1 && wd >= 1 && hd <= H && wd <= W && (int64_t)hd * wd < (1 << 30), "bad sizes");
     hipLaunchKernelGGL(roi_cost_bwd_kernel, dim3(blocks_for((int64_t)hd * wd), B), dim3(NT), 0, (hipStream_t)stream, sig, mask,
-                       org, hd, wd, H, W, gscale, (float)(1.0 / ((double)B * (double)H * (double)W)), g_pre);
+                       org, hd, wd, H, W, gscale, (float)((double)scale / ((double)B * (double)H * (double)W)), g_pre);
     return check_launch("dmh_roi_cost_bwd");
 }
 

@@ -73,11 +73,10 @@ constexpr int SK_SLOT = 16 * NT * 4;      // floats of one partial item: [output
 // mode 1: backward  u[c][k] from w[k][c][2-ky][2-kx]   (output channels of the pass = C of the filter)
 // scale (optional): per-channel factor of the convolution OUTPUT of the forward pass (an eval-mode BatchNorm folded
 // into the filter): multiplies filter row ko in mode 0 and filter column ci (the same channel) in mode 1.
-__global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict__ w, int Kw, int Cw, int mode,
-                                                         const float* __restrict__ scale, float* __restrict__ U, int Kp) {
+__device__ __forceinline__ void wino_weight_element(const float* __restrict__ w, int Kw, int Cw, int mode,
+                                                    const float* __restrict__ scale, float* __restrict__ U, int Kp, int i) {
     // "out" / "in" are the channel roles of the pass this transform is for
     const int n_out = mode ? Cw : Kw, n_in = mode ? Kw : Cw;
-    const int i = blockIdx.x * NT + threadIdx.x;       // over Kp * n_in
     if (i >= Kp * n_in) return;
     const int ko = i % Kp, ci = i / Kp;
     float g[3][3];
@@ -114,6 +113,30 @@ __global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict
             U[((((size_t)cc * 16 + p) * 2 + h) * Kp + ko) * 4 + s] = u[b];
         }
     }
+}
+
+__global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict__ w, int Kw, int Cw, int mode,
+                                                         const float* __restrict__ scale, float* __restrict__ U, int Kp) {
+    wino_weight_element(w, Kw, Cw, mode, scale, U, Kp, (int)blockIdx.x * NT + (int)threadIdx.x);    // over Kp * n_in
+}
+
+// Many filters in ONE launch (dmh_wino_weight_transform_batch): the jobs travel by value in the kernel arguments, a block finds
+// its job by a scan of the jobs' first blocks (uniform: scalar code).  A step transforms ~76 filters of 37 K ... 2.4 M elements
+// each -- as 76 launches of 5-20 us they cost 0.67 ms of an 85 ms step, most of it launch ramp.
+constexpr int WT_MAX_JOBS = 32;
+struct WtBatch {
+    const float* w[WT_MAX_JOBS];
+    const float* scale[WT_MAX_JOBS];
+    float* U[WT_MAX_JOBS];
+    int K[WT_MAX_JOBS], C[WT_MAX_JOBS], mode[WT_MAX_JOBS], Kp[WT_MAX_JOBS];
+    int first[WT_MAX_JOBS + 1];     // first block of job j; first[n] = grid size
+    int n;
+};
+__global__ __launch_bounds__(NT) void wino_weight_batch_kernel(const WtBatch b) {
+    int j = 0;
+    while (j + 1 < b.n && (int)blockIdx.x >= b.first[j + 1]) ++j;
+    wino_weight_element(b.w[j], b.K[j], b.C[j], b.mode[j], b.scale[j], b.U[j], b.Kp[j],
+                        ((int)blockIdx.x - b.first[j]) * NT + (int)threadIdx.x);
 }
 
 // Decoded work item: 64 output channels x one TRH x TRW tile region of one image.  Items are numbered with the
@@ -741,6 +764,30 @@ int dmh_wino_weight_transform_scaled(const float* w, int K, int C, int backward,
 
 int dmh_wino_weight_transform(const float* w, int K, int C, int backward, float* U, void* stream) {
     return dmh_wino_weight_transform_scaled(w, K, C, backward, nullptr, U, stream);
+}
+
+int dmh_wino_weight_transform_batch(const dmh_wino_wt_job* jobs, int n, void* stream) {
+    DMH_REQUIRE(n >= 0 && (jobs || n == 0), "null pointer");
+    for (int lo = 0; lo < n; lo += WT_MAX_JOBS) {
+        WtBatch b;
+        b.n = n - lo < WT_MAX_JOBS ? n - lo : WT_MAX_JOBS;
+        long long blocks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const dmh_wino_wt_job& q = jobs[lo + j];
+            DMH_REQUIRE(q.w && q.U, "null pointer");
+            const int n_out = q.backward ? q.C : q.K, n_in = q.backward ? q.K : q.C;
+            DMH_REQUIRE(q.K > 0 && q.C > 0 && n_in % CK == 0, "the pass's input channel count must be a multiple of 8");
+            b.w[j] = q.w; b.scale[j] = q.scale; b.U[j] = q.U; b.K[j] = q.K; b.C[j] = q.C; b.mode[j] = q.backward ? 1 : 0;
+            b.Kp[j] = (n_out + 63) / 64 * 64;
+            b.first[j] = (int)blocks;
+            blocks += ((long long)b.Kp[j] * n_in + NT - 1) / NT;
+            DMH_REQUIRE(blocks < ((long long)1 << 30), "too many elements in one batch");
+        }
+        b.first[b.n] = (int)blocks;
+        hipLaunchKernelGGL(wino_weight_batch_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, b);
+        if (int rc = check_launch("dmh_wino_weight_transform_batch")) return rc;
+    }
+    return DMH_OK;
 }
 
 static int wino_conv_common(const float* x, const float* U, const float* bias, const float* residual, int relu, bool epi,

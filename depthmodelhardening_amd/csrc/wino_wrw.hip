@@ -68,7 +68,9 @@ struct RArgs {
     int nchunks, nk, nc, S, cps;   // chunks in total; channel blocks; slices per pair; chunks per slice
 };
 
-template <int KS, int CS>
+// IL (round 6): the interleaved form of the chunk loop -- see "interleaved form" below.  Same sums in the same order: the two
+// forms give bit-identical results (tests/test_gpu_conv_anchor.py).
+template <int KS, int CS, bool IL>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_wrw_kernel(RArgs a) {
     using G = Cfg<KS, CS>;
     constexpr int KCH = G::KCH, CCH = G::CCH, NXL = G::NXL, NDL = G::NDL, XRAW = G::XRAW, RAWBUF = G::RAWBUF;
@@ -252,7 +254,208 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const f32x4* const Mw = M_lds + (4 * wv_s) * (2 * KCH) + (lane >> 5) * KCH + (lane & 31);
     const f32x4* const Vw = V_lds + (4 * wv_s) * (2 * CCH) + (lane >> 5) * CCH + (lane & 31);
 
-    if (n > 0) {
+    if (IL && n > 0) {
+        // ---- interleaved form.  The two-phase loop below it leaves the matrix pipe idle while the transforms run (LDS read ->
+        // arithmetic -> LDS write, a chain of latencies that one wave per SIMD cannot cover: 107 of 388 us at layer1's shape,
+        // tools/wrw_ablate.py) because the images are single-buffered and there is no LDS for a second pair (2 x 64 KB).  But an
+        // image word holds FOUR tiles (its components = the 4 k-steps of a chunk), and a k-step only reads its own component:
+        // the chunk is cut in two halves by k-step, J = 0: components .xy (tiles h, h + 2), J = 1: .zw (tiles h + 4, h + 6):
+        //     phase A(g):  MFMAs of chunk g, k-steps 0-1 (read .xy)   beside   transform of chunk g,     tiles of J = 1 (write .zw)
+        //     phase B(g):  MFMAs of chunk g, k-steps 2-3 (read .zw)   beside   transform of chunk g + 1, tiles of J = 0 (write .xy)
+        //                  + raw registers (chunk g + 2) -> raw[g & 1], refill with chunk g + 3
+        // one barrier after each phase (as many as before), every accumulator still receives k-steps 0, 1, 2, 3 of every chunk
+        // in that order.  A transform work item is ONE tile of one channel (4-byte image writes instead of 8-byte ones), the
+        // d-tiles first, then the x-tiles, dealt over the threads; a phase is 8 fenced slots of KS CS MFMAs, the transform's
+        // reads in slot 0, its arithmetic in slots 2-3, its writes in slots 4-7.
+        constexpr int NDT = KCH * 4, NXT = CCH * 4;                 // d- and x-tiles of one half J
+        static_assert(NDT <= NT && NDT % 64 == 0 && NXT % 64 == 0, "tile items are dealt by whole waves");
+        constexpr int NXI = (NXT + NT - 1) / NT;                    // x-tiles per thread and phase (1 or 2)
+        constexpr int XTAIL = NXT % NT;                             // the last round's items go to the UPPER threads (the lower
+                                                                    // ones hold the d-tiles when those do not fill the workgroup)
+        float* const Mf = reinterpret_cast<float*>(M_lds);
+        float* const Vf = reinterpret_cast<float*>(V_lds);
+        const bool has_d = NDT == NT || wv_s * 64 < NDT;            // wave-uniform
+        const int d_ch = tid % KCH, d_q = (tid / KCH) & 3;
+        const int d_off_r = XRAW + d_ch * DCS + 2 * ((d_q & 1) + 2 * (d_q >> 1));           // + 8 J (tile = th + 4 J + 2 s)
+        // the images of this form are [position][h][J][channel] 8-BYTE words (the two tiles of half J a k-step pair reads):
+        // an operand read is one lane-linear ds_read_b64, and the 4-byte writes of 32 consecutive channels fall on 32 different
+        // banks two by two (in the 16-byte words of the other form they met four by four)
+        const int d_off_w = (d_q & 1) * (4 * KCH) + 2 * d_ch + (d_q >> 1);                  // + 2 KCH J
+        int x_off_r[NXI], x_off_w[NXI];
+        bool has_x[NXI];
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            const bool tail = XTAIL != 0 && k == NXI - 1;
+            const int e = tail ? NT * k + tid - (NT - XTAIL) : NT * k + tid;
+            has_x[k] = !tail || wv_s * 64 >= NT - XTAIL;
+            const int ee = has_x[k] ? e : 0, ch = ee % CCH, q = ee / CCH;
+            x_off_r[k] = ch * XCS + coff + 2 * ((q & 1) + 2 * (q >> 1));
+            x_off_w[k] = (q & 1) * (4 * CCH) + 2 * ch + (q >> 1);
+        }
+        float dt[16], xt[NXI][16];                                  // a tile's patch, then its 16 transformed values
+        auto t_read = [&](const int buf, const int J) __attribute__((always_inline)) {
+            if (has_d) {
+                const float* ds = raw + buf * RAWBUF + d_off_r + 8 * J;
+                const float2 r0 = *reinterpret_cast<const float2*>(ds), r1 = *reinterpret_cast<const float2*>(ds + DC);
+                dt[0] = r0.x; dt[1] = r0.y; dt[2] = r1.x; dt[3] = r1.y;
+            }
+#pragma unroll
+            for (int k = 0; k < NXI; ++k)
+                if (has_x[k]) {
+                    const float* xs = raw + buf * RAWBUF + x_off_r[k] + 8 * J;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float* row = xs + i * XC;
+                        xt[k][4 * i] = row[0]; xt[k][4 * i + 1] = row[1]; xt[k][4 * i + 2] = row[2]; xt[k][4 * i + 3] = row[3];
+                    }
+                }
+        };
+        auto t_math_d = [&]() __attribute__((always_inline)) {          // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
+            if (has_d) {
+                const float a0 = dt[0], a1 = dt[1], b0 = dt[2], b1 = dt[3];
+                const float u0[4] = {a0, a0 + b0, a0 - b0, -b0}, u1[4] = {a1, a1 + b1, a1 - b1, -b1};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    dt[4 * i + 0] = u0[i];
+                    dt[4 * i + 1] = u0[i] + u1[i];
+                    dt[4 * i + 2] = u0[i] - u1[i];
+                    dt[4 * i + 3] = -u1[i];
+                }
+            }
+        };
+        auto t_math_x = [&](const int k) __attribute__((always_inline)) {     // V = B^T d B
+            if (has_x[k]) {
+                float q[4][4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    q[0][j] = xt[k][j] - xt[k][8 + j];
+                    q[1][j] = xt[k][4 + j] + xt[k][8 + j];
+                    q[2][j] = xt[k][8 + j] - xt[k][4 + j];
+                    q[3][j] = xt[k][4 + j] - xt[k][12 + j];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    xt[k][4 * i + 0] = q[i][0] - q[i][2];
+                    xt[k][4 * i + 1] = q[i][1] + q[i][2];
+                    xt[k][4 * i + 2] = q[i][2] - q[i][1];
+                    xt[k][4 * i + 3] = q[i][1] - q[i][3];
+                }
+            }
+        };
+        // image writes, 4 bytes each: position pp of the tile -> component s of word [pp][h][J][channel]
+        auto t_write_d = [&](const int J, const int part) __attribute__((always_inline)) {      // positions 8 part .. 8 part + 7
+            if (has_d) {
+                float* md = Mf + d_off_w + 2 * KCH * J;
+#pragma unroll
+                for (int pp = 8 * part; pp < 8 * part + 8; ++pp) md[pp * (8 * KCH)] = dt[pp];
+            }
+        };
+        auto t_write_x = [&](const int J, const int k, const int part) __attribute__((always_inline)) {
+            if (has_x[k]) {
+                float* vd = Vf + x_off_w[k] + 2 * CCH * J;
+#pragma unroll
+                for (int pp = 8 * part; pp < 8 * part + 8; ++pp) vd[pp * (8 * CCH)] = xt[k][pp];
+            }
+        };
+        const float2* const Mw2 = reinterpret_cast<const float2*>(M_lds) + (4 * wv_s) * (4 * KCH) + (lane >> 5) * (2 * KCH) + (lane & 31);
+        const float2* const Vw2 = reinterpret_cast<const float2*>(V_lds) + (4 * wv_s) * (4 * CCH) + (lane >> 5) * (2 * CCH) + (lane & 31);
+        constexpr int NST = NXL + NDL;
+        // one phase: the 8 (position, k-step) MFMA groups of half J on the images, with the transform of (tbuf, tJ) and --
+        // STAGE -- the raw stores / refill loads dealt over its slots
+        auto phase = [&](const int J, const int tbuf, const int tJ, const bool stage, const int sbuf, const int g)
+            __attribute__((always_inline)) {
+            float2 ua[2][KS], vb[2][CS];
+#pragma unroll
+            for (int i = 0; i < KS; ++i) ua[0][i] = Mw2[J * KCH + i * 32];
+#pragma unroll
+            for (int i = 0; i < CS; ++i) vb[0][i] = Vw2[J * CCH + i * 32];
+            const int wrem_st = wrem_held;
+            Chunk cn;
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int sl = q * 2 + ks;
+#pragma unroll
+                    for (int ci = 0; ci < CS; ++ci)
+#pragma unroll
+                        for (int ki = 0; ki < KS; ++ki) {
+                            f32x16& c = acc[(q * CS + ci) * KS + ki];
+                            const float av = ks ? ua[q & 1][ki].y : ua[q & 1][ki].x, bv = ks ? vb[q & 1][ci].y : vb[q & 1][ci].x;
+                            if (!(DMH_WRW_ABLATE & 8)) c = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, c, 0, 0, 0);
+                            else c[ks] += av * bv;
+                        }
+                    if (q + 1 < 4) {                          // operands of the next position, spread over the two k-steps
+#pragma unroll
+                        for (int r = ks; r < KS + CS; r += 2) {
+                            if (r < KS) ua[(q + 1) & 1][r] = Mw2[(q + 1) * (4 * KCH) + J * KCH + r * 32];
+                            else vb[(q + 1) & 1][r - KS] = Vw2[(q + 1) * (4 * CCH) + J * CCH + (r - KS) * 32];
+                        }
+                    }
+                    if (!(DMH_WRW_ABLATE & 2)) {            // the transform of (tbuf, tJ): reads, arithmetic, writes
+                        if (sl == 0) t_read(tbuf, tJ);
+                        if (sl == 2) { t_math_d(); t_math_x(0); }
+                        if (sl == 3 && NXI > 1) t_math_x(1);
+                        if (sl == 3) t_write_d(tJ, 0);
+                        if (sl == 4) t_write_d(tJ, 1);
+                        if (sl == 4) t_write_x(tJ, 0, 0);
+                        if (sl == 5) t_write_x(tJ, 0, 1);
+                        if (sl == 6 && NXI > 1) t_write_x(tJ, 1, 0);
+                        if (sl == 7 && NXI > 1) t_write_x(tJ, 1, 1);
+                    }
+                    if (stage) {
+                        if (sl < 4) {                           // raw registers (chunk g + 2) -> raw[sbuf]
+                            if (!(DMH_WRW_ABLATE & 4)) {
+#pragma unroll
+                                for (int k = sl * NST / 4; k < (sl + 1) * NST / 4; ++k) {
+                                    if (k < NXL) store_x(sbuf, k);
+                                    else store_d(sbuf, k - NXL, wrem_st);
+                                }
+                            }
+                        } else {                                // refill with chunk g + 3
+                            if (sl == 4) cn = chunk_at(c_first + g + 3);
+#pragma unroll
+                            for (int k = (sl - 4) * NST / 4; k < (sl - 3) * NST / 4; ++k) {
+                                if (k < NXL) load_x(cn, k);
+                                else load_d(cn, k - NXL);
+                            }
+                            if (sl == 7) wrem_held = cn.wrem;
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // raw s_barrier + lgkmcnt only: __syncthreads() would also wait for the loads just issued (vmcnt(0))
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (!(DMH_WRW_ABLATE & 16)) __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        };
+        // prologue: chunk 0 -> raw[0]; chunk 1 -> raw[1]; chunk 2 in registers; the J = 0 half of chunk 0's images
+        load_chunk(c_first);
+        store_raw(0);
+        load_chunk(c_first + 1);
+        __syncthreads();
+        t_read(0, 0);
+        t_math_d();
+        t_write_d(0, 0);
+        t_write_d(0, 1);
+#pragma unroll
+        for (int k = 0; k < NXI; ++k) {
+            t_math_x(k);
+            t_write_x(0, k, 0);
+            t_write_x(0, k, 1);
+        }
+        store_raw(1);
+        load_chunk(c_first + 2);
+        __syncthreads();
+        for (int g = 0; g < n; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            phase(0, cur, 1, false, 0, g);          // A: k-steps 0-1 of chunk g      | tiles J = 1 of chunk g     (raw[cur])
+            phase(1, nxt, 0, true, cur, g);         // B: k-steps 2-3 of chunk g      | tiles J = 0 of chunk g + 1 (raw[nxt]); staging
+        }
+    }
+    if (!IL && n > 0) {
         // prologue: chunk 0 -> raw[0] -> images; chunk 1 -> raw[1]; chunk 2 in registers
         load_chunk(c_first);
         store_raw(0);
@@ -405,14 +608,21 @@ void plan(RArgs& a, int kch, int cch) {
     a.cps = (a.nchunks + S - 1) / S;
 }
 
-template <int KS, int CS>
-int launch(const RArgs& a, hipStream_t st) {
+template <int KS, int CS, bool IL>
+int launch_form(const RArgs& a, hipStream_t st) {
     constexpr size_t smem = Cfg<KS, CS>::SMEM;
     static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
-    if (configure_dynamic_lds(wino_wrw_kernel<KS, CS>, smem, configured) != hipSuccess)
+    if (configure_dynamic_lds(wino_wrw_kernel<KS, CS, IL>, smem, configured) != hipSuccess)
         return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_wrw");
-    hipLaunchKernelGGL((wino_wrw_kernel<KS, CS>), dim3((unsigned)(a.nk * a.nc * a.S)), dim3(NT), smem, st, a);
+    hipLaunchKernelGGL((wino_wrw_kernel<KS, CS, IL>), dim3((unsigned)(a.nk * a.nc * a.S)), dim3(NT), smem, st, a);
     return check_launch("dmh_wino_wrw");
+}
+
+template <int KS, int CS>
+int launch(const RArgs& a, hipStream_t st) {
+    // DMH_WRW_FORM=0: the two-phase loop of rounds 3-5 (A/B switch; bit-identical results)
+    static const bool il = !(getenv("DMH_WRW_FORM") && atoi(getenv("DMH_WRW_FORM")) == 0);
+    return il ? launch_form<KS, CS, true>(a, st) : launch_form<KS, CS, false>(a, st);
 }
 
 }  // namespace

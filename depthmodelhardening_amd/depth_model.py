@@ -22,12 +22,12 @@ class DepthModelWrapper(torch.nn.Module):
         return self.decoder(feats)[("disp", 0)]
 
 
-    def masked_sq_mean(self, input_image, mask, plan=None, tab=None, clean=None):
+    def masked_sq_mean(self, input_image, mask, plan=None, tab=None, clean=None, negate=False):
         """mean((disp_0(input_image) * mask)^2): the cost every object attack maximises (phy_obj_atk.py:92-94,
         phy_obj_atk_l0.py:125-127).  With a window plan (roi.RoiPlan + its device table) around the pasted object, and a
         decoder that supports it, the decoder below its first stage and the encoder head's backward run on the windows only;
         with ``clean`` (the same frames without the object: input_image equals it outside the plan's boxes) the encoder
-        head's forward does too."""
+        head's forward does too.  ``negate``: returns -mean(.), what the L_inf attack differentiates (phy_obj_atk.py:95)."""
         from . import ops
         # the decoder's static capability is asked BEFORE the encoder may hand back window-shaped features
         roi_dec = plan is not None and hasattr(self.decoder, "roi_ok") and self.decoder.roi_static_ok(plan)
@@ -39,7 +39,7 @@ class DepthModelWrapper(torch.nn.Module):
         else:
             feats = self.encoder(input_image)
         if roi_dec and self.decoder.roi_ok(feats, plan):
-            return self.decoder.masked_sq_mean(feats, mask, plan, tab)
+            return self.decoder.masked_sq_mean(feats, mask, plan, tab, negate=negate)
         if plan is not None and (plan.head_windowed or plan.f0_compact):
             # the decoder turned the plan down on the features' sizes after all: the whole-frame path serves the call
             plan.head_windowed = plan.f0_compact = False
@@ -48,7 +48,8 @@ class DepthModelWrapper(torch.nn.Module):
             disp = self.decoder(feats, only_scales=(0,))[("disp", 0)]
         else:
             disp = self.decoder(feats)[("disp", 0)]
-        return ops.masked_sq_mean(disp, mask)
+        cost = ops.masked_sq_mean(disp, mask)
+        return -cost if negate else cost
 
 
 def import_depth_model(scene_size, model_type='monodepth2', pre_model_path=None):

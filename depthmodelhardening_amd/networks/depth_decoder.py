@@ -38,6 +38,17 @@ class DepthDecoder(nn.Module):
             return self._forward_fused(input_features, only_scales)
         return self._forward_reference(input_features)
 
+    def _prefetch_filters(self):
+        """The K10 filters of the stages in one launch (ops.wino_prefetch): once per ops.frozen_weights() scope inside an
+        attack, once per forward otherwise; forward and -- when a backward can follow -- backward-data forms."""
+        from .. import ops
+        dirs = (False, True) if torch.is_grad_enabled() else (False,)
+        jobs = [(blk.conv.conv.weight, bw, None) for key, blk in self.convs.items() if key[0] == "upconv" for bw in dirs]
+        if ops.weights_frozen():
+            ops.frozen_memo(("prefetch", id(self)), lambda: ops.wino_prefetch(jobs) or True)
+        else:
+            ops.wino_prefetch(jobs)
+
     def _forward_fused(self, input_features, only_scales=None):
         """Same arithmetic as the reference forward, with the element-wise passes between the convolutions fused
         into the HIP glue kernels (ops.up_cat_pad / ops.elu_pad) and the convolutions run un-padded on pre-padded
@@ -50,6 +61,7 @@ class DepthDecoder(nn.Module):
             return ops.conv3x3(t, c.weight, c.bias, 0)
 
         self.outputs = {}
+        self._prefetch_filters()
         p = ops.elu_pad(input_features[-1], apply_elu=False)
         for i in range(4, -1, -1):
             y = conv(self.convs[("upconv", i, 0)].conv, p)
@@ -93,12 +105,12 @@ class DepthDecoder(nn.Module):
             out.append(c[("upconv", i, 1)].conv.conv)
         return out + [c[("dispconv", 0)].conv]
 
-    def masked_sq_mean(self, input_features, mask, plan, tab):
+    def masked_sq_mean(self, input_features, mask, plan, tab, negate=False):
         """mean((disp_0 * mask)^2) -- the attack's cost (phy_obj_atk.py:92-94) -- with the decoder below stage
         (plan.depth, 0) evaluated on the windows of ``plan`` only (roi.RoiPlan around the pasted object, where the mask
         lives): the stages above run on the whole maps, upconv(depth,1) ... dispconv(0) inside the windows.  Exact, not an
         approximation: the mask is zero outside the plan's boxes, so nothing outside the windows' receptive field reaches
-        the cost."""
+        the cost.  ``negate``: returns minus the mean (the attacks' `cost = -loss`), signed inside the cost kernel."""
         from .. import ops
 
         def conv(block, t):
@@ -106,13 +118,14 @@ class DepthDecoder(nn.Module):
             return ops.conv3x3(t, c.weight, c.bias, 0)
 
         depth = plan.depth
+        self._prefetch_filters()
         p = ops.elu_pad(input_features[-1], apply_elu=False)
         for i in range(4, depth, -1):
             y = conv(self.convs[("upconv", i, 0)].conv, p)
             p = ops.up_cat_pad(y, input_features[i - 1])
             p = ops.elu_pad(conv(self.convs[("upconv", i, 1)].conv, p))
         y_top = conv(self.convs[("upconv", depth, 0)].conv, p)
-        return ops.roi_tail_cost(y_top, input_features[:depth], mask, plan, tab, self._tail_convs(depth))
+        return ops.roi_tail_cost(y_top, input_features[:depth], mask, plan, tab, self._tail_convs(depth), negate=negate)
 
     def _forward_reference(self, input_features):
         self.outputs = {}

@@ -239,6 +239,30 @@ class ResnetEncoder(nn.Module):
         if num_layers > 34:
             self.num_ch_enc[1:] *= 4
 
+    def _k10_convs(self):
+        """[(conv, bn)] of the 3x3 stride-1 convolutions of the residual blocks: the filters K10 may be asked for."""
+        if getattr(self, "_k10_list", None) is None:
+            out = []
+            for layer in (self.encoder.layer1, self.encoder.layer2, self.encoder.layer3, self.encoder.layer4):
+                for blk in layer:
+                    for conv, bn in ((getattr(blk, "conv1", None), getattr(blk, "bn1", None)),
+                                     (getattr(blk, "conv2", None), getattr(blk, "bn2", None))):
+                        if conv is not None and conv.kernel_size == (3, 3) and _plain3x3(conv):
+                            out.append((conv, bn))
+            self._k10_list = out
+        return self._k10_list
+
+    def _prefetch_filters(self, aff=None):
+        """All K10 filters of this encoder in one launch (ops.wino_prefetch): with ``aff`` (an attack: inside
+        ops.frozen_weights(), once per scope) the forms with the eval-mode BatchNorm scale folded in, otherwise (the train pass,
+        every forward) the plain forms; forward and -- when a backward can follow -- backward-data."""
+        dirs = (False, True) if torch.is_grad_enabled() else (False,)
+        if aff is not None:
+            ops.frozen_memo(("prefetch", id(self)), lambda: ops.wino_prefetch(
+                [(c.weight, bw, aff[bn][0]) for c, bn in self._k10_convs() for bw in dirs]) or True)
+        else:
+            ops.wino_prefetch([(c.weight, bw, None) for c, _ in self._k10_convs() for bw in dirs], fresh=True)
+
     def _stem(self, input_image):
         """conv1((input_image - 0.45) / 0.225): one K14 launch for the standard first layer on the GPU, the reference's
         two steps otherwise."""
@@ -260,6 +284,8 @@ class ResnetEncoder(nn.Module):
         if e.fused_eval_ok(input_image):
             self.features = self._forward_fused_eval(input_image, roi, clean)
             return self.features
+        if input_image.is_cuda and input_image.dtype == torch.float32 and e.bn1.training:
+            self._prefetch_filters()
         z = self._stem(input_image)
         if _train_fused(e.bn1, z) and z.shape[2] % 2 == 0 and z.shape[3] % 2 == 0:
             f0, p = ops.stem_bn_relu_pool_train(e.bn1, z)
@@ -303,6 +329,8 @@ class ResnetEncoder(nn.Module):
     def _forward_fused_eval(self, input_image, roi=None, clean=None):
         e = self.encoder
         aff = e.eval_affine()
+        if ops.weights_frozen():
+            self._prefetch_filters(aff)
         layers = (e.layer1, e.layer2, e.layer3, e.layer4)
         feats = None
         if roi is not None:

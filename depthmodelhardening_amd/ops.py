@@ -705,13 +705,15 @@ def _bn_train_stats(x, bn):
     if bn.momentum is None:
         raise RuntimeError("bn_act_train: cumulative-average BatchNorm (momentum=None) is not supported")
     track = bn.track_running_stats and bn.running_mean is not None
-    N.check(_timed("bn_train_stats", lambda: lib.dmh_bn_train_stats(
+    nbt = bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None
+    if nbt is not None and not (nbt.is_cuda and nbt.dtype == torch.int64 and nbt.numel() == 1):
+        raise RuntimeError("bn_act_train: num_batches_tracked must be a CUDA int64 scalar")
+    N.check(_timed("bn_train_stats", lambda: lib.dmh_bn_train_stats_tracked(
         N.ptr(x), B, Cc, HW, N.ptr(None if bn.weight is None else _c(bn.weight.detach())),
         N.ptr(None if bn.bias is None else _c(bn.bias.detach())), float(bn.momentum), float(bn.eps),
-        N.ptr(bn.running_mean if track else None), N.ptr(bn.running_var if track else None), N.ptr(part), N.ptr(scale),
+        N.ptr(bn.running_mean if track else None), N.ptr(bn.running_var if track else None),
+        None if nbt is None else C.c_void_p(nbt.data_ptr()), N.ptr(part), N.ptr(scale),
         N.ptr(shift), N.ptr(mean), N.ptr(invstd), N.stream()), 4 * x.numel()))
-    if track and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
     return scale, shift, mean, invstd
 
 
@@ -954,6 +956,10 @@ def _wino_filter(weight, backward, scale=None):
     key = (weight.data_ptr(), weight._version, bool(backward), None if scale is None else scale.data_ptr())
     if _wino_frozen and key in _wino_cache:
         return _wino_cache[key]
+    if scale is None and not _wino_frozen:
+        ready = _wino_ready.get((key[0], key[2]))      # transformed ahead of its use by wino_prefetch()
+        if ready is not None and ready[0] == key[1] and ready[1].device == weight.device:
+            return ready[1]
     n_out, n_in = (Cc, K) if backward else (K, Cc)
     U = torch.empty(lib.dmh_wino_weight_size(n_out, n_in), device=weight.device, dtype=torch.float32)
     N.check(lib.dmh_wino_weight_transform_scaled(N.ptr(_c(weight.detach())), K, Cc, int(backward), N.ptr(scale), N.ptr(U),
@@ -961,6 +967,57 @@ def _wino_filter(weight, backward, scale=None):
     if _wino_frozen:
         _wino_cache[key] = U
     return U
+
+
+WINO_PREFETCH = os.environ.get("DMH_WINO_PREFETCH", "1") != "0"     # A/B switch: 0 = every filter transformed at its first use
+_wino_ready = {}        # (weight pointer, backward) -> (weight version, U, weight): the filters of ONE pass outside a
+                        # frozen_weights() scope (the train pass: forward forms now, backward-data forms for its backward); an
+                        # entry keeps its weight tensor alive, so the pointer cannot come to name another tensor's data
+
+
+def wino_prefetch(jobs, fresh=False):
+    """Transform many K10 filters in ONE launch (dmh_wino_weight_transform_batch) ahead of their use: ``jobs`` = iterable of
+    (weight [K, C, 3, 3], backward, scale or None) -- what _wino_filter() will be asked for.  A step needs every filter in its
+    forward and its backward-data form, for the attack's frozen weights (BatchNorm scale folded in) and again for the train
+    pass: 76 launches of 5-20 us when each is made at its first use.  Forms the kernel does not take (input channels of the pass
+    not a multiple of 8) are skipped; whatever is not prefetched is still transformed on demand.  Inside frozen_weights() the
+    results join that scope's cache (scaled forms included); outside it only unscaled forms are taken, into a table that the
+    first prefetch of the next pass (``fresh``: the encoder's) empties.  Returns the number of filters transformed."""
+    if not (WINO_ENABLED and WINO_PREFETCH):
+        return 0
+    lib = N.lib()
+    todo, keep = [], []
+    if fresh and not _wino_frozen:
+        _wino_ready.clear()
+    for weight, backward, scale in jobs:
+        if not (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+            continue
+        K, Cc = weight.shape[0], weight.shape[1]
+        n_out, n_in = (Cc, K) if backward else (K, Cc)
+        if n_in % 8 or n_in < 24 or n_out < 64:        # not a K10 shape in this direction (ops._wino_ok)
+            continue
+        if scale is not None and not _wino_frozen:     # a scale is a temporary: only a frozen scope's cache may key on it
+            continue
+        sc = None if scale is None else _c(scale.detach())
+        key = (weight.data_ptr(), weight._version, bool(backward), None if sc is None else sc.data_ptr())
+        if _wino_frozen and key in _wino_cache:
+            continue
+        # (outside a frozen scope a job is always done: an entry of an earlier call may predate a change of the weight that
+        #  did not bump its version counter -- p.data.copy_(...))
+        U = torch.empty(lib.dmh_wino_weight_size(n_out, n_in), device=weight.device, dtype=torch.float32)
+        w = _c(weight.detach())
+        keep.append((w, sc))
+        todo.append((N.ptr(w), N.ptr(sc), N.ptr(U), K, Cc, int(bool(backward))))
+        if _wino_frozen:
+            _wino_cache[key] = U
+        else:
+            _wino_ready[(key[0], key[2])] = (key[1], U, weight)
+    if todo:
+        arr = (N.WinoWtJob * len(todo))()
+        for j, (w, sc, U, K, Cc, bw) in enumerate(todo):
+            arr[j].w, arr[j].scale, arr[j].U, arr[j].K, arr[j].C, arr[j].backward = w, sc, U, K, Cc, bw
+        N.check(lib.dmh_wino_weight_transform_batch(arr, len(todo), N.stream()))
+    return len(todo)
 
 
 WINO_SK = os.environ.get("DMH_WINO_SK", "1") != "0"       # A/B switch: stream-K decomposition of the plain K10 launches
@@ -1786,6 +1843,7 @@ class _RoiTail(torch.autograd.Function):
     def forward(ctx, plan, depth, x_top, *rest):
         lib = N.lib()
         dev = x_top.device
+        depth, sign = (depth if isinstance(depth, tuple) else (depth, 1.0))       # (depth, -1.0): the negated cost
         feats, mask, tab = rest[:depth], rest[depth], rest[depth + 1]
         wb = rest[depth + 2:]
         chain = _roi_chain(depth)
@@ -1808,10 +1866,10 @@ class _RoiTail(torch.autograd.Function):
         sig = torch.empty_like(d_pre)
         part = torch.empty(lib.dmh_roi_cost_partials_size(B, hd, wd_), device=dev, dtype=torch.float32)
         cost = torch.empty((), device=dev, dtype=torch.float32)
-        N.check(lib.dmh_roi_cost_fwd(N.ptr(d_pre), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, H0, W0, N.ptr(sig),
-                                     N.ptr(part), N.ptr(cost), N.stream()))
+        N.check(lib.dmh_roi_cost_fwd_scaled(N.ptr(d_pre), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, H0, W0, sign, N.ptr(sig),
+                                            N.ptr(part), N.ptr(cost), N.stream()))
         ctx.save_for_backward(x_top, mask, tab, sig, *feats, *outs, *wb[0::2])
-        ctx.plan, ctx.depth, ctx.f0c = plan, depth, f0c
+        ctx.plan, ctx.depth, ctx.f0c, ctx.sign = plan, depth, f0c, sign
         return cost
 
     @staticmethod
@@ -1830,8 +1888,8 @@ class _RoiTail(torch.autograd.Function):
         sz = plan.size
         hd, wd_ = sz["d"]
         g_cur = torch.empty_like(sig)
-        N.check(lib.dmh_roi_cost_bwd(N.ptr(sig), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, H0, W0,
-                                     N.ptr(_c(g.to(torch.float32))), N.ptr(g_cur), N.stream()))
+        N.check(lib.dmh_roi_cost_bwd_scaled(N.ptr(sig), N.ptr(mask), N.ptr(org["d"]), B, hd, wd_, H0, W0, ctx.sign,
+                                            N.ptr(_c(g.to(torch.float32))), N.ptr(g_cur), N.stream()))
         g_feats = [None] * depth
         for k in range(n - 1, -1, -1):
             name, lvl, up, skip = chain[k]
@@ -1865,12 +1923,13 @@ def roi_tail_ok(x_top, feats, convs, depth):
             and x_top.shape[2] >= 2 and x_top.shape[3] >= 2)
 
 
-def roi_tail_cost(x_top, feats, mask, plan, tab, convs):
+def roi_tail_cost(x_top, feats, mask, plan, tab, convs, negate=False):
     """mean((sigmoid(dispconv0(...)) * mask)^2) of the decoder tail on the windows of ``plan`` (roi.RoiPlan; ``tab`` is
     its origin table on the device, int32 [len(roi.TABLE), B, 2]).  ``x_top``: upconv(depth,0)'s whole-frame output (before
     its ELU), depth = plan.depth; ``feats``: encoder features 0 .. depth-1; ``convs``: the nn.Conv2d modules of upconv(depth,1)
     ... upconv(0,1), dispconv(0) in execution order.  Equals ops.masked_sq_mean(decoder(...)[("disp", 0)], mask) when the
-    mask is zero outside the plan's boxes."""
+    mask is zero outside the plan's boxes; ``negate``: minus that (what an attack hands to autograd), the sign applied inside
+    the cost kernels."""
     depth = plan.depth
     feats = tuple(feats)
     if not roi_tail_ok(x_top, feats, convs, depth):
@@ -1880,7 +1939,7 @@ def roi_tail_cost(x_top, feats, mask, plan, tab, convs):
     wb = []
     for c in convs:
         wb += [c.weight.detach(), None if c.bias is None else _c(c.bias.detach())]
-    return _RoiTail.apply(plan, depth, _c(x_top), *[_c(f) for f in feats], _c(mask), _c(tab), *wb)
+    return _RoiTail.apply(plan, (depth, -1.0) if negate else depth, _c(x_top), *[_c(f) for f in feats], _c(mask), _c(tab), *wb)
 
 
 def _roi_crop(src, gate, g, org, size):

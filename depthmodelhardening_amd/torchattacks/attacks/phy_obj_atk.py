@@ -64,6 +64,7 @@ class Phy_obj_atk(Attack):
         self.use_graph = False
         self.common_windows = False     # the common-size window plans without the graph (tests: the eager twin of use_graph)
         self._graph_pool = None
+        self._model_negates = None      # does model.masked_sq_mean take negate=...?  (asked once)
         self._capture_fault = False     # test hook: make the capture of _graph_steps fail after its first launch
         self.graph_failure = None       # why use_graph switched itself off (a failed capture), else None
         self._graph = None      # (graph of the previous attack, event behind its last replay): destroyed once it has run
@@ -78,6 +79,19 @@ class Phy_obj_atk(Attack):
                                            dist_range=dist_range)
         self.phy_trans_ben = PhysicalTrans(self.obj_img, self.obj_mask, conf, (1, 3, ori_H, ori_W),
                                            dist_range=dist_range)
+
+    def _neg_cost(self, adv, m, plan, tab, clean):
+        """-mean((disp * mask)^2) on the plan's windows (phy_obj_atk.py:94-95); a model whose masked_sq_mean takes ``negate``
+        applies the sign inside its cost kernel (no element-wise launch for it, forward or backward)."""
+        if self._model_negates is None:
+            import inspect
+            try:
+                self._model_negates = "negate" in inspect.signature(self.model.masked_sq_mean).parameters
+            except (TypeError, ValueError):
+                self._model_negates = False
+        if self._model_negates:
+            return self.model.masked_sq_mean(adv, m, plan, tab, clean, negate=True)
+        return -self.model.masked_sq_mean(adv, m, plan, tab, clean)
 
     def _draw(self, batch_size, explicit=False):
         """One set of (z0, alpha) for ``batch_size`` scenes in the reference's RNG order: project()'s draw
@@ -178,7 +192,7 @@ class Phy_obj_atk(Attack):
             adv_scenes, obj_masks_out = ops.eot_paste(scene_imgs, obj_img_adv, mask, coeffs[s], l_pad, t_pad,
                                                       self.scene_size)
             if plans is not None:
-                cost = -self.model.masked_sq_mean(adv_scenes, obj_masks_out, plans[s], tabs[s], clean)
+                cost = self._neg_cost(adv_scenes, obj_masks_out, plans[s], tabs[s], clean)
             else:
                 adv_depth = self.model(adv_scenes)
                 cost = -ops.masked_sq_mean(adv_depth, obj_masks_out)  # -MSE(adv_depth * mask, 0)
@@ -215,7 +229,7 @@ class Phy_obj_atk(Attack):
         def step():
             p = patch_in.detach().requires_grad_(True)
             adv, m = ops.eot_paste(scene_imgs, p, mask, coeff_cur, l_pad, t_pad, self.scene_size)
-            cost = -self.model.masked_sq_mean(adv, m, plan, tab_cur, clean)
+            cost = self._neg_cost(adv, m, plan, tab_cur, clean)
             (grad,) = torch.autograd.grad(cost, p)
             ops.pgd_linf_step(p, self.obj_img, grad, self.alpha, self.eps, out=patch_out)
             patch_in.copy_(patch_out)

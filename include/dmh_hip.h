@@ -356,6 +356,13 @@ int dmh_roi_cost_fwd(const float* d_pre, const float* mask, const int* org, int 
                      float* partials, float* cost, void* stream);
 int dmh_roi_cost_bwd(const float* sig, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
                      const float* gscale, float* g_pre, void* stream);
+/* scale = +1 or -1: the attacks MAXIMISE the cost, i.e. hand autograd -mean(.) (phy_obj_atk.py:95 `cost = -loss(...)`); with
+ * scale = -1 the sign is applied here (bit-identical to negating the result and the incoming gradient: two element-wise
+ * launches per attack step less). */
+int dmh_roi_cost_fwd_scaled(const float* d_pre, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
+                            float scale, float* sig, float* partials, float* cost, void* stream);
+int dmh_roi_cost_bwd_scaled(const float* sig, const float* mask, const int* org, int B, int hd, int wd, int H, int W,
+                            float scale, const float* gscale, float* g_pre, void* stream);
 
 /* K19, encoder side: the backward of conv1 / bn1 / relu / maxpool and layer1 (torchvision ResNet under
  * MD2/networks/resnet_encoder.py:85-98) on one window per scene -- the patch gradient reads d cost / d image under the pasted
@@ -406,6 +413,12 @@ int64_t dmh_bn_stats_partials_size(int B, int C, int HW);
 int dmh_bn_train_stats(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
                        float eps, float* running_mean, float* running_var, float* partials, float* scale, float* shift,
                        float* save_mean, float* save_invstd, void* stream);
+/* The same, and num_batches_tracked[0] += 1 (the module's int64 counter, nn.BatchNorm2d.forward in train mode; may be NULL) in
+ * the second launch instead of one more element-wise launch per BatchNorm (20 per train pass of the ResNet-18 encoder). */
+int dmh_bn_train_stats_tracked(const float* x, int B, int C, int HW, const float* weight, const float* bias, float momentum,
+                               float eps, float* running_mean, float* running_var, long long* num_batches_tracked,
+                               float* partials, float* scale, float* shift, float* save_mean, float* save_invstd,
+                               void* stream);
 /* out[c] = sum over (b, hw) of g[b][c][hw]: the bias gradient of a convolution (aten::convolution_backward's third
  * output, aten::sum(g, (0, 2, 3))).  Two launches, fixed order.  partials: dmh_channel_sum_partials_size(B, C, HW) floats. */
 int64_t dmh_channel_sum_partials_size(int B, int C, int HW);
@@ -462,6 +475,17 @@ int dmh_wino_weight_transform_scaled(const float* w, int K, int C, int backward,
                                      void* stream);
 int dmh_wino_conv3x3_act(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,
                          int K, int H, int W, int pad, float* y, void* stream);
+/* Many filters in one launch: jobs[i] = one dmh_wino_weight_transform_scaled call (scale may be NULL); `jobs` is a HOST array,
+ * read before the call returns (its entries travel in the kernel arguments, 32 per launch).  A training step re-transforms
+ * every filter twice (forward and backward-data form, once for the attack's frozen weights and once for the train pass): ~76
+ * launches of 5-20 us otherwise. */
+typedef struct dmh_wino_wt_job {
+    const float* w;         /* [K][C][3][3] */
+    const float* scale;     /* per-channel factor of the forward OUTPUT (eval-mode BatchNorm), or NULL */
+    float* U;               /* dmh_wino_weight_size(n_out, n_in) floats */
+    int K, C, backward;
+} dmh_wino_wt_job;
+int dmh_wino_weight_transform_batch(const dmh_wino_wt_job* jobs, int n, void* stream);
 /* The same with a caller-owned stream-K workspace (see dmh_wino_conv3x3_ws).  With the fused epilogue only launches of fewer
  * than 200 tile regions are decomposed (layer4 at the attack batch: 120); the second kernel applies shift / residual / ReLU. */
 int dmh_wino_conv3x3_act_ws(const float* x, const float* U, const float* bias, const float* residual, int relu, int B, int C,

@@ -12,11 +12,7 @@ GOLDEN = os.path.join(REPO, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    # under pytest-xdist every worker is a process of its own: share the host cores instead of each taking all of them
-    workers = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "0") or 0)
-    if workers > 1 and os.environ.get("PYTEST_XDIST_WORKER"):
-        import torch
-        torch.set_num_threads(max(1, (os.cpu_count() or workers) // workers))
+    config.addinivalue_line("markers", "xdist_group(name): pytest-xdist --dist loadgroup (registered here for serial runs)")
 
 
 @pytest.fixture(scope="session")

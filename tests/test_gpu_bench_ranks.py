@@ -58,9 +58,9 @@ def test_two_ranks_on_one_gpu(shared):
 
 def test_a_rank_that_stops_fails_the_job_within_the_shortened_timeout():
     """Rank 1 stops taking part after the warm-up: rank 0 sits in the next step's gradient all-reduce until the process group's
-    steady-state timeout (DMH_DIST_STEADY_TIMEOUT_MIN, here 0.2 min) fails it; the launcher then stops rank 1 and exits
+    steady-state timeout (DMH_DIST_STEADY_TIMEOUT_MIN, here 0.1 min) fails it; the launcher then stops rank 1 and exits
     non-zero -- minutes earlier than the 60-minute start-up timeout would."""
-    r, took = _bench(env={"DMH_BENCH_AFTER_WARMUP": "hang:1", "DMH_DIST_STEADY_TIMEOUT_MIN": "0.2"}, timeout=420)
+    r, took = _bench(env={"DMH_BENCH_AFTER_WARMUP": "hang:1", "DMH_DIST_STEADY_TIMEOUT_MIN": "0.1"}, timeout=420)
     assert r.returncode != 0, (r.stdout[-2000:], r.stderr[-4000:])
     assert "stopping the other ranks" in r.stderr
     assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

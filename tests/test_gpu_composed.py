@@ -41,8 +41,8 @@ def _watch_windows(model):
     seen = []
     inner = model.masked_sq_mean
 
-    def wrapped(img, mask, plan=None, tab=None, clean=None):
-        out = inner(img, mask, plan, tab, clean)
+    def wrapped(img, mask, plan=None, tab=None, clean=None, negate=False):
+        out = inner(img, mask, plan, tab, clean, negate=negate)
         seen.append(None if plan is None else (bool(plan.head_windowed), bool(plan.f0_compact)))
         return out
     model.masked_sq_mean = wrapped
@@ -239,7 +239,8 @@ def _trainer(tmp_path, H, W, extra=()):
     from depthmodelhardening_amd.trainer import Trainer
     argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", str(H), "--width", str(W),
             "--batch_size", "2", "--weights_init", "scratch", "--log_dir", str(tmp_path), "--model_name", "t",
-            "--synthetic_len", "8", "--atk_steps", "1", "--atk_batch_size", "2", "--adv_train", "--no_flip_sides"] + list(extra)
+            "--synthetic_len", "8", "--atk_steps", "1", "--atk_batch_size", "2", "--adv_train", "--norm_type", "l_inf",
+            "--no_flip_sides"] + list(extra)
     torch.manual_seed(3)
     return Trainer(MonodepthOptions().parse(argv), device=torch.device("cuda"))
 

@@ -31,7 +31,8 @@ def _worker(rank, world, port, tmp, sync_attack, ret):
     torch.manual_seed(100 + rank)                      # different initial weights per rank: broadcast must fix it
     argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "64", "--width", "192",
             "--batch_size", "2", "--weights_init", "scratch", "--log_dir", os.path.join(tmp, "r%d" % rank),
-            "--model_name", "t", "--synthetic_len", "8", "--adv_train", "--atk_steps", "1", "--atk_batch_size", "2"]
+            "--model_name", "t", "--synthetic_len", "8", "--adv_train", "--norm_type", "l_inf", "--atk_steps", "1", "--atk_batch_size",
+            "2"]
     if sync_attack:
         argv.append("--sync_attack")
     tr = Trainer(MonodepthOptions().parse(argv), rank=r, world_size=w, device=dev)

@@ -66,11 +66,11 @@ def _pool_seeds(B, H, W, seed):
 
 
 @pytest.mark.parametrize("variant", ["md2", "dh"])
-@pytest.mark.parametrize("shape", [(8, 32, 96, 21), (2, 192, 640, 22), (5, 48, 80, 5), (3, 64, 200, 9)])
+@pytest.mark.parametrize("shape", [(16, 32, 96, 21), (2, 192, 640, 22), (12, 48, 80, 5), (6, 64, 200, 9)])
 @pytest.mark.parametrize("with_noise", [False, True])
 def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
-    # (the two small image sizes run at batch 8 / 5: the pooled pixel count is what decides the gradient bound, and a seed
-    # costs two oracle passes whose time at these sizes is all per-call overhead; batch 2 / 1 at those sizes: the goldens)
+    # (the three small image sizes run at batch 16 / 12 / 6: the pooled pixel count is what decides the gradient bound, and a
+    # seed costs two oracle passes whose time at these sizes is all per-call overhead; batch 2 at such sizes: the goldens)
     if not with_noise and shape[1:3] in ((48, 80), (64, 200)):
         pytest.skip("the noise-free form is covered at two shapes; with the tie-break noise at all four (suite time)")
     N, ops, loss_ref, _, synth, _ = _mods()
@@ -216,10 +216,10 @@ def test_photo_loss_two_frames_and_options():
     """Two source frames (min over frames) with a general pose (rotation + translation, different per sample) for the
     second one; then --no_ssim, --disable_automasking.  Gradients pooled over seeds against the fp64 oracle."""
     N, ops, loss_ref, _, synth, _ = _mods()
-    B, H, W = 2, 40, 136
+    B, H, W = 6, 40, 136                # (6 images x 4 seeds: the pixel count of the 2 x 12 it replaces, a third of the oracle calls)
     fids = (0, -1, "s")
     pool = GradPool()
-    for seed in (77, 177, 277, 377, 477, 577, 677, 777, 877, 977, 1077, 1177):
+    for seed in (77, 177, 277, 377):
         inputs, disps = synth.make_loss_case(B, H, W, seed)
         g = torch.Generator().manual_seed(seed + 1)
         inputs[("color", -1, 0)] = (0.8 * torch.roll(inputs[("color", 0, 0)], -2, 3) +

@@ -110,7 +110,8 @@ def _trainer_worker(rank, world, port, tmp, ret):
     random.seed(100 + rank)
     argv = ["--dataset", "synthetic", "--frame_ids", "0", "--use_stereo", "--height", "64", "--width", "192",
             "--batch_size", "2", "--weights_init", "scratch", "--log_dir", os.path.join(tmp, "r%d" % rank),
-            "--model_name", "t", "--synthetic_len", "8", "--adv_train", "--atk_steps", "2", "--atk_batch_size", "3",
+            "--model_name", "t", "--synthetic_len", "8", "--adv_train", "--norm_type", "l_inf", "--atk_steps", "2",
+            "--atk_batch_size", "3",
             "--shared_patch", "--sync_attack"]
     tr = Trainer(MonodepthOptions().parse(argv), rank=r, world_size=w, device=dev)
     tr.set_train()

@@ -116,3 +116,18 @@ class GradPool(object):
             assert self.bad_h_on_ok[s] <= max(1e-3 * self.ok_r[s], 1.0) + self.bad_r[s], (
                 "%s scale %d: HIP beyond 1e-4 on %d of the %d elements where the fp32 reference is within 1e-4 of fp64" % (
                     name, s, self.bad_h_on_ok[s], self.ok_r[s]))
+
+
+def no_miopen(fn):
+    """Decorator for tests whose only library convolutions belong to the SCAFFOLDING network (oracle.synth.TinyDepthNet through
+    nn.Conv2d): run them on ATen's own GPU convolution.  On a fresh box MIOpen compiles a kernel per new (shape, direction) --
+    3-5 s each, 45 s for the fifteen configurations of one harness test -- for arithmetic no assertion is about."""
+    import functools
+
+    import torch
+
+    @functools.wraps(fn)
+    def wrapped(*a, **kw):
+        with torch.backends.cudnn.flags(enabled=False):
+            return fn(*a, **kw)
+    return wrapped

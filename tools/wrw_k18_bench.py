@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""K18 (Winograd-domain weight gradient) vs MIOpen at the train-pass shapes (batch 32):  python3 tools/wrw_k18_bench.py [B=32]"""
+"""K18 (Winograd-domain weight gradient) vs MIOpen at the train-pass shapes (batch 32):  python3 tools/wrw_k18_bench.py [B=32]
+[nomiopen].  Prints a checksum of the result's bits per shape: DMH_WRW_FORM=0 (the two-phase loop) and the default (the
+interleaved loop) must print the same ones."""
 import sys
 
 import torch
@@ -8,6 +10,7 @@ sys.path.insert(0, ".")
 from depthmodelhardening_amd import _native as N  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+MIOPEN = "nomiopen" not in sys.argv
 dev = torch.device("cuda")
 lib = N.lib()
 torch.backends.cudnn.benchmark = False
@@ -41,12 +44,13 @@ for C, K, Ho, Wo, pad, name in SHAPES:
     ref = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1, [False, True, False])[1]
     N.check(lib.dmh_wino_wrw(N.ptr(x), N.ptr(gy), B, C, K, H, W, pad, N.ptr(ws), N.ptr(dw), N.stream()))
     err = float((dw - ref).abs().max() / ref.abs().max())
+    bits = int(dw.view(torch.int32).to(torch.int64).sum())
     t_m = timeit(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [pad, pad], [1, 1], False, [0, 0], 1,
-                                                             [False, True, False]))
+                                                             [False, True, False])) if MIOPEN else float("nan")
     t_k = timeit(lambda: N.check(lib.dmh_wino_wrw(N.ptr(x), N.ptr(gy), B, C, K, H, W, pad, N.ptr(ws), N.ptr(dw), N.stream())))
     fl = 2.0 * 9 * B * K * C * Ho * Wo
     tot_m += t_m
     tot_k += t_k
     print("%-10s C%4d K%4d %3dx%-4d | miopen (with transposes) %7.1f us (%5.1f TF/s) | K18 %7.1f us (%5.1f TF/s direct-equivalent) | "
-          "rel err %.1e" % (name, C, K, Ho, Wo, t_m, fl / t_m / 1e6, t_k, fl / t_k / 1e6, err), flush=True)
+          "rel err %.1e | bits %d" % (name, C, K, Ho, Wo, t_m, fl / t_m / 1e6, t_k, fl / t_k / 1e6, err, bits), flush=True)
 print("sum: miopen %.0f us, K18 %.0f us" % (tot_m, tot_k))
