@@ -1795,6 +1795,13 @@ def _roi_glue_bwd(a, g_out, device, want_skip, y_region=None, skip_region=None, 
     """``y_region`` / ``skip_region`` = (org table [B,2], (rows, cols)): for a whole-frame source only that rectangle is
     computed; the rest of g_y is zero-filled, and so is the rest of g_skip unless ``skip_prezero`` is False (its consumer
     reads inside the rectangle only)."""
+    # A rectangle needs the rest of its plane zero-filled first (one more launch, and every byte of the plane written once more):
+    # where the plane is less than three times the rectangle the kernel takes the WHOLE plane instead and writes the zeros of
+    # the elements no window entry reads itself (round 6: upconv(depth,0)'s output and encoder feature 3 at the attack's sizes)
+    if y_region is not None and a.sh * a.sw < 3 * y_region[1][0] * y_region[1][1]:
+        y_region = None
+    if skip_region is not None and skip_prezero and a.kh * a.kw < 3 * skip_region[1][0] * skip_region[1][1]:
+        skip_region = None
     new = torch.zeros if y_region is not None else torch.empty
     g_y = new((a.B, a.C1, a.sh, a.sw), device=device, dtype=torch.float32)
     g_skip = None

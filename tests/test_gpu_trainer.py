@@ -1378,23 +1378,29 @@ def test_wino_prefetch_equals_on_demand_transforms():
     assert not ops._wino_cache
     # the train pass: gradients with the prefetch equal those without it, bit for bit
     enc.train()
-    x = torch.rand(2, 3, 64, 192, device=dev)
+    x = torch.rand(4, 3, 192, 640, device=dev)      # (large enough for K10 to take the encoder's and the decoder's convolutions)
 
     def grads():
         for p in list(enc.parameters()) + list(dec.parameters()):
             p.grad = None
         out = dec(enc(x))
         sum(o.mean() for o in out.values()).backward()
-        return [p.grad.clone() for p in list(enc.parameters()) + list(dec.parameters()) if p.grad is not None]
+        return ([out[("disp", k)].detach().clone() for k in range(4)],
+                [p.grad.clone() for p in list(enc.parameters()) + list(dec.parameters()) if p.grad is not None])
     torch.manual_seed(0)
-    a = grads()
+    ya, a = grads()
     assert ops._wino_ready and all(k[1] in (False, True) and len(k) == 2 for k in ops._wino_ready)
     saved = ops.WINO_PREFETCH
     try:
         ops.WINO_PREFETCH = False
         ops._wino_ready.clear()
-        b = grads()
+        yb, b = grads()
         assert not ops._wino_ready
     finally:
         ops.WINO_PREFETCH = saved
-    assert len(a) == len(b) and all(torch.equal(u, v) for u, v in zip(a, b))
+    # forward: the same bits.  Gradients: at this small shape some weight gradients are MIOpen's (atomics: the last bits differ
+    # from run to run with or without the prefetch), so they are compared to 1e-5 of their scale
+    assert all(torch.equal(u, v) for u, v in zip(ya, yb))
+    assert len(a) == len(b)
+    for u, v in zip(a, b):
+        assert float((u - v).abs().max()) <= 1e-5 * float(v.abs().max()) + 1e-12

@@ -366,6 +366,42 @@ def test_attack_replayed_from_a_hip_graph_equals_the_eager_attack():
 
 
 @pytest.mark.gpu
+def test_a_failed_graph_capture_falls_back_to_eager_launches():
+    """A HIP-graph capture that dies half way (an injected error after the captured step's first launch: what a HIP call of
+    another thread does to a capture in the default error mode) must not cost the attack: nothing of the captured step has
+    executed, so the eager loop takes over on the same common-size windows from step 1 -- the result is bit for bit the
+    common-windows attack --, use_graph switches itself off with the reason kept, and the next attack runs eagerly."""
+    import random
+    import warnings
+
+    from depthmodelhardening_amd.torchattacks import Phy_obj_atk
+    from oracle import synth
+    dev = torch.device("cuda")
+    model = _unet(dev, seed=5)
+    obj, pmask = synth.make_object()
+    scenes = synth.kitti_like(4, 3, 375, 1242, torch.Generator().manual_seed(28)).to(dev)
+    noise = (torch.rand(obj.shape, generator=torch.Generator().manual_seed(29)) * 2 - 1) * 0.1
+    out = {}
+    for mode in ("common", "broken"):
+        atk = Phy_obj_atk(model, obj.to(dev), pmask.to(dev), eps=0.1, alpha=0.02, steps=4, dist_range=list(np.arange(5, 10, 0.2)))
+        atk.common_windows, atk.use_graph, atk._capture_fault = mode == "common", mode == "broken", mode == "broken"
+        atk.random_start_noise = noise
+        random.seed(33)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            adv, ben, m, patch = atk(scenes, 4)
+        out[mode] = (adv.cpu(), patch.cpu())
+        if mode == "broken":
+            assert atk.use_graph is False and atk._graph is None and "injected capture fault" in atk.graph_failure
+            assert any("capture of the attack step failed" in str(w.message) for w in caught)
+            atk.common_windows = True           # the next attack of the same object: eager, no capture attempted
+            random.seed(33)
+            adv2, _, _, patch2 = atk(scenes, 4)
+            assert torch.equal(patch2.cpu(), out["common"][1])
+    assert torch.equal(out["broken"][1], out["common"][1]) and torch.equal(out["broken"][0], out["common"][0])
+
+
+@pytest.mark.gpu
 def test_l0_attack_with_windows_equals_attack_without():
     """BASELINE config 3's timed path: Phy_obj_atk_l0 takes the same windowed cost (phy_obj_atk_l0.py:118-127 through
     DepthModelWrapper.masked_sq_mean).  use_roi on / off: the same per-iteration trace, the same pattern gradients handed to
