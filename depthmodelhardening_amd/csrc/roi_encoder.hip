@@ -22,38 +22,50 @@ constexpr int NT = 256;
 
 // mode 0: crop src; 1: crop src and mask by gate's window; 2: mask the compact g by gate's window; +4: gate is itself a
 // compact window (same origin and size)
+// (round 6: CPT consecutive channel planes of one sample per thread -- they share the window's geometry, and a block that moved
+//  one plane of a 56 x 78 window lived longer on its argument / origin loads than on its data: see roi_glue_bwd2_kernel)
+template <int CPT>
 __global__ __launch_bounds__(NT) void roi_crop_kernel(const float* __restrict__ src, const float* __restrict__ gate,
                                                       const float* __restrict__ g, const int* __restrict__ org, int C, int H,
                                                       int W, int hc, int wc, int mode, float* __restrict__ out) {
     const int t = (blockIdx.x * NT + threadIdx.x) * 2;         // wc is even
     if (t >= hc * wc) return;
-    const int plane = blockIdx.y, b = plane / C;
+    const int groups = C / CPT;
+    const int b = (int)blockIdx.y / groups, plane0 = b * C + ((int)blockIdx.y - b * groups) * CPT;
     const int i = t / wc, j = t - i * wc;
-    const size_t so = ((size_t)plane * H + org[2 * b] + i) * W + org[2 * b + 1] + j;      // even: 8-byte aligned
-    const size_t co = (size_t)plane * hc * wc + t;
-    float2 v;
-    if ((mode & 3) == 2) v = *reinterpret_cast<const float2*>(g + co);
-    else v = *reinterpret_cast<const float2*>(src + so);
-    if ((mode & 3) != 0) {
-        const float2 q = *reinterpret_cast<const float2*>(gate + ((mode & 4) ? co : so));
-        v.x = q.x > 0.f ? v.x : 0.f;
-        v.y = q.y > 0.f ? v.y : 0.f;
+    size_t so = ((size_t)plane0 * H + org[2 * b] + i) * W + org[2 * b + 1] + j;      // even: 8-byte aligned
+    size_t co = (size_t)plane0 * hc * wc + t;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k, so += (size_t)H * W, co += (size_t)hc * wc) {
+        float2 v;
+        if ((mode & 3) == 2) v = *reinterpret_cast<const float2*>(g + co);
+        else v = *reinterpret_cast<const float2*>(src + so);
+        if ((mode & 3) != 0) {
+            const float2 q = *reinterpret_cast<const float2*>(gate + ((mode & 4) ? co : so));
+            v.x = q.x > 0.f ? v.x : 0.f;
+            v.y = q.y > 0.f ? v.y : 0.f;
+        }
+        *reinterpret_cast<float2*>(out + co) = v;
     }
-    *reinterpret_cast<float2*>(out + co) = v;
 }
 
 // dst[b, c, win_b + (i, j)] = src[...] for the h x w window at frame position win_org: src is a compact [B,C,sh,sw] window at
 // frame origin src_org, or (src_org == NULL) a whole-frame tensor like dst
+template <int CPT>
 __global__ __launch_bounds__(NT) void roi_paste_kernel(const float* __restrict__ src, const int* __restrict__ src_org, int sh,
                                                        int sw, const int* __restrict__ win_org, int C, int H, int W, int h,
                                                        int w, float* __restrict__ dst) {
     const int t = blockIdx.x * NT + threadIdx.x;
     if (t >= h * w) return;
-    const int plane = blockIdx.y, b = plane / C;
+    const int groups = C / CPT;
+    const int b = (int)blockIdx.y / groups, plane0 = b * C + ((int)blockIdx.y - b * groups) * CPT;
     const int i = t / w, j = t - i * w;
     const int Y = win_org[2 * b] + i, X = win_org[2 * b + 1] + j;
     const int sy = Y - (src_org ? src_org[2 * b] : 0), sx = X - (src_org ? src_org[2 * b + 1] : 0);
-    dst[((size_t)plane * H + Y) * W + X] = src[((size_t)plane * sh + sy) * sw + sx];
+    float* d = dst + ((size_t)plane0 * H + Y) * W + X;
+    const float* sp = src + ((size_t)plane0 * sh + sy) * sw + sx;
+#pragma unroll
+    for (int k = 0; k < CPT; ++k, d += (size_t)H * W, sp += (size_t)sh * sw) *d = *sp;
 }
 
 // one thread = one 2 x 2 quad of the window of the H x W map (quad (i, j) = rows 2i, 2i+1: aligned with pooling cell (i, j))
@@ -122,8 +134,12 @@ int dmh_roi_paste(const float* src, const int* src_org, int sh, int sw, const in
     DMH_REQUIRE(B > 0 && C > 0 && (int64_t)B * C <= 65535 && h >= 1 && w >= 1 && h <= H && w <= W && (int64_t)H * W < (1 << 30),
                 "bad sizes (window inside the frame)");
     DMH_REQUIRE(src_org ? (h <= sh && w <= sw) : (sh == H && sw == W), "the source must hold the window");
-    hipLaunchKernelGGL(roi_paste_kernel, dim3(blocks_for((int64_t)h * w), B * C), dim3(NT), 0, (hipStream_t)stream, src, src_org,
-                       sh, sw, win_org, C, H, W, h, w, dst);
+    if (C % 8 == 0)
+        hipLaunchKernelGGL(roi_paste_kernel<8>, dim3(blocks_for((int64_t)h * w), B * (C / 8)), dim3(NT), 0, (hipStream_t)stream, src,
+                           src_org, sh, sw, win_org, C, H, W, h, w, dst);
+    else
+        hipLaunchKernelGGL(roi_paste_kernel<1>, dim3(blocks_for((int64_t)h * w), B * C), dim3(NT), 0, (hipStream_t)stream, src,
+                           src_org, sh, sw, win_org, C, H, W, h, w, dst);
     return check_launch("dmh_roi_paste");
 }
 
@@ -135,8 +151,12 @@ int dmh_roi_crop(const float* src, const float* gate, const float* g, const int*
                     wc <= W && (int64_t)H * W < (1 << 30),
                 "bad sizes (window inside the frame, even widths)");
     const int mode = (g ? 2 : (gate ? 1 : 0)) | ((gate && gate_compact) ? 4 : 0);
-    hipLaunchKernelGGL(roi_crop_kernel, dim3(blocks_for((int64_t)hc * wc / 2), B * C), dim3(NT), 0, (hipStream_t)stream, src,
-                       gate, g, org, C, H, W, hc, wc, mode, out);
+    if (C % 8 == 0)
+        hipLaunchKernelGGL(roi_crop_kernel<8>, dim3(blocks_for((int64_t)hc * wc / 2), B * (C / 8)), dim3(NT), 0, (hipStream_t)stream,
+                           src, gate, g, org, C, H, W, hc, wc, mode, out);
+    else
+        hipLaunchKernelGGL(roi_crop_kernel<1>, dim3(blocks_for((int64_t)hc * wc / 2), B * C), dim3(NT), 0, (hipStream_t)stream, src,
+                           gate, g, org, C, H, W, hc, wc, mode, out);
     return check_launch("dmh_roi_crop");
 }
 

@@ -43,40 +43,47 @@ __device__ __forceinline__ void split_rc(int t, int w2, unsigned magic, int& row
     col2 = t - r * w2;
 }
 
+template <int CPT>
 __global__ __launch_bounds__(NT) void roi_glue_fwd_kernel(const dmh_roi_glue_args a, unsigned magic, float* __restrict__ out) {
+    // CPT consecutive channel planes of one part (the up-sampled y planes, or the skip planes) of one sample per thread: they
+    // share the index map, so it is formed once (see roi_glue_bwd2_kernel)
     const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
     const int t = blockIdx.x * NT + threadIdx.x;                // PW is even: a pair never straddles two rows
     if (2 * t >= PH * PW) return;
-    const int plane = blockIdx.y, b = plane / C, c = plane - b * C;
+    const int groups = C / CPT, g1 = a.C1 / CPT;
+    const int b = (int)blockIdx.y / groups, cg = (int)blockIdx.y - b * groups;
     int i, j;
     split_rc(t, PW >> 1, magic, i, j);
     j *= 2;
-    const int idx = 2 * t;
     const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
     const int Y = reflect_idx(oy + i - 1, a.H);
     const int X0 = reflect_idx(ox + j - 1, a.W), X1 = reflect_idx(ox + j, a.W);
-    float v0, v1;
-    if (c < a.C1) {
+    float* op = out + ((size_t)(b * C) + (cg < g1 ? cg * CPT : a.C1 + (cg - g1) * CPT)) * PH * PW + 2 * t;
+    if (cg < g1) {
         const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
         const int yy = min(max((a.up ? Y >> 1 : Y) - sy0, 0), a.sh - 1);
         const int x0 = min(max((a.up ? X0 >> 1 : X0) - sx0, 0), a.sw - 1);
         const int x1 = min(max((a.up ? X1 >> 1 : X1) - sx0, 0), a.sw - 1);
-        const float* row = a.y + ((size_t)(b * a.C1 + c) * a.sh + yy) * a.sw;
-        v0 = row[x0];
-        v1 = row[x1];
-        if (a.elu) {
-            v0 = elu_f(v0);
-            v1 = elu_f(v1);
+        const float* row = a.y + ((size_t)(b * a.C1 + cg * CPT) * a.sh + yy) * a.sw;
+        const size_t splane = (size_t)a.sh * a.sw;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k, row += splane, op += PH * PW) {
+            float v0 = row[x0], v1 = row[x1];
+            if (a.elu) {
+                v0 = elu_f(v0);
+                v1 = elu_f(v1);
+            }
+            *reinterpret_cast<float2*>(op) = make_float2(v0, v1);
         }
     } else {
         const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
         const int yy = min(max(Y - ky0, 0), a.kh - 1);
         const int x0 = min(max(X0 - kx0, 0), a.kw - 1), x1 = min(max(X1 - kx0, 0), a.kw - 1);
-        const float* row = a.skip + ((size_t)(b * a.C2 + (c - a.C1)) * a.kh + yy) * a.kw;
-        v0 = row[x0];
-        v1 = row[x1];
+        const float* row = a.skip + ((size_t)(b * a.C2 + (cg - g1) * CPT) * a.kh + yy) * a.kw;
+        const size_t kplane = (size_t)a.kh * a.kw;
+#pragma unroll
+        for (int k = 0; k < CPT; ++k, row += kplane, op += PH * PW) *reinterpret_cast<float2*>(op) = make_float2(row[x0], row[x1]);
     }
-    *reinterpret_cast<float2*>(out + (size_t)plane * PH * PW + idx) = make_float2(v0, v1);
 }
 
 // sum of the window's padded-gradient entries that read frame position (Y, X): the entry straight above it and, on
@@ -211,23 +218,28 @@ struct Region2 {
     unsigned ymagic, kmagic;    // ceil(2^32 / (width / 2)) of the two parts
     int yblocks, kblocks;       // blocks along x of the two parts
 };
+template <int CPT>
 __global__ __launch_bounds__(NT) void roi_glue_bwd2_kernel(const dmh_roi_glue_args a, const Region2 r2,
                                                            const float* __restrict__ g_out, float* __restrict__ g_y,
                                                            float* __restrict__ g_skip) {
+    // CPT consecutive channel planes of one sample per thread: the planes of a sample share their geometry (origins, window
+    // offsets, the fast-path test), so the index arithmetic is done once and a block moves CPT times the bytes.  Measured: no
+    // gain here (see the launcher: the default is CPT = 1); the forward kernel, roi_crop and roi_paste take 5-15 % from it.
     const Region& rg = r2.rg;
     const int PH = a.hc + 2, PW = a.wc + 2, C = a.C1 + a.C2;
-    // flat grid: the blocks of the g_y planes, then those of the g_skip planes (uniform decode: scalar divisions)
-    const int ytotal = r2.yblocks * a.B * a.C1;
+    // flat grid: the blocks of the g_y plane groups, then those of the g_skip plane groups (uniform decode: scalar divisions)
+    const int ytotal = r2.yblocks * a.B * (a.C1 / CPT);
     const bool ypart = (int)blockIdx.x < ytotal;
     const int bid = ypart ? (int)blockIdx.x : (int)blockIdx.x - ytotal;
     const int per = ypart ? r2.yblocks : r2.kblocks;
     const int pl = bid / per;
     const int t = (bid - pl * per) * NT + (int)threadIdx.x;
+    const size_t gplane = (size_t)PH * PW;
     if (ypart) {
-        const int plane = pl;
+        const int groups = a.C1 / CPT;
+        const int b = pl / groups, c0 = (pl - b * groups) * CPT;
         const int w2 = rg.yw >> 1;
         if (t >= rg.yh * w2) return;
-        const int b = plane / a.C1, c = plane - b * a.C1;
         const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
         const int sy0 = a.y_org ? a.y_org[2 * b] : 0, sx0 = a.y_org ? a.y_org[2 * b + 1] : 0;
         int yy, xx;
@@ -238,42 +250,67 @@ __global__ __launch_bounds__(NT) void roi_glue_bwd2_kernel(const dmh_roi_glue_ar
             xx += rg.y_org[2 * b + 1];
         }
         const int Ys = sy0 + yy, Xs = sx0 + xx;
-        const float* gp = g_out + (size_t)(b * C + c) * PH * PW;
-        float v0, v1;
-        bool fast = false;
+        const float* gp = g_out + (size_t)(b * C + c0) * gplane;
+        const size_t splane = (size_t)a.sh * a.sw;
+        size_t o = ((size_t)(b * a.C1 + c0) * a.sh + yy) * a.sw + xx;
+        int fast = 0, off = 0;              // 1: up-sampled, all eight entries inside; 2: plain, both entries inside
         if (a.up) {
             const int Y0 = 2 * Ys, X0 = 2 * Xs, r = Y0 + 1 - oy, q = X0 + 1 - ox;
-            // both elements away from the frame's border and all eight entries inside the window
             if (Y0 > 1 && Y0 + 1 < a.H - 2 && X0 > 1 && X0 + 3 < a.W - 2 && r >= 0 && r + 1 < PH && q >= 0 && q + 3 < PW) {
-                const float* p0 = gp + r * PW + q;
-                v0 = p0[0] + p0[1] + p0[PW] + p0[PW + 1];
-                v1 = p0[2] + p0[3] + p0[PW + 2] + p0[PW + 3];
-                fast = true;
+                fast = 1;
+                off = r * PW + q;
             }
         } else {
             const int r = Ys + 1 - oy, q = Xs + 1 - ox;
             if (Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs + 1 < a.W - 2 && r >= 0 && r < PH && q >= 0 && q + 1 < PW) {
-                v0 = gp[r * PW + q];
-                v1 = gp[r * PW + q + 1];
-                fast = true;
+                fast = 2;
+                off = r * PW + q;
             }
         }
-        if (!fast) {
-            v0 = glue_bwd_y_elem(a, gp, Ys, Xs, oy, ox, PH, PW);
-            v1 = glue_bwd_y_elem(a, gp, Ys, Xs + 1, oy, ox, PH, PW);
+        // the three cases as three loops (fast is per thread, but the common case must not carry the general path's code in
+        // every unrolled iteration: a first version did, and ran at half the speed of the one-plane kernel)
+        if (fast == 1) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j, gp += gplane, o += splane) {
+                const float* p0 = gp + off;
+                float v0 = p0[0] + p0[1] + p0[PW] + p0[PW + 1];
+                float v1 = p0[2] + p0[3] + p0[PW + 2] + p0[PW + 3];
+                if (a.elu) {
+                    const float2 yv = *reinterpret_cast<const float2*>(a.y + o);
+                    v0 = v0 != 0.f ? v0 * elu_grad(yv.x) : v0;
+                    v1 = v1 != 0.f ? v1 * elu_grad(yv.y) : v1;
+                }
+                *reinterpret_cast<float2*>(g_y + o) = make_float2(v0, v1);
+            }
+        } else if (fast == 2) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j, gp += gplane, o += splane) {
+                float v0 = gp[off], v1 = gp[off + 1];
+                if (a.elu) {
+                    const float2 yv = *reinterpret_cast<const float2*>(a.y + o);
+                    v0 = v0 != 0.f ? v0 * elu_grad(yv.x) : v0;
+                    v1 = v1 != 0.f ? v1 * elu_grad(yv.y) : v1;
+                }
+                *reinterpret_cast<float2*>(g_y + o) = make_float2(v0, v1);
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < CPT; ++j, gp += gplane, o += splane) {
+                float v0 = glue_bwd_y_elem(a, gp, Ys, Xs, oy, ox, PH, PW);
+                float v1 = glue_bwd_y_elem(a, gp, Ys, Xs + 1, oy, ox, PH, PW);
+                if (a.elu) {
+                    const float2 yv = *reinterpret_cast<const float2*>(a.y + o);
+                    v0 = v0 != 0.f ? v0 * elu_grad(yv.x) : v0;
+                    v1 = v1 != 0.f ? v1 * elu_grad(yv.y) : v1;
+                }
+                *reinterpret_cast<float2*>(g_y + o) = make_float2(v0, v1);
+            }
         }
-        const size_t o = ((size_t)plane * a.sh + yy) * a.sw + xx;
-        if (a.elu) {
-            const float2 yv = *reinterpret_cast<const float2*>(a.y + o);
-            v0 = v0 != 0.f ? v0 * elu_grad(yv.x) : v0;
-            v1 = v1 != 0.f ? v1 * elu_grad(yv.y) : v1;
-        }
-        *reinterpret_cast<float2*>(g_y + o) = make_float2(v0, v1);
     } else {
-        const int q = pl;
+        const int groups = a.C2 / CPT;
+        const int b = pl / groups, c0 = (pl - b * groups) * CPT;
         const int w2 = rg.kw >> 1;
         if (t >= rg.kh * w2) return;
-        const int b = q / a.C2, c = q - b * a.C2;
         const int oy = a.dst_org[2 * b], ox = a.dst_org[2 * b + 1];
         const int ky0 = a.skip_org ? a.skip_org[2 * b] : 0, kx0 = a.skip_org ? a.skip_org[2 * b + 1] : 0;
         int yy, xx;
@@ -283,20 +320,25 @@ __global__ __launch_bounds__(NT) void roi_glue_bwd2_kernel(const dmh_roi_glue_ar
             yy += rg.skip_org[2 * b];
             xx += rg.skip_org[2 * b + 1];
         }
-        const float* gp = g_out + (size_t)(b * C + a.C1 + c) * PH * PW;
+        const float* gp = g_out + (size_t)(b * C + a.C1 + c0) * gplane;
         const int Ys = ky0 + yy, Xs = kx0 + xx;
         const int r = Ys + 1 - oy, qq = Xs + 1 - ox;
-        float v0, v1;
-        if (Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs + 1 < a.W - 2 && r >= 0 && r < PH && qq >= 0 && qq + 1 < PW) {
-            v0 = gp[r * PW + qq];
-            v1 = gp[r * PW + qq + 1];
+        const bool fast = Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs + 1 < a.W - 2 && r >= 0 && r < PH && qq >= 0 && qq + 1 < PW;
+        const bool in0 = Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs < a.W - 2, in1 = Ys > 1 && Ys < a.H - 2 && Xs + 1 > 1 && Xs + 1 < a.W - 2;
+        const size_t kplane = (size_t)a.kh * a.kw;
+        float* gs = g_skip + ((size_t)(b * a.C2 + c0) * a.kh + yy) * a.kw + xx;
+        if (fast) {
+#pragma unroll
+            for (int j = 0; j < CPT; ++j, gp += gplane, gs += kplane)
+                *reinterpret_cast<float2*>(gs) = make_float2(gp[r * PW + qq], gp[r * PW + qq + 1]);
         } else {
-            v0 = (Ys > 1 && Ys < a.H - 2 && Xs > 1 && Xs < a.W - 2) ? gather_interior(gp, Ys, Xs, oy, ox, PH, PW)
-                                                                     : gather_pad(gp, Ys, Xs, a.H, a.W, oy, ox, PH, PW);
-            v1 = (Ys > 1 && Ys < a.H - 2 && Xs + 1 > 1 && Xs + 1 < a.W - 2) ? gather_interior(gp, Ys, Xs + 1, oy, ox, PH, PW)
-                                                                             : gather_pad(gp, Ys, Xs + 1, a.H, a.W, oy, ox, PH, PW);
+#pragma unroll 1
+            for (int j = 0; j < CPT; ++j, gp += gplane, gs += kplane) {
+                const float v0 = in0 ? gather_interior(gp, Ys, Xs, oy, ox, PH, PW) : gather_pad(gp, Ys, Xs, a.H, a.W, oy, ox, PH, PW);
+                const float v1 = in1 ? gather_interior(gp, Ys, Xs + 1, oy, ox, PH, PW) : gather_pad(gp, Ys, Xs + 1, a.H, a.W, oy, ox, PH, PW);
+                *reinterpret_cast<float2*>(gs) = make_float2(v0, v1);
+            }
         }
-        *reinterpret_cast<float2*>(g_skip + ((size_t)q * a.kh + yy) * a.kw + xx) = make_float2(v0, v1);
     }
 }
 
@@ -372,8 +414,11 @@ int dmh_roi_glue_fwd(const dmh_roi_glue_args* a, float* out, void* stream) {
     if (int rc = check_glue(a)) return rc;
     DMH_REQUIRE(out, "null pointer");
     const unsigned magic = (unsigned)(((uint64_t)1 << 32) / (unsigned)((a->wc + 2) >> 1)) + 1u;
-    hipLaunchKernelGGL(roi_glue_fwd_kernel, dim3(blocks_for((int64_t)(a->hc + 2) * (a->wc + 2) / 2), a->B * (a->C1 + a->C2)),
-                       dim3(NT), 0, (hipStream_t)stream, *a, magic, out);
+    const int cpt = (a->C1 % 8 == 0 && a->C2 % 8 == 0) ? 8 : ((a->C1 % 4 == 0 && a->C2 % 4 == 0) ? 4 : 1);
+    const dim3 grid(blocks_for((int64_t)(a->hc + 2) * (a->wc + 2) / 2), (unsigned)(a->B * ((a->C1 + a->C2) / cpt)));
+    if (cpt == 8) hipLaunchKernelGGL(roi_glue_fwd_kernel<8>, grid, dim3(NT), 0, (hipStream_t)stream, *a, magic, out);
+    else if (cpt == 4) hipLaunchKernelGGL(roi_glue_fwd_kernel<4>, grid, dim3(NT), 0, (hipStream_t)stream, *a, magic, out);
+    else hipLaunchKernelGGL(roi_glue_fwd_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, *a, magic, out);
     return check_launch("dmh_roi_glue_fwd");
 }
 
@@ -408,10 +453,18 @@ int dmh_roi_glue_bwd(const dmh_roi_glue_args* a, const float* g_out, float* g_y,
         r2.kmagic = (unsigned)(((uint64_t)1 << 32) / kw2) + 1u;
         r2.yblocks = (int)blocks_for(ny / 2);
         r2.kblocks = skip ? (int)blocks_for(nk / 2) : 1;
-        const int64_t total = (int64_t)r2.yblocks * a->B * a->C1 + (skip ? (int64_t)r2.kblocks * a->B * a->C2 : 0);
+        const int c2 = skip ? a->C2 : 0;
+        // planes per thread: ONE.  The forward kernel, the crops and the pastes gain 5-15 % from eight planes per thread (shared
+        // index map); this gather does not -- with eight planes it ran at HALF the speed of one (3.6 against 1.97 ms per step,
+        // profiles/README.md round 6), whichever way its three cases were laid out: DMH_ROI_GLUE_CPT=8 / 4 keeps it measurable
+        static const int cpt_env = getenv("DMH_ROI_GLUE_CPT") ? atoi(getenv("DMH_ROI_GLUE_CPT")) : 1;
+        const int cpt = (cpt_env == 8 && a->C1 % 8 == 0 && c2 % 8 == 0) ? 8 : ((cpt_env >= 4 && a->C1 % 4 == 0 && c2 % 4 == 0) ? 4 : 1);
+        const int64_t total = (int64_t)r2.yblocks * a->B * (a->C1 / cpt) + (skip ? (int64_t)r2.kblocks * a->B * (c2 / cpt) : 0);
         DMH_REQUIRE(total < ((int64_t)1 << 31), "too many blocks");
-        hipLaunchKernelGGL(roi_glue_bwd2_kernel, dim3((unsigned)total), dim3(NT), 0, (hipStream_t)stream, *a, r2, g_out, g_y,
-                           g_skip);
+        const dim3 grid((unsigned)total);
+        if (cpt == 8) hipLaunchKernelGGL(roi_glue_bwd2_kernel<8>, grid, dim3(NT), 0, (hipStream_t)stream, *a, r2, g_out, g_y, g_skip);
+        else if (cpt == 4) hipLaunchKernelGGL(roi_glue_bwd2_kernel<4>, grid, dim3(NT), 0, (hipStream_t)stream, *a, r2, g_out, g_y, g_skip);
+        else hipLaunchKernelGGL(roi_glue_bwd2_kernel<1>, grid, dim3(NT), 0, (hipStream_t)stream, *a, r2, g_out, g_y, g_skip);
         return check_launch("dmh_roi_glue_bwd");
     }
     hipLaunchKernelGGL(roi_glue_bwd_kernel, dim3(blocks_for(ny > nk ? ny : nk), planes), dim3(NT), 0, (hipStream_t)stream, *a,

@@ -73,51 +73,58 @@ constexpr int SK_SLOT = 16 * NT * 4;      // floats of one partial item: [output
 // mode 1: backward  u[c][k] from w[k][c][2-ky][2-kx]   (output channels of the pass = C of the filter)
 // scale (optional): per-channel factor of the convolution OUTPUT of the forward pass (an eval-mode BatchNorm folded
 // into the filter): multiplies filter row ko in mode 0 and filter column ci (the same channel) in mode 1.
+// One thread = one output channel x FOUR consecutive input channels of the pass (the four components s of an image word): the
+// 16 transformed values of each go out as 16-byte stores that consecutive threads (ko fastest) write back to back.  (Through
+// round 5 a thread owned one (ko, ci) and wrote 16 single floats 16 bytes apart: a quarter of every store's lanes' bytes.)
 __device__ __forceinline__ void wino_weight_element(const float* __restrict__ w, int Kw, int Cw, int mode,
                                                     const float* __restrict__ scale, float* __restrict__ U, int Kp, int i) {
     // "out" / "in" are the channel roles of the pass this transform is for
     const int n_out = mode ? Cw : Kw, n_in = mode ? Kw : Cw;
-    if (i >= Kp * n_in) return;
-    const int ko = i % Kp, ci = i / Kp;
-    float g[3][3];
-    if (ko < n_out) {
-        const float* src = mode ? w + ((size_t)ci * Cw + ko) * 9 : w + ((size_t)ko * Cw + ci) * 9;
-        const float sc = scale ? scale[mode ? ci : ko] : 1.f;
+    if (i >= Kp * (n_in >> 2)) return;
+    const int ko = i % Kp, cq = i / Kp;          // cq: quad of input channels 4 cq .. 4 cq + 3
+    float u[4][16];
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+    for (int s = 0; s < 4; ++s) {
+        const int ci = 4 * cq + s;
+        float g[3][3];
+        if (ko < n_out) {
+            const float* src = mode ? w + ((size_t)ci * Cw + ko) * 9 : w + ((size_t)ko * Cw + ci) * 9;
+            const float sc = scale ? scale[mode ? ci : ko] : 1.f;
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = sc * (mode ? src[(2 - a) * 3 + (2 - b)] : src[a * 3 + b]);
-    } else {
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) g[a][b] = sc * (mode ? src[(2 - a) * 3 + (2 - b)] : src[a * 3 + b]);
+        } else {
 #pragma unroll
-            for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
-    }
-    float t[4][3];
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-    for (int b = 0; b < 3; ++b) {
-        t[0][b] = g[0][b];
-        t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-        t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-        t[3][b] = g[2][b];
-    }
-    const int cc = ci / CK, cl = ci % CK, h = cl >> 2, s = cl & 3;
+                for (int b = 0; b < 3; ++b) g[a][b] = 0.f;
+        }
+        float t[4][3];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-        const float u0 = t[a][0], u1 = 0.5f * (t[a][0] + t[a][1] + t[a][2]), u2 = 0.5f * (t[a][0] - t[a][1] + t[a][2]),
-                    u3 = t[a][2];
-        const float u[4] = {u0, u1, u2, u3};
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int p = a * 4 + b;
-            U[((((size_t)cc * 16 + p) * 2 + h) * Kp + ko) * 4 + s] = u[b];
+        for (int a = 0; a < 4; ++a) {
+            u[s][a * 4 + 0] = t[a][0];
+            u[s][a * 4 + 1] = 0.5f * (t[a][0] + t[a][1] + t[a][2]);
+            u[s][a * 4 + 2] = 0.5f * (t[a][0] - t[a][1] + t[a][2]);
+            u[s][a * 4 + 3] = t[a][2];
         }
     }
+    const int cc = cq >> 1, h = cq & 1;          // chunk of 8 channels, half of the MFMA k pair
+    f32x4* Uw = reinterpret_cast<f32x4*>(U);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) Uw[(((size_t)cc * 16 + p) * 2 + h) * Kp + ko] = f32x4{u[0][p], u[1][p], u[2][p], u[3][p]};
 }
 
 __global__ __launch_bounds__(NT) void wino_weight_kernel(const float* __restrict__ w, int Kw, int Cw, int mode,
                                                          const float* __restrict__ scale, float* __restrict__ U, int Kp) {
-    wino_weight_element(w, Kw, Cw, mode, scale, U, Kp, (int)blockIdx.x * NT + (int)threadIdx.x);    // over Kp * n_in
+    wino_weight_element(w, Kw, Cw, mode, scale, U, Kp, (int)blockIdx.x * NT + (int)threadIdx.x);    // over Kp * n_in / 4
 }
 
 // Many filters in ONE launch (dmh_wino_weight_transform_batch): the jobs travel by value in the kernel arguments, a block finds
@@ -755,8 +762,9 @@ int dmh_wino_weight_transform_scaled(const float* w, int K, int C, int backward,
     DMH_REQUIRE(w && U, "null pointer");
     const int n_out = backward ? C : K, n_in = backward ? K : C;
     DMH_REQUIRE(K > 0 && C > 0 && n_in % CK == 0, "the pass's input channel count must be a multiple of 8");
+    DMH_REQUIRE(((uintptr_t)U & 15) == 0, "U must be 16-byte aligned");
     const int Kp = (n_out + 63) / 64 * 64;
-    const long long n = (long long)Kp * n_in;
+    const long long n = (long long)Kp * (n_in / 4);
     hipLaunchKernelGGL(wino_weight_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, w, K, C,
                        backward ? 1 : 0, scale, U, Kp);
     return check_launch("dmh_wino_weight_transform");
@@ -774,13 +782,13 @@ int dmh_wino_weight_transform_batch(const dmh_wino_wt_job* jobs, int n, void* st
         long long blocks = 0;
         for (int j = 0; j < b.n; ++j) {
             const dmh_wino_wt_job& q = jobs[lo + j];
-            DMH_REQUIRE(q.w && q.U, "null pointer");
+            DMH_REQUIRE(q.w && q.U && ((uintptr_t)q.U & 15) == 0, "null pointer / U not 16-byte aligned");
             const int n_out = q.backward ? q.C : q.K, n_in = q.backward ? q.K : q.C;
             DMH_REQUIRE(q.K > 0 && q.C > 0 && n_in % CK == 0, "the pass's input channel count must be a multiple of 8");
             b.w[j] = q.w; b.scale[j] = q.scale; b.U[j] = q.U; b.K[j] = q.K; b.C[j] = q.C; b.mode[j] = q.backward ? 1 : 0;
             b.Kp[j] = (n_out + 63) / 64 * 64;
             b.first[j] = (int)blocks;
-            blocks += ((long long)b.Kp[j] * n_in + NT - 1) / NT;
+            blocks += ((long long)b.Kp[j] * (n_in / 4) + NT - 1) / NT;
             DMH_REQUIRE(blocks < ((long long)1 << 30), "too many elements in one batch");
         }
         b.first[b.n] = (int)blocks;
