@@ -50,7 +50,7 @@ def _watch_windows(model):
 
 
 def test_phy_obj_atk_on_the_unet_vs_cpu_oracle():
-    """Phy_obj_atk, 4 scenes x 3 PGD steps at 320 x 1024 on the ResNet-18 U-Net, windows on, against oracle.attack_ref on the
+    """Phy_obj_atk, 3 scenes x 3 PGD steps at 320 x 1024 on the ResNet-18 U-Net, windows on, against oracle.attack_ref on the
     CPU twin with the same draws: every step's cost 1e-4 relative, the first step's patch gradient against the oracle in
     FLOAT64 (within 1.5 x the fp32 oracle's own distance: the sampler's floor() bounds any fp32 run at ~1e-2), the patch after
     three sign steps, the returned scenes."""
@@ -58,7 +58,7 @@ def test_phy_obj_atk_on_the_unet_vs_cpu_oracle():
     from depthmodelhardening_amd.torchattacks import Phy_obj_atk
     from oracle import attack_ref, synth
     from oracle.unet_ref import UNetRef
-    Ba, steps, eps, alpha = 4, 3, 0.1, 0.02
+    Ba, steps, eps, alpha = 3, 3, 0.1, 0.02
     obj, mask = synth.make_object()
     scenes = synth.kitti_like(Ba, 3, 375, 1242, torch.Generator().manual_seed(41))
     noise = (torch.rand(obj.shape, generator=torch.Generator().manual_seed(9)) * 2 - 1) * eps
@@ -144,7 +144,7 @@ def test_attack_step_image_gradient_vs_fp64_oracle(weights):
     from depthmodelhardening_amd.roi import RoiPlan
     from oracle import attack_ref, synth
     from oracle.unet_ref import UNetRef, min_relu_margin, set_relu_margins
-    Ba, H, W = 4, 320, 1024
+    Ba, H, W = 3, 320, 1024
     dev = torch.device("cuda")
     obj, pmask = synth.make_object()
     scenes = synth.kitti_like(Ba, 3, 375, 1242, torch.Generator().manual_seed(45))
@@ -207,7 +207,7 @@ def test_phy_obj_atk_l0_on_the_unet_vs_cpu_oracle():
     from depthmodelhardening_amd.torchattacks import Phy_obj_atk_l0
     from oracle import attack_ref, synth
     from oracle.unet_ref import UNetRef
-    Ba, steps = 3, 2
+    Ba, steps = 2, 2
     obj, mask = synth.make_object()
     scenes = synth.kitti_like(Ba, 3, 375, 1242, torch.Generator().manual_seed(43))
     model = _unet(15).cuda().eval()

@@ -58,21 +58,22 @@ def _oracle_loss(loss_ref, inputs, disps, noise, variant, frame_ids=(0, "s")):
 
 
 def _pool_seeds(B, H, W, seed):
-    """Seeds to pool so that the gradient bound is decided by >= ~2e5 pixels, not by a handful of flips -- and no more than
+    """Seeds to pool so that the gradient bound is decided by >= ~1.2e5 pixels, not by a handful of flips -- and no more than
     that: every seed is one float32 and one float64 oracle pass on the CPU (the suite's time budget, profiles/
     r06_gpu_suite_durations.txt)."""
-    n = int(min(24, max(1, -(-200000 // (B * H * W)))))
+    n = int(min(24, max(1, -(-120000 // (B * H * W)))))
     return [seed + 1000 * i for i in range(n)]
 
 
 @pytest.mark.parametrize("variant", ["md2", "dh"])
-@pytest.mark.parametrize("shape", [(16, 32, 96, 21), (2, 192, 640, 22), (12, 48, 80, 5), (6, 64, 200, 9)])
+@pytest.mark.parametrize("shape", [(32, 32, 96, 21), (2, 192, 640, 22), (24, 48, 80, 5), (12, 64, 200, 9)])
 @pytest.mark.parametrize("with_noise", [False, True])
 def test_photo_smooth_loss_vs_oracle(variant, shape, with_noise):
-    # (the three small image sizes run at batch 16 / 12 / 6: the pooled pixel count is what decides the gradient bound, and a
+    # (the three small image sizes run at batch 32 / 24 / 12: the pooled pixel count is what decides the gradient bound, and a
     # seed costs two oracle passes whose time at these sizes is all per-call overhead; batch 2 at such sizes: the goldens)
-    if not with_noise and shape[1:3] in ((48, 80), (64, 200)):
-        pytest.skip("the noise-free form is covered at two shapes; with the tie-break noise at all four (suite time)")
+    if not with_noise and shape[1:3] != (192, 640):
+        pytest.skip("the noise-free form is covered at the config-1 shape (and by the conditioning tests and the goldens); with "
+                    "the tie-break noise at all four (suite time)")
     N, ops, loss_ref, _, synth, _ = _mods()
     B, H, W, seed0 = shape
     pool = GradPool(count_floor=2.0 / (H * W) if variant == "dh" else 0.0)
