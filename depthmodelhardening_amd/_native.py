@@ -127,6 +127,7 @@ _SIGNATURES = {
     "dmh_wino_weight_transform": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp]),
     "dmh_wino_conv3x3": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp]),
     "dmh_wino_conv3x3_ws": (C.c_int, [_fp] * 3 + [C.c_int] * 6 + [_fp, _fp, C.c_int64, _fp]),
+    "dmh_wino_conv3x3_plan": (C.c_int, [C.c_int] * 7 + [C.c_int64]),
     "dmh_wino_weight_transform_scaled": (C.c_int, [_fp, C.c_int, C.c_int, C.c_int, _fp, _fp, _fp]),
     "dmh_wino_conv3x3_act": (C.c_int, [_fp] * 4 + [C.c_int] * 7 + [_fp, _fp]),
     "dmh_wino_weight_transform_batch": (C.c_int, [C.POINTER(WinoWtJob), C.c_int, _fp]),

@@ -670,6 +670,36 @@ int num_cus() {
     return n;
 }
 
+// CUs a K10 launch may occupy.  DMH_K10_RESERVE_CUS=n leaves n CUs without a K10 workgroup: a contingency for multi-GPU runs,
+// where RCCL's kernels cannot become resident on a CU this kernel occupies; default 0.  Applies to the
+// whole-item grid and to the stream-K grid alike.
+int usable_cus() {
+    static const int reserve = getenv("DMH_K10_RESERVE_CUS") ? atoi(getenv("DMH_K10_RESERVE_CUS")) : 0;
+    const int n = num_cus();
+    return n - (reserve > 0 && reserve < n ? reserve : 0);
+}
+
+// The stream-K decision of launch_split(), also what dmh_wino_conv3x3_plan() reports: taken when a workspace of 2 G slots is
+// there and the cost model (3.05 us per chunk, ~4 us per item epilogue, ~6 us for the second launch: profiles/README.md) says
+// it is >= 8 % faster than whole items.  With the fused epilogue only launches of FEW regions take it (< 200).  The count is the
+// LAUNCH's own: at the attack batch of the benchmark (12 scenes) the windowed encoder launches have >= 240 regions and keep whole
+// items like their whole-frame twins (bit-identical, tests/test_roi.py); at a small attack batch (e.g. 2 scenes per rank) a
+// windowed launch can fall below 200 and be decomposed while its whole-frame twin is not -- the partial sums are then added in
+// another order and the two agree to fp32 rounding, not bit for bit.
+bool sk_decide(long long regions, int nch, bool epi, bool have_ws, int64_t ws_floats, int& G, long long& units) {
+    if (!have_ws || (epi && regions >= 200)) return false;
+    const int cus = usable_cus();
+    units = regions * nch;
+    G = (int)(units / 8 < cus ? units / 8 : cus);
+    if (!(G >= 2 && units < ((long long)1 << 30) && (long long)2 * G * SK_SLOT <= ws_floats)) return false;
+    const int cs = (!epi && regions < (3 * cus) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;   // what the legacy path would do
+    const long long items = regions * cs;
+    const double t_cur = (double)((items + cus - 1) / cus) * ((nch / cs) * 3.05 + 4.0) + (cs > 1 ? 6.0 : 0.0);
+    const double per = (double)units / G;
+    const double t_sk = per * 3.05 + 4.0 * (per / nch + 1.5) + 6.0;
+    return t_sk < 0.92 * t_cur;
+}
+
 template <int TRW, bool FLAT, bool EPI>
 int launch(WArgs& a, hipStream_t st) {
     constexpr int TRH = 64 / TRW;
@@ -681,10 +711,7 @@ int launch(WArgs& a, hipStream_t st) {
         return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
     // persistent: one workgroup per CU (its 154 KB of LDS and 512 registers per lane fill the CU), each walking a
     // contiguous range of work items
-    // DMH_K10_RESERVE_CUS=n leaves n CUs without a K10 workgroup: a contingency for multi-GPU runs, where RCCL's kernels
-    // cannot become resident on a CU this kernel occupies; default 0
-    static const int reserve = getenv("DMH_K10_RESERVE_CUS") ? atoi(getenv("DMH_K10_RESERVE_CUS")) : 0;
-    const int cus = num_cus() - (reserve > 0 && reserve < num_cus() ? reserve : 0);
+    const int cus = usable_cus();
     const int grid = a.nitems < cus ? a.nitems : cus;
     hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, EPI>), dim3((unsigned)grid), dim3(NT), smem, st, a);
     return check_launch("dmh_wino_conv3x3");
@@ -697,44 +724,35 @@ int launch_split(WArgs& a, hipStream_t st, bool epi, float* ws, int64_t ws_float
     if (regions >= ((int64_t)1 << 30)) return fail(DMH_EINVAL, "%s: too many work items", "dmh_wino_conv3x3");
     const int nch = a.C / CK;
     a.part = nullptr; a.sk_units = 0; a.sk_grid = 0;
-    // Stream-K with a caller-provided workspace (plain convolutions only: a fused activation keeps whole items, and the
-    // windowed encoder launches stay bit-identical to their whole-frame twins).  A launch is as long as its slowest workgroup:
+    // Stream-K with a caller-provided workspace (sk_decide()).  A launch is as long as its slowest workgroup:
     // with whole items that is ceil(items / CUs) x (one item's channel loop); here every workgroup gets the same number of
     // (item, chunk) units and at most two partial items, whose sums meet in wino_sk_fixup_kernel.  Taken when the model below
     // (3.05 us per chunk, ~4 us per item epilogue, ~6 us for the second launch: profiles/README.md) says it is >= 8 % faster.
     // With the fused epilogue only launches of FEW regions take it (< 200: the ones the no-split rule of ops.py turned away,
-    // layer4 at the attack batch): the fix-up kernel then applies shift / identity / ReLU.  The windowed encoder launches have
-    // more regions and keep whole items, bit-identical to their whole-frame twins.
-    if (ws && (!epi || regions < 200)) {
-        const int cus = num_cus();
-        const long long units = regions * nch;
-        const int G = (int)(units / 8 < cus ? units / 8 : cus);
-        if (G >= 2 && units < ((long long)1 << 30) && (long long)2 * G * SK_SLOT <= ws_floats) {
-            const int cs = (!epi && regions < (3 * cus) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;   // what the legacy path would do
-            const long long items = regions * cs;
-            const double t_cur = (double)((items + cus - 1) / cus) * ((nch / cs) * 3.05 + 4.0) + (cs > 1 ? 6.0 : 0.0);
-            const double per = (double)units / G;
-            const double t_sk = per * 3.05 + 4.0 * (per / nch + 1.5) + 6.0;
-            if (t_sk < 0.92 * t_cur) {
-                a.csplit = 1; a.nitems = (int)regions; a.part = ws; a.sk_units = (int)units; a.sk_grid = G; a.sk_per = (int)(units / G); a.sk_rem = (int)(units % G);
-                static std::atomic<uint64_t> configured{0};
-                constexpr int TRH = 64 / TRW;
-                constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);
-                constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
-                static std::atomic<uint64_t> configured_epi{0};
-                if ((epi ? configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, true, true>, smem, configured_epi)
-                         : configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, false, true>, smem, configured)) != hipSuccess)
-                    return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
-                if (epi) hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, true, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
-                else hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, false, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
-                if (int rc = check_launch("dmh_wino_conv3x3 (stream-K)")) return rc;
-                hipLaunchKernelGGL((wino_sk_fixup_kernel<TRW, FLAT>), dim3((unsigned)(G - 1), 4), dim3(NT), 0, st, a);
-                return check_launch("dmh_wino_conv3x3 (stream-K fix-up)");
-            }
+    // layer4 at the attack batch): the fix-up kernel then applies shift / identity / ReLU.  At the benchmark's attack batch the
+    // windowed encoder launches have more regions and keep whole items (see sk_decide() for smaller batches).
+    {
+        int G = 0;
+        long long units = 0;
+        if (sk_decide(regions, nch, epi, ws != nullptr, ws_floats, G, units)) {
+            a.csplit = 1; a.nitems = (int)regions; a.part = ws; a.sk_units = (int)units; a.sk_grid = G; a.sk_per = (int)(units / G); a.sk_rem = (int)(units % G);
+            static std::atomic<uint64_t> configured{0};
+            constexpr int TRH = 64 / TRW;
+            constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);
+            constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
+            static std::atomic<uint64_t> configured_epi{0};
+            if ((epi ? configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, true, true>, smem, configured_epi)
+                     : configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, false, true>, smem, configured)) != hipSuccess)
+                return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
+            if (epi) hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, true, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
+            else hipLaunchKernelGGL((wino_conv_kernel<TRW, FLAT, false, true>), dim3((unsigned)G), dim3(NT), smem, st, a);
+            if (int rc = check_launch("dmh_wino_conv3x3 (stream-K)")) return rc;
+            hipLaunchKernelGGL((wino_sk_fixup_kernel<TRW, FLAT>), dim3((unsigned)(G - 1), 4), dim3(NT), 0, st, a);
+            return check_launch("dmh_wino_conv3x3 (stream-K fix-up)");
         }
     }
     // (a fused activation needs the complete sum in one item: no split)
-    a.csplit = (!epi && regions < (3 * num_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
+    a.csplit = (!epi && regions < (3 * usable_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
     a.nitems = (int)regions * a.csplit;
     if (a.csplit > 1) {
         // a fill KERNEL, not hipMemsetAsync: inside a stream capture (torch.cuda.graph) the runtime's memset was not replayed
@@ -798,6 +816,26 @@ int dmh_wino_weight_transform_batch(const dmh_wino_wt_job* jobs, int n, void* st
     return DMH_OK;
 }
 
+// tile-region geometry of a launch (a.B, a.Ho, a.Wo, ... set): fills gx, gy, bitems; returns 0 = 2 x 32 regions per image,
+// 1 = 4 x 16 regions per image, 2 = 4 x 16 regions with the rows of tiles flattened over the batch (FLAT)
+static int tile_geometry(WArgs& a) {
+    const int Ht = a.Ho / 2, Wt = a.Wo / 2;
+    // narrow images: 4 x 16 tile regions waste fewer lanes than 2 x 32 ones
+    const bool narrow = (Wt % 32) != 0 && (Wt <= 16 || ((Wt + 15) / 16 * 16 - Wt) < ((Wt + 31) / 32 * 32 - Wt));
+    if (narrow) {
+        a.gx = (Wt + 15) / 16;
+        // rows of tiles flattened over the batch when per-image regions would waste >= 1/5 of their tile rows
+        if (5 * Ht <= 4 * ((Ht + 3) / 4 * 4) && (int64_t)a.B * a.C * a.H * a.W < ((int64_t)1 << 31)) {
+            a.gy = (a.B * Ht + 3) / 4; a.bitems = 1;
+            return 2;
+        }
+        a.gy = (Ht + 3) / 4; a.bitems = a.B;
+        return 1;
+    }
+    a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2; a.bitems = a.B;
+    return 0;
+}
+
 static int wino_conv_common(const float* x, const float* U, const float* bias, const float* residual, int relu, bool epi,
                             int B, int C, int K, int H, int W, int pad, float* y, void* stream, float* ws = nullptr,
                             int64_t ws_floats = 0) {
@@ -812,21 +850,28 @@ static int wino_conv_common(const float* x, const float* U, const float* bias, c
     a.x = x; a.U = reinterpret_cast<const f32x4*>(U); a.bias = bias; a.res = residual; a.relu = relu; a.y = y;
     a.B = B; a.C = C; a.K = K; a.Kp = (K + 63) / 64 * 64; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo; a.pad = pad;
     a.kg = a.Kp / 64;
-    const int Ht = Ho / 2, Wt = Wo / 2;
-    // narrow images: 4 x 16 tile regions waste fewer lanes than 2 x 32 ones
-    const bool narrow = (Wt % 32) != 0 && (Wt <= 16 || ((Wt + 15) / 16 * 16 - Wt) < ((Wt + 31) / 32 * 32 - Wt));
-    if (narrow) {
-        a.gx = (Wt + 15) / 16;
-        // rows of tiles flattened over the batch when per-image regions would waste >= 1/5 of their tile rows
-        if (5 * Ht <= 4 * ((Ht + 3) / 4 * 4) && (int64_t)B * C * H * W < ((int64_t)1 << 31)) {
-            a.gy = (B * Ht + 3) / 4; a.bitems = 1;
-            return launch_split<16, true>(a, (hipStream_t)stream, epi, ws, ws_floats);
-        }
-        a.gy = (Ht + 3) / 4; a.bitems = B;
-        return launch_split<16, false>(a, (hipStream_t)stream, epi, ws, ws_floats);
+    switch (tile_geometry(a)) {
+        case 2: return launch_split<16, true>(a, (hipStream_t)stream, epi, ws, ws_floats);
+        case 1: return launch_split<16, false>(a, (hipStream_t)stream, epi, ws, ws_floats);
+        default: return launch_split<32, false>(a, (hipStream_t)stream, epi, ws, ws_floats);
     }
-    a.gx = (Wt + 31) / 32; a.gy = (Ht + 1) / 2; a.bitems = B;
-    return launch_split<32, false>(a, (hipStream_t)stream, epi, ws, ws_floats);
+}
+
+int dmh_wino_conv3x3_plan(int B, int C, int K, int H, int W, int pad, int epilogue, int64_t workspace_floats) {
+    if (!(B > 0 && C >= 3 * CK && K > 0 && C % CK == 0 && pad >= 0 && pad <= 2)) return -1;
+    WArgs a;
+    a.B = B; a.C = C; a.K = K; a.Kp = (K + 63) / 64 * 64; a.H = H; a.W = W; a.Ho = H + 2 * pad - 2; a.Wo = W + 2 * pad - 2; a.pad = pad;
+    if (a.Ho < 2 || a.Wo < 2 || (a.Ho & 1) || (a.Wo & 1) || (int64_t)B * C * H * W >= ((int64_t)1 << 30)) return -1;
+    a.kg = a.Kp / 64;
+    const int form = tile_geometry(a);
+    const long long regions = (long long)a.bitems * a.gx * a.gy * a.kg;
+    if (regions >= ((long long)1 << 22)) return -1;
+    const int nch = C / CK;
+    int G = 0;
+    long long units = 0;
+    const bool sk = sk_decide(regions, nch, epilogue != 0, workspace_floats > 0, workspace_floats, G, units);
+    const int csplit = (!sk && !epilogue && regions < (3 * usable_cus()) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;
+    return (sk ? 1 : 0) | (csplit == 2 ? 2 : 0) | (form << 2) | ((int)(regions * csplit) << 8);
 }
 
 int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,

@@ -1052,10 +1052,16 @@ def _wino_ok(B, n_in, n_out, Ho, Wo, allow_split=True, allow_sk=False):
     regions *= -(-n_out // 64)
     nch = n_in // 8
     split = 2 if (allow_split and regions < 192 and nch % 2 == 0 and nch >= 6) else 1      # mirrors launch_split()
-    if allow_split and WINO_SK and regions * nch >= 8 * _WINO_MIN_ITEMS:
-        return True     # stream-K (_wino_conv): >= 8 channel chunks for each of >= 200 workgroups, however few the regions
-    if allow_sk and WINO_SK and regions < 200 and regions * nch >= 8 * _WINO_MIN_ITEMS:
-        return True     # the same under the fused epilogue (_k10_act): launches of few regions only, see launch_split()
+    if WINO_SK and (allow_split or allow_sk) and regions * nch >= 8 * _WINO_MIN_ITEMS:
+        # enough (item, chunk) units for the stream-K form -- IF the library takes it for this shape: its own decision is asked
+        # (dmh_wino_conv3x3_plan: cost model, workspace size, the fused epilogue's few-regions rule), not mirrored here
+        try:
+            ws_floats = _sk_ws_floats(torch.cuda.current_device()) if torch.cuda.is_available() else 2 * 256 * _SK_SLOT_FLOATS
+        except Exception:
+            ws_floats = 2 * 256 * _SK_SLOT_FLOATS
+        plan = N.lib().dmh_wino_conv3x3_plan(B, n_in, n_out, Ho, Wo, 1, 0 if allow_split else 1, ws_floats)
+        if plan >= 0 and (plan & 1):
+            return True
     return regions * split >= (_WINO_MIN_ITEMS if WINO_SK else max(_WINO_MIN_ITEMS, 200))     # whole items only: round 4's threshold
 
 
@@ -1122,7 +1128,12 @@ def _wino32_conv(x, U, bias, K, pad):
 
 
 _sk_ws = {}         # (device, stream) -> workspace of the stream-K launches (caller-owned: the library keeps nothing)
-_SK_WS_FLOATS = 8 << 20         # 32 MB = 2 slots x 256 workgroups x 16,384 floats (one partial work item each)
+_SK_SLOT_FLOATS = 16384         # one partial work item: 16 output channels x 256 threads x float4
+
+
+def _sk_ws_floats(device):
+    """2 slots per workgroup, one workgroup per CU (MI355X: 256 CUs = 32 MB): sized from the device, not assumed."""
+    return 2 * torch.cuda.get_device_properties(device).multi_processor_count * _SK_SLOT_FLOATS
 
 
 def _sk_workspace(device):
@@ -1133,7 +1144,7 @@ def _sk_workspace(device):
     key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     ws = _sk_ws.get(key)
     if ws is None:
-        ws = _sk_ws[key] = torch.empty(_SK_WS_FLOATS, device=device, dtype=torch.float32)
+        ws = _sk_ws[key] = torch.empty(_sk_ws_floats(device), device=device, dtype=torch.float32)
     return ws
 
 
@@ -1475,8 +1486,10 @@ def _down_image(w3, wd):
     def make():
         img = torch.empty(lib.dmh_down_conv_image_size(rows, inner), device=w3.device, dtype=torch.float32)
         N.check(lib.dmh_down_conv_weight_image(N.ptr(w3), N.ptr(wd), rows, inner, N.ptr(img), N.stream()))
-        return img
-    return frozen_memo(("down_img", w3.data_ptr(), w3._version, None if wd is None else (wd.data_ptr(), wd._version)), make)
+        # the entry keeps its source tensors: a caller may hand in a temporary (a contiguous copy of a channels_last parameter),
+        # and a freed temporary's address could come to name another layer's data with the same version inside one scope
+        return img, w3, wd
+    return frozen_memo(("down_img", w3.data_ptr(), w3._version, None if wd is None else (wd.data_ptr(), wd._version)), make)[0]
 
 
 def _k15_fwd(lib, x, w3, wd, shift3, shiftd, relu3, B, Cin, Cout, H, W, y3, yd, stream):

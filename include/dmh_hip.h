@@ -464,6 +464,11 @@ int dmh_wino_conv3x3(const float* x, const float* U, const float* bias, int B, i
  * where a cost model says it is faster; NULL / too small a workspace = dmh_wino_conv3x3. */
 int dmh_wino_conv3x3_ws(const float* x, const float* U, const float* bias, int B, int C, int K, int H, int W, int pad,
                         float* y, float* workspace, int64_t workspace_floats, void* stream);
+/* What a dmh_wino_conv3x3(_act)_ws call of this shape would do, WITHOUT launching: -1 for a shape the kernel does not take, else
+ * bit 0: stream-K form, bit 1: two-way channel split, bits 2-3: tile regions (0: 2 x 32 per image, 1: 4 x 16 per image, 2: 4 x 16
+ * over the flattened batch), bits 8...: work items.  `epilogue` != 0 asks for the _act form; workspace_floats = the size the
+ * caller would pass (0: none).  The caller's dispatch rule (ops._wino_ok) asks this instead of mirroring the decision. */
+int dmh_wino_conv3x3_plan(int B, int C, int K, int H, int W, int pad, int epilogue, int64_t workspace_floats);
 /* conv -> BatchNorm(eval) -> (+ identity) -> ReLU of a BasicBlock in one launch (torchvision BasicBlock.forward under
  * MD2/networks/resnet_encoder.py:85-98, model in eval()): the per-channel scale is folded into the filter by
  * weight_transform_scaled (backward != 0: into the filter of the backward-data pass, whose input is then the masked

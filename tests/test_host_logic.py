@@ -168,6 +168,25 @@ def test_step_log_reports_device_time_not_enqueue_time(tmp_path):
         assert line["device_ms"] == pytest.approx(total, abs=0.01)
 
 
+def test_the_library_reports_its_own_launch_plan():
+    """dmh_wino_conv3x3_plan: what a K10 call of a shape would do (tile regions, work items, two-way split, stream-K), asked by
+    ops._wino_ok instead of mirrored (pure host logic: no launch, no GPU)."""
+    from depthmodelhardening_amd import _native as N, ops
+    lib = N.lib()
+    ws = 2 * 256 * 16384
+    p = lib.dmh_wino_conv3x3_plan(12, 64, 64, 80, 256, 1, 1, ws)            # layer1, attack batch, fused epilogue
+    assert p >= 0 and (p & 3) == 0 and ((p >> 2) & 3) == 0 and (p >> 8) == 12 * 20 * 4          # 960 whole items, 2 x 32 regions
+    p = lib.dmh_wino_conv3x3_plan(12, 512, 256, 12, 34, 0, 0, ws)           # upconv(4,0): 60 regions of 4 x 16 tiles over the batch
+    assert p >= 0 and (p & 1) == 1 and ((p >> 2) & 3) == 2 and (p >> 8) == 60
+    p = lib.dmh_wino_conv3x3_plan(12, 512, 256, 12, 34, 0, 0, 0)            # ... without a workspace: the two-way channel split
+    assert p >= 0 and (p & 3) == 2 and (p >> 8) == 120
+    p = lib.dmh_wino_conv3x3_plan(12, 512, 512, 10, 32, 1, 1, ws)           # layer4 under the epilogue: few regions -> stream-K
+    assert p >= 0 and (p & 1) == 1
+    assert lib.dmh_wino_conv3x3_plan(12, 20, 64, 80, 256, 1, 0, ws) == -1   # input channels not a multiple of 8
+    assert lib.dmh_wino_conv3x3_plan(12, 64, 64, 81, 256, 1, 0, ws) == -1   # odd output height
+    assert ops._wino_ok(12, 512, 256, 10, 32) and ops._wino_ok(12, 512, 512, 10, 32, allow_split=False, allow_sk=True)
+
+
 def test_conv_dispatch_rule_mirrors_the_launcher():
     """ops._wino_ok / _small_ok: which 3x3 convolutions of a step go to K10 / K11 (pure host logic)."""
     from depthmodelhardening_amd import ops
