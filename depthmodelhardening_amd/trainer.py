@@ -179,9 +179,9 @@ class Trainer:
         if self.opt.predictive_mask:
             assert self.opt.disable_automasking, \
                 "When using predictive_mask, please disable automasking with --disable_automasking"    # MD2/trainer.py:123-125
-            if self.opt.loss_variant != "md2" or self.opt.v1_multiscale:
-                raise NotImplementedError("--predictive_mask is served at the frame's resolution by Monodepth2's loss "
-                                          "(MD2/trainer.py:623-635)")
+            if self.opt.v1_multiscale:
+                raise NotImplementedError("--predictive_mask is served at the frame's resolution "
+                                          "(MD2/trainer.py:623-635, DH/trainer.py:674-687)")
         if self.opt.use_depth_hints and (self.opt.loss_variant != "dh" or self.opt.disable_automasking):
             raise RuntimeError("--use_depth_hints is the DepthHints trainer's option: use --loss_variant dh with "
                                "auto-masking (DH/trainer.py:71-75,557-590)")
@@ -470,9 +470,8 @@ class Trainer:
         if self.opt.v1_multiscale:
             return self._losses_v1_multiscale(inputs, outputs, losses, total_loss, frames)
         if self.opt.predictive_mask or (self.opt.avg_reprojection and len(frames) > 1):
-            if self.opt.loss_variant != "md2":      # DepthHints forms its masks differently (DH/trainer.py:667-712): not composed here
-                raise NotImplementedError("--predictive_mask / --avg_reprojection over several source frames: Monodepth2's loss "
-                                          "only (--loss_variant md2)")
+            if self.opt.loss_variant != "md2":      # DepthHints forms its masks differently (DH/trainer.py:667-712)
+                return self._losses_composed_dh(inputs, outputs, losses, total_loss, frames)
             return self._losses_composed(inputs, outputs, losses, total_loss, frames)
         out = ops.photometric_smooth_loss(
             inputs[("color", 0, 0)], [inputs[("color", f, 0)] for f in frames],
@@ -559,6 +558,80 @@ class Trainer:
             if automask:
                 outputs["identity_selection/{}".format(scale)] = (idxs > ident.shape[1] - 1).float()
             loss = loss + to_optimise.mean()
+            norm_disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
+            loss = loss + self.opt.disparity_smoothness * get_smooth_loss(norm_disp, inputs[("color", 0, scale)]) / (2 ** scale)
+            losses["loss/{}".format(scale)] = loss
+            per_scale.append(loss)
+        total_loss = total_loss + sum(per_scale) / self.num_scales
+        losses["loss"] = total_loss
+        return losses
+
+    def _losses_composed_dh(self, inputs, outputs, losses, total_loss, frames):
+        """The same option branches in DepthHints' per-scale body (DH/trainer.py:638-741), composed like _losses_composed.  What
+        differs from Monodepth2's: the candidates are reduced over the source frames first (the minimum "as we go", :668-671 /
+        :693-697, or the mean with --avg_reprojection), the tie-break noise has one channel, compute_loss_masks (:559-590) turns the
+        argmin over [reprojection, identity, hint reprojection] into masks -- without auto-masking every pixel counts -- and the
+        photometric term of a scale is sum(loss * mask) / (sum(mask) + 1e-7); --predictive_mask multiplies the per-frame losses
+        before the reduction and adds 0.2 * BCE(mask, 1); --use_depth_hints adds the hint candidate (warped once, with the stereo
+        pose, :510-525) and the proxy log-L1 term where it wins (:716-727)."""
+        target = inputs[("color", 0, 0)]
+        B, _, H, W = target.shape
+        automask = not self.opt.disable_automasking
+        hint_reproj = None
+        if self.opt.use_depth_hints:
+            if not automask:    # the reference's compute_loss_masks evaluates `if <tensor>:` there and raises (:568)
+                raise RuntimeError("--use_depth_hints with --disable_automasking: DepthHints' compute_loss_masks cannot form its "
+                                   "masks (depth-hints/trainer.py:568)")
+            if "s" not in frames:
+                raise KeyError(("color_depth_hint", "s", 0))        # the hint is only warped for the stereo frame (:513)
+            from .layers import BackprojectDepth, Project3D
+            cam = BackprojectDepth(B, H, W).to(target.device)(inputs["depth_hint"], inputs[("inv_K", 0)])
+            grid = Project3D(B, H, W).to(target.device)(cam, inputs[("K", 0)], inputs["stereo_T"])
+            pred = F.grid_sample(inputs[("color", "s", 0)], grid, padding_mode="border", align_corners=False)
+            outputs[("color_depth_hint", "s", 0)] = pred
+            hint_reproj = self.compute_reprojection_loss(pred, target) + 1000 * (1 - inputs["depth_hint_mask"])
+        per_scale = []
+        for scale in self.opt.scales:
+            loss = 0
+            disp = outputs[("disp", scale)]
+            reproj = []
+            for f in frames:
+                key = ("color", f, scale)
+                if key not in outputs or ("depth", 0, scale) not in outputs:
+                    depth, _, pred = ops.warp_view(inputs[("color", f, 0)], disp, inputs[("K", 0)], inputs[("inv_K", 0)],
+                                                   self._frame_T(inputs, outputs, f), H, W, self.opt.min_depth, self.opt.max_depth)
+                    outputs.setdefault(("depth", 0, scale), depth)
+                pred = outputs[key] if key in outputs else pred
+                reproj.append(self.compute_reprojection_loss(pred, target))
+            reproj = torch.cat(reproj, 1)
+            ident = None
+            if automask:
+                ident = torch.cat([self.compute_reprojection_loss(inputs[("color", f, 0)], target) for f in frames], 1)
+                ident = ident.mean(1, keepdim=True) if self.opt.avg_reprojection else torch.min(ident, dim=1, keepdim=True)[0]
+            elif self.opt.predictive_mask:
+                mask = F.interpolate(outputs["predictive_mask"][("disp", scale)], [H, W], mode="bilinear", align_corners=False)
+                reproj = reproj * mask
+                loss = loss + 0.2 * F.binary_cross_entropy(mask, torch.ones_like(mask))     # pushes the mask to 1
+            reproj = reproj.mean(1, keepdim=True) if self.opt.avg_reprojection else torch.min(reproj, dim=1, keepdim=True)[0]
+            if automask:
+                ident = ident + torch.randn(ident.shape, device=ident.device) * 0.00001     # breaks ties
+                cands = [reproj, ident] + ([hint_reproj] if hint_reproj is not None else [])
+                idxs = torch.argmin(torch.cat(cands, dim=1), dim=1, keepdim=True)
+                rmask = (idxs != 1).float()         # the auto-mask is candidate 1
+            else:
+                rmask = torch.ones_like(reproj)
+            reproj_loss = (reproj * rmask).sum() / (rmask.sum() + 1e-7)
+            outputs["identity_selection/{}".format(scale)] = (1 - rmask).float()
+            losses["reproj_loss/{}".format(scale)] = reproj_loss
+            loss = loss + reproj_loss
+            if hint_reproj is not None:
+                hmask = (idxs == 2).float()
+                hint_loss = torch.log(torch.abs(inputs["depth_hint"] - outputs[("depth", 0, scale)]) + 1) \
+                    * inputs["depth_hint_mask"] * hmask
+                hint_loss = hint_loss.sum() / (hmask.sum() + 1e-7)
+                outputs["depth_hint_pixels/{}".format(scale)] = hmask
+                losses["depth_hint_loss/{}".format(scale)] = hint_loss
+                loss = loss + hint_loss
             norm_disp = disp / (disp.mean(2, True).mean(3, True) + 1e-7)
             loss = loss + self.opt.disparity_smoothness * get_smooth_loss(norm_disp, inputs[("color", 0, scale)]) / (2 ** scale)
             losses["loss/{}".format(scale)] = loss

@@ -251,6 +251,67 @@ def compute_losses_options(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2,
     return losses, maps
 
 
+def compute_losses_options_dh(inputs, outputs, frame_ids=(0, "s"), scales=(0, 1, 2, 3), noise=None, smooth_wt=SMOOTH_WT,
+                              automask=True, avg_reprojection=False, predictive_mask=None, use_depth_hints=False):
+    """The same option branches in DepthHints' per-scale body, depth-hints/trainer.py:638-741: the candidates are reduced over
+    the source frames FIRST (minimum "as we go", :668-671 / :693-697, or the mean with --avg_reprojection), the tie-break noise
+    has ONE channel (:699-702), the masks come from compute_loss_masks (:559-590: without auto-masking every pixel counts) and the
+    scale's photometric term is sum(loss * mask) / (sum(mask) + 1e-7) (:712-713); --predictive_mask multiplies the per-frame
+    losses before that reduction and adds 0.2 * BCE(mask, 1) (:674-687).  ``use_depth_hints`` (needs the stereo frame and
+    auto-masking: without it compute_loss_masks evaluates ``if <tensor>:`` and raises, :568) adds the hint candidate and the
+    proxy log-L1 term (:629-636, :716-727).  Needs outputs[("color", f, s)] and ("depth", 0, s) (generate_images_pred)."""
+    losses, maps = {}, {}
+    total = 0
+    H, W = inputs[("color", 0, 0)].shape[-2:]
+    target = inputs[("color", 0, 0)]
+    hint_reproj = None
+    if use_depth_hints:
+        assert automask and "s" in frame_ids[1:]
+        pred = warp_hint(inputs["depth_hint"], inputs[("color", "s", 0)], inputs[("K", 0)], inputs[("inv_K", 0)],
+                         inputs["stereo_T"], H, W)
+        outputs[("color_depth_hint", "s", 0)] = pred
+        hint_reproj = compute_reprojection_loss(pred, target) + 1000 * (1 - inputs["depth_hint_mask"])
+    for scale in scales:
+        loss = 0
+        disp = outputs[("disp", scale)]
+        color = inputs[("color", 0, scale)]
+        reproj = torch.cat([compute_reprojection_loss(outputs[("color", f, scale)], target) for f in frame_ids[1:]], 1)
+        ident = None
+        if automask:
+            ident = torch.cat([compute_reprojection_loss(inputs[("color", f, 0)], target) for f in frame_ids[1:]], 1)
+            ident = ident.mean(1, keepdim=True) if avg_reprojection else torch.min(ident, dim=1, keepdim=True)[0]
+        elif predictive_mask is not None:
+            mask = F.interpolate(predictive_mask[scale], [H, W], mode="bilinear", align_corners=False)
+            reproj = reproj * mask
+            loss = loss + 0.2 * F.binary_cross_entropy(mask, torch.ones_like(mask))
+        reproj = reproj.mean(1, keepdim=True) if avg_reprojection else torch.min(reproj, dim=1, keepdim=True)[0]
+        if automask:
+            if noise is not None:
+                ident = ident + noise[scale]
+            cands = [reproj, ident] + ([hint_reproj] if hint_reproj is not None else [])
+            idxs = torch.argmin(torch.cat(cands, dim=1), dim=1, keepdim=True)
+            rmask = (idxs != 1).float()
+        else:
+            rmask = torch.ones_like(reproj)
+        rl = (reproj * rmask).sum() / (rmask.sum() + 1e-7)
+        outputs["identity_selection/{}".format(scale)] = (1 - rmask).float()
+        losses["reproj_loss/{}".format(scale)] = rl
+        maps[scale] = reproj * rmask
+        loss = loss + rl
+        if hint_reproj is not None:
+            hmask = (idxs == 2).float()
+            hl = torch.log(torch.abs(inputs["depth_hint"] - outputs[("depth", 0, scale)]) + 1) * inputs["depth_hint_mask"] * hmask
+            hl = hl.sum() / (hmask.sum() + 1e-7)
+            outputs["depth_hint_pixels/{}".format(scale)] = hmask
+            losses["depth_hint_loss/{}".format(scale)] = hl
+            loss = loss + hl
+        loss = loss + smooth_wt * normalised_smooth_loss(disp, color) / (2 ** scale)
+        total = total + loss
+        losses["loss/{}".format(scale)] = loss
+    losses["loss"] = total / len(scales)
+    return losses, maps
+
+
 def v1_multiscale_losses(inputs, disps, noise=None, smooth_wt=SMOOTH_WT):
     """--v1_multiscale (trainer.py:478-483,593-596): every scale is warped, compared and smoothed at its own resolution
     with the intrinsics of that scale; loss = mean_s(loss_s), loss_s = mean(min(identity, reprojection)) + wt *

@@ -269,17 +269,24 @@ def gold_v1_multiscale(trainer_mod, layers):
     save("loss_md2_v1ms", **keep)
 
 
-def gold_options(trainer_mod, layers):
-    """The option branches of MD2's per-scale loss body (trainer.py:608-658): --predictive_mask (with --disable_automasking,
-    one and two source frames) and --avg_reprojection over two source frames (auto-masking on, recorded tie-break noise)."""
-    from oracle.synth import options_case
+def gold_options(trainer_mod, layers, tag="md2"):
+    """The option branches of the per-scale loss body (MD2 trainer.py:608-658; tag "dh": depth-hints/trainer.py:638-741, which
+    reduces over the frames first and normalises by its masks): --predictive_mask (with --disable_automasking, one and two source
+    frames) and --avg_reprojection over two source frames (auto-masking on, recorded tie-break noise); DepthHints also with
+    --use_depth_hints beside --avg_reprojection (frames -1 and "s": the hint is warped with the stereo pose)."""
+    from oracle.synth import options_case, make_depth_hint
     B, H, W, seed = 2, 32, 96, 33
-    for name, frames, kw in (("pmask", ["s"], dict(disable_automasking=True, predictive_mask=True)),
-                             ("pmask2", [-1, "s"], dict(disable_automasking=True, predictive_mask=True)),
-                             ("avg2", [-1, 1], dict(avg_reprojection=True)),
-                             ("avg2_noauto", [-1, 1], dict(avg_reprojection=True, disable_automasking=True))):
+    cases = [("pmask", ["s"], dict(disable_automasking=True, predictive_mask=True)),
+             ("pmask2", [-1, "s"], dict(disable_automasking=True, predictive_mask=True)),
+             ("avg2", [-1, 1], dict(avg_reprojection=True)),
+             ("avg2_noauto", [-1, 1], dict(avg_reprojection=True, disable_automasking=True))]
+    if tag == "dh":
+        cases.append(("avg2s_hints", [-1, "s"], dict(avg_reprojection=True, use_depth_hints=True)))
+    for name, frames, kw in cases:
         inputs, disps, poses, masks = options_case(B, H, W, seed, frames)
-        self, T = _fake_trainer(trainer_mod, layers, B, H, W, "md2")
+        if kw.get("use_depth_hints"):
+            inputs["depth_hint"], inputs["depth_hint_mask"] = make_depth_hint(B, H, W, seed + 50)
+        self, T = _fake_trainer(trainer_mod, layers, B, H, W, tag)
         self.opt.frame_ids = [0] + frames
         for k, v in kw.items():
             setattr(self.opt, k, v)
@@ -320,7 +327,12 @@ def gold_options(trainer_mod, layers):
                 keep["grad_mask_%d" % s] = mleaves[s].grad
             if "identity_selection/%d" % s in outputs:
                 keep["identity_selection_%d" % s] = np.packbits(outputs["identity_selection/%d" % s].numpy().astype(np.uint8))
-        save("loss_md2_opt_%s" % name, **keep)
+            for k in ("reproj_loss", "depth_hint_loss"):
+                if "%s/%d" % (k, s) in losses:
+                    keep["%s_%d" % (k, s)] = losses["%s/%d" % (k, s)]
+            if "depth_hint_pixels/%d" % s in outputs:
+                keep["depth_hint_pixels_%d" % s] = np.packbits(outputs["depth_hint_pixels/%d" % s].numpy().astype(np.uint8))
+        save("loss_%s_opt_%s" % (tag, name), **keep)
 
 
 def gold_depth_hints(trainer_mod, layers):
@@ -621,6 +633,8 @@ def main():
         gold_losses(dh_trainer, dh_layers, "dh")
     if want("hints"):
         gold_depth_hints(dh_trainer, dh_layers)
+    if want("options") or want("options_dh"):
+        gold_options(dh_trainer, dh_layers, "dh")
 
 
 if __name__ == "__main__":

@@ -1243,7 +1243,7 @@ def _options_self(frames, H, W, **kw):
     for k, v in kw.items():
         setattr(opt, k, v)
     me = SimpleNamespace(opt=opt, num_scales=4, _ssim=None)
-    for name in ("compute_reprojection_loss", "_frame_T", "_losses_composed", "_losses_v1_multiscale"):
+    for name in ("compute_reprojection_loss", "_frame_T", "_losses_composed", "_losses_composed_dh", "_losses_v1_multiscale"):
         setattr(me, name, getattr(Trainer, name).__get__(me))
     return me
 
@@ -1263,20 +1263,25 @@ def _anchored(name, got, ref32, g64, floor=1e-6):
     assert int(out_h.sum()) <= int(out_r.sum()) + max(8, int(2e-3 * g64.numel())), (name, int(out_h.sum()), int(out_r.sum()))
 
 
-@pytest.mark.parametrize("name", ["pmask", "pmask2", "avg2", "avg2_noauto"])
-def test_option_branches_vs_reference(golden, monkeypatch, name):
+@pytest.mark.parametrize("variant,name", [("md2", "pmask"), ("md2", "pmask2"), ("md2", "avg2"), ("md2", "avg2_noauto"),
+                                          ("dh", "pmask"), ("dh", "pmask2"), ("dh", "avg2"), ("dh", "avg2_noauto"),
+                                          ("dh", "avg2s_hints")])
+def test_option_branches_vs_reference(golden, monkeypatch, variant, name):
     """--predictive_mask (one / two source frames, --disable_automasking) and --avg_reprojection over two source frames
-    (MD2/trainer.py:608-658) through Trainer.compute_losses -> _losses_composed (warp kernel + ssim_map + smooth_loss
-    operators), against the REFERENCE's own run of the same inputs (tests/golden/loss_md2_opt_*.npz): losses 2e-5, disparity
-    gradients like the fused path's, mask gradients 1e-4."""
+    (MD2/trainer.py:608-658; DepthHints' form of the body, DH/trainer.py:638-741, also beside --use_depth_hints) through
+    Trainer.compute_losses -> _losses_composed / _losses_composed_dh (warp kernel + ssim_map + smooth_loss operators), against the
+    REFERENCE's own run of the same inputs (tests/golden/loss_<variant>_opt_*.npz): losses 2e-5, disparity gradients like the
+    fused path's, mask gradients 1e-4."""
     from depthmodelhardening_amd.trainer import Trainer
-    from oracle.synth import options_case
+    from oracle.synth import options_case, make_depth_hint
     from tests.test_oracle_golden import OPTION_CASES, run_oracle_options
     from tests.util import to_dev
     frames, kw = OPTION_CASES[name]
-    g = golden("loss_md2_opt_" + name)
+    g = golden("loss_%s_opt_%s" % (variant, name))
     B, H, W, seed = [int(v) for v in g["shape"]]
     inputs, disps, poses, masks = options_case(B, H, W, seed, frames)
+    if kw.get("use_depth_hints"):
+        inputs["depth_hint"], inputs["depth_hint_mask"] = make_depth_hint(B, H, W, seed + 50)
     inputs = to_dev(inputs)
     outputs = {("cam_T_cam", 0, f): P.cuda() for f, P in poses.items()}
     leaves = [d.cuda().requires_grad_(True) for d in disps]
@@ -1286,8 +1291,9 @@ def test_option_branches_vs_reference(golden, monkeypatch, name):
     if kw.get("with_mask"):
         mleaves = [m.cuda().requires_grad_(True) for m in masks]
         outputs["predictive_mask"] = {("disp", s): m for s, m in enumerate(mleaves)}
-    me = _options_self(frames, H, W, disable_automasking=not kw.get("automask", True),
-                       avg_reprojection=kw.get("avg_reprojection", False), predictive_mask=bool(kw.get("with_mask")))
+    me = _options_self(frames, H, W, disable_automasking=not kw.get("automask", True), loss_variant=variant,
+                       avg_reprojection=kw.get("avg_reprojection", False), predictive_mask=bool(kw.get("with_mask")),
+                       use_depth_hints=bool(kw.get("use_depth_hints")))
     gen = torch.Generator().manual_seed(seed + 100)
     queue = [torch.randn(B, 1, H, W, generator=gen) for _ in range(4)]
     real_randn = torch.randn
@@ -1300,22 +1306,28 @@ def test_option_branches_vs_reference(golden, monkeypatch, name):
     assert abs(float(losses["loss"].detach()) - ref) <= 2e-5 * abs(ref), (float(losses["loss"].detach()), ref)
     # disparity gradients: the fp32 reference is itself 1e-3 ... 1e-2 from exact arithmetic (bilinear floor() flips, min ties);
     # both are measured against the float64 oracle, as tests/util.py::GradPool does for the fused path
-    _, _, leaves64, mleaves64 = run_oracle_options(name, torch.float64)
+    _, _, leaves64, mleaves64 = run_oracle_options(name, torch.float64, variant=variant)
     for s in range(4):
         assert abs(float(losses["loss/%d" % s].detach()) - float(g["loss_%d" % s])) <= 2e-5 * abs(float(g["loss_%d" % s]))
-        _anchored("%s grad_disp[%d]" % (name, s), leaves[s].grad, g["grad_disp_%d" % s], leaves64[s].grad)
+        for k in ("reproj_loss", "depth_hint_loss"):
+            if "%s_%d" % (k, s) in g:
+                r_ = float(g["%s_%d" % (k, s)])
+                assert abs(float(losses["%s/%d" % (k, s)].detach()) - r_) <= 2e-5 * abs(r_) + 1e-9, (k, s)
+        _anchored("%s %s grad_disp[%d]" % (variant, name, s), leaves[s].grad, g["grad_disp_%d" % s], leaves64[s].grad)
         if mleaves is not None:
-            _anchored("%s grad_mask[%d]" % (name, s), mleaves[s].grad, g["grad_mask_%d" % s], mleaves64[s].grad, floor=1e-7)
-        if "identity_selection_%d" % s in g:
-            sel = np.unpackbits(g["identity_selection_%d" % s])[:B * H * W].reshape(B, H, W)
-            assert (outputs["identity_selection/%d" % s].cpu().numpy() != sel).mean() <= 2e-3
+            _anchored("%s %s grad_mask[%d]" % (variant, name, s), mleaves[s].grad, g["grad_mask_%d" % s], mleaves64[s].grad, floor=1e-7)
+        for key in ("identity_selection", "depth_hint_pixels"):
+            if "%s_%d" % (key, s) in g:
+                sel = np.unpackbits(g["%s_%d" % (key, s)])[:B * H * W].reshape(B, H, W)
+                assert (outputs["%s/%d" % (key, s)].cpu().numpy().reshape(B, H, W) != sel).mean() <= 2e-3, (key, s)
 
 
-def test_trainer_predictive_mask_step(tmp_path):
-    """--predictive_mask --disable_automasking through the Trainer (MD2/trainer.py:123-133,362-363,623-635): the second decoder
-    exists, its masks reach the loss, a step trains it, the checkpoint holds it; without --disable_automasking the reference's
-    assertion fires."""
-    tr = _trainer(tmp_path, ["--predictive_mask", "--disable_automasking"])
+@pytest.mark.parametrize("variant", ["md2", "dh"])
+def test_trainer_predictive_mask_step(tmp_path, variant):
+    """--predictive_mask --disable_automasking through the Trainer (MD2/trainer.py:123-133,362-363,623-635; DepthHints' loss:
+    DH/trainer.py:674-687): the second decoder exists, its masks reach the loss, a step trains it, the checkpoint holds it; without
+    --disable_automasking the reference's assertion fires."""
+    tr = _trainer(tmp_path, ["--predictive_mask", "--disable_automasking", "--loss_variant", variant])
     assert "predictive_mask" in tr.models and tr.models["predictive_mask"].num_output_channels == 1
     tr.set_train()
     inputs = tr.dataset.next_batch(2)

@@ -435,17 +435,22 @@ def test_v1_multiscale_oracle_vs_reference(golden):
 OPTION_CASES = {"pmask": (["s"], dict(automask=False, with_mask=True)),
                 "pmask2": ([-1, "s"], dict(automask=False, with_mask=True)),
                 "avg2": ([-1, 1], dict(avg_reprojection=True)),
-                "avg2_noauto": ([-1, 1], dict(avg_reprojection=True, automask=False))}
+                "avg2_noauto": ([-1, 1], dict(avg_reprojection=True, automask=False)),
+                "avg2s_hints": ([-1, "s"], dict(avg_reprojection=True, use_depth_hints=True))}     # DepthHints only
+OPTION_RUNS = [("md2", n) for n in ("pmask", "pmask2", "avg2", "avg2_noauto")] + [("dh", n) for n in sorted(OPTION_CASES)]
 
 
-def run_oracle_options(name, dtype=torch.float32):
-    """The oracle on the inputs of tests/golden/loss_md2_opt_<name>.npz; returns (losses, outputs, disparity leaves, mask leaves)."""
-    from oracle.synth import options_case
+def run_oracle_options(name, dtype=torch.float32, variant="md2"):
+    """The oracle on the inputs of tests/golden/loss_<variant>_opt_<name>.npz; returns (losses, outputs, disparity leaves, mask
+    leaves)."""
+    from oracle.synth import options_case, make_depth_hint
     frames, kw = OPTION_CASES[name]
     kw = dict(kw)
     with_mask = kw.pop("with_mask", False)
     B, H, W, seed = 2, 32, 96, 33
     inputs, disps, poses, masks = options_case(B, H, W, seed, frames)
+    if kw.get("use_depth_hints"):
+        inputs["depth_hint"], inputs["depth_hint_mask"] = make_depth_hint(B, H, W, seed + 50)
     inputs = {k: v.to(dtype) for k, v in inputs.items()}
     outputs = {("cam_T_cam", 0, f): P.to(dtype) for f, P in poses.items()}
     leaves = [d.clone().to(dtype).requires_grad_(True) for d in disps]
@@ -456,27 +461,33 @@ def run_oracle_options(name, dtype=torch.float32):
     noise = {s: (torch.randn(B, 1, H, W, generator=gen) * 0.00001).to(dtype) for s in range(4)}
     fids = tuple([0] + frames)
     loss_ref.generate_images_pred(inputs, outputs, frame_ids=fids)
-    losses, _ = loss_ref.compute_losses_options(inputs, outputs, frame_ids=fids, noise=noise,
-                                                predictive_mask=dict(enumerate(mleaves)) if with_mask else None, **kw)
+    fn = loss_ref.compute_losses_options if variant == "md2" else loss_ref.compute_losses_options_dh
+    losses, _ = fn(inputs, outputs, frame_ids=fids, noise=noise,
+                   predictive_mask=dict(enumerate(mleaves)) if with_mask else None, **kw)
     losses["loss"].backward()
     return losses, outputs, leaves, mleaves
 
 
-@pytest.mark.parametrize("name", sorted(OPTION_CASES))
-def test_option_branches_oracle_vs_reference(golden, name):
+@pytest.mark.parametrize("variant,name", OPTION_RUNS)
+def test_option_branches_oracle_vs_reference(golden, variant, name):
     """--predictive_mask (one and two source frames) and --avg_reprojection over two source frames, with and without
-    auto-masking (MD2/trainer.py:608-658): the restatement against the reference's own run."""
-    g = golden("loss_md2_opt_" + name)
+    auto-masking (MD2/trainer.py:608-658; DepthHints' form of the same body, depth-hints/trainer.py:638-741, also with
+    --use_depth_hints): the restatement against the reference's own run."""
+    g = golden("loss_%s_opt_%s" % (variant, name))
     B, H, W, _ = [int(v) for v in g["shape"]]
-    losses, outputs, leaves, mleaves = run_oracle_options(name)
+    losses, outputs, leaves, mleaves = run_oracle_options(name, variant=variant)
     torch.testing.assert_close(losses["loss"].detach(), t(g["loss"]), rtol=1e-6, atol=0)
     for s in range(4):
         torch.testing.assert_close(losses["loss/%d" % s].detach(), t(g["loss_%d" % s]), rtol=1e-6, atol=0)
+        for k in ("reproj_loss", "depth_hint_loss"):
+            if "%s_%d" % (k, s) in g:
+                torch.testing.assert_close(losses["%s/%d" % (k, s)].detach(), t(g["%s_%d" % (k, s)]), rtol=1e-6, atol=0)
         ref = t(g["grad_disp_%d" % s])
         bad = ((leaves[s].grad - ref).abs() > 1e-5 * ref.abs().max() + 1e-4 * ref.abs()).float().mean().item()
         assert bad <= 2e-3, (name, s, bad)
         if mleaves is not None:
             torch.testing.assert_close(mleaves[s].grad, t(g["grad_mask_%d" % s]), rtol=1e-4, atol=1e-9)
-        if "identity_selection_%d" % s in g:
-            sel = np.unpackbits(g["identity_selection_%d" % s])[:B * H * W].reshape(B, H, W)
-            assert (outputs["identity_selection/%d" % s].numpy() != sel).mean() <= 1e-3
+        for key in ("identity_selection", "depth_hint_pixels"):
+            if "%s_%d" % (key, s) in g:
+                sel = np.unpackbits(g["%s_%d" % (key, s)])[:B * H * W].reshape(B, H, W)
+                assert (outputs["%s/%d" % (key, s)].numpy().reshape(B, H, W) != sel).mean() <= 1e-3
