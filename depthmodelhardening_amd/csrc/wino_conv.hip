@@ -146,6 +146,41 @@ __global__ __launch_bounds__(NT) void wino_weight_batch_kernel(const WtBatch b) 
                         ((int)blockIdx.x - b.first[j]) * NT + (int)threadIdx.x);
 }
 
+// DMH_WINO_PK (round 6): the input transform B^T d B on PACKED fp32 adds.  A thread transforms the patches of TWO channels of
+// one tile; the raw region keeps the rows of such a channel pair INTERLEAVED ([pair][row][channel of the pair][word]), so that the
+// same patch element of both channels is one ds_read2_b32 (offsets j, j + row pitch) into a register pair, both passes of the
+// transform are v_pk_add_f32 on such pairs (32 instructions instead of 64 -- the fp32 MFMA shadows no vector instruction, so
+// they come straight off the chunk time), and the results are the (channel, channel + 1) pairs the 8-byte image writes want.
+// Same additions in the same order: bit-identical results.
+#ifndef DMH_WINO_PK
+#define DMH_WINO_PK 1
+#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// as asm: hipcc splits the <2 x float> additions of the transform into v_add_f32 pairs (its own v_pk_add_f32 patterns lose to the
+// scalar form once the operands come out of ds_read2_b32)
+__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// 16-byte words of one channel's raw region (rows x words per row), and the channel pitch in words
+template <int TRW, bool FLAT>
+struct RawGeo {
+    static constexpr int TRH = 64 / TRW;
+    static constexpr int NWR = (2 * TRW + 2 + 6) / 4;
+    static constexpr int RH = FLAT ? 4 * TRH : 2 * TRH + 2;
+    static constexpr int CHW = RH * NWR;
+    static constexpr int CHPW = CHW;
+    static constexpr int RAWN = CK * CHPW;
+    static constexpr size_t SMEM = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
+    static_assert(SMEM <= 160 * 1024, "LDS");
+};
+
 // Decoded work item: 64 output channels x one TRH x TRW tile region of one image.  Items are numbered with the
 // output-channel group fastest and every workgroup takes a CONTIGUOUS range, so the channel groups of one region run
 // back to back on the same CU and re-read its input from L1/L2.
@@ -185,7 +220,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     constexpr int RWA = 4 * NWR;                            // LDS row pitch in floats
     constexpr int RH = FLAT ? 4 * TRH : 2 * TRH + 2;        // raw input rows of a work item (per channel)
     constexpr int TRS = (FLAT ? 4 : 2) * RWA;               // raw floats from one tile row to the next
-    constexpr int RAW_N = CK * RH * NWR;                    // words of one raw buffer
+    constexpr int CHPW = RawGeo<TRW, FLAT>::CHPW;           // words of one channel's raw region
+    constexpr int CHP = 4 * CHPW;                           // ... floats
+    constexpr int PKI = DMH_WINO_PK ? 2 : 1;                // DMH_WINO_PK: the rows of a channel pair are interleaved
+    constexpr int RAW_N = CK * CHPW;                        // words of one raw buffer
+    static_assert(RH * NWR == RawGeo<TRW, FLAT>::CHW, "raw geometry");
     constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;
     constexpr int RAW_BUF = FLAT ? 0 : RAW_N;               // words from raw buffer 0 to buffer 1 (FLAT: one buffer)
     constexpr int BUF = 16 * 2 * 64;                        // f32x4 words of one U or V image (32 KB)
@@ -224,7 +263,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int tly = lane / TRW, tlx = lane - tly * TRW;
     const int coff = (4 - (a.pad & 3)) & 3;                 // columns of the first word in front of the region
     const bool partial = a.pad > 0 && (a.W & 3) != 0;       // a word can straddle the right image edge
-    const float* rsrc = raw + (2 * wv) * (RH * RWA) + tly * TRS + 2 * tlx + coff;
+    const float* rsrc = raw + (2 * wv) * CHP + tly * (PKI * TRS) + 2 * tlx + coff;
     float* vdst = reinterpret_cast<float*>(V_lds + (wv >> 1) * 64 + lane) + 2 * (wv & 1);
     const int kb = wv & 1, tb = wv >> 1;
     const int aidx = (lane >> 5) * 64 + kb * 32 + (lane & 31);
@@ -266,7 +305,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         }                                                                                         \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
-            const int c = e / (RH * NWR), rem = e - c * (RH * NWR), rr = rem / NWR, xx = 4 * (rem - rr * NWR); \
+            /* LDS order: [channel][row][word]; DMH_WINO_PK: [channel pair][row][channel of the pair][word] */ \
+            const int cq = e / (PKI * CHPW), r1 = e - cq * (PKI * CHPW), rr = r1 / (PKI * NWR), r2 = r1 - rr * (PKI * NWR); \
+            const int c = PKI * cq + r2 / NWR, xx = 4 * (r2 % NWR);                               \
             int iy, bofs = cbase;                                                                 \
             bool okr = e < RAW_N;                                                                 \
             if (FLAT) {                                                                           \
@@ -352,7 +393,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             float d[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {       // 4-byte aligned only (coff is odd for pad 1): dword reads, paired by the compiler
-                const float* row = rsrc + ch * (RH * RWA) + i * RWA;
+                const float* row = DMH_WINO_PK ? rsrc + (2 * i + ch) * RWA : rsrc + ch * CHP + i * RWA;
                 d[i][0] = row[0]; d[i][1] = row[1]; d[i][2] = row[2]; d[i][3] = row[3];
             }
 #pragma unroll
@@ -405,7 +446,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             f32x4 ua[16], vb[16];
             ua[0] = Uc[0]; vb[0] = Vc[0];
             ua[1] = Uc[128]; vb[1] = Vc[128];
+#if DMH_WINO_PK
+            f32x2 D[4][4], T[4][4];         // (channel, channel + 1) pairs: patch elements, then B^T d
+#else
             float d[4][4], t[2][4][4];
+#endif
             __builtin_amdgcn_sched_barrier(0);
 #if DMH_WINO_ABLATE & 16
 #define DMH_MFMA(A, B, C) (C)
@@ -431,9 +476,37 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 if (sl < 8) {                               // filter chunk g+1 -> U[nxt] by LDS-DMA, one row per slot
                     if (!(DMH_WINO_ABLATE & 1)) DMH_WINO_GLDS_U_ROW(ucb, nxt, sl)
                 } else if (DMH_WINO_ABLATE & 2) {
+#if DMH_WINO_PK
+                } else if (sl < 22) {
+                    if (sl < 12) {              // column sl - 8 of BOTH channels' patches: one read per row = (channel, channel + 1)
+                        const int j = sl - 8;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float* e = rs + 2 * i * RWA + j;
+                            D[i][j] = f32x2{e[0], e[RWA]};
+                        }
+                    }
+                    if (sl >= 10 && sl < 14) {  // B^T d of the column read two slots earlier: four packed adds
+                        const int j = sl - 10;
+                        T[0][j] = pk_sub(D[0][j], D[2][j]);
+                        T[1][j] = pk_add(D[1][j], D[2][j]);
+                        T[2][j] = pk_sub(D[2][j], D[1][j]);
+                        T[3][j] = pk_sub(D[1][j], D[3][j]);
+                    }
+                    if (sl >= 14) {             // (B^T d) B: half an output row (2 positions) per slot -> V
+                        const int rr = (sl - 14) >> 1;
+                        if ((sl & 1) == 0) {
+                            *reinterpret_cast<f32x2*>(vd + (rr * 4 + 0) * 512) = pk_sub(T[rr][0], T[rr][2]);
+                            *reinterpret_cast<f32x2*>(vd + (rr * 4 + 1) * 512) = pk_add(T[rr][1], T[rr][2]);
+                        } else {
+                            *reinterpret_cast<f32x2*>(vd + (rr * 4 + 2) * 512) = pk_sub(T[rr][2], T[rr][1]);
+                            *reinterpret_cast<f32x2*>(vd + (rr * 4 + 3) * 512) = pk_sub(T[rr][1], T[rr][3]);
+                        }
+                    }
+#else
                 } else if ((sl >= 8 && sl < 12) || (sl >= 14 && sl < 18)) {   // raw patch row of channel 0 / 1
                     const int c2 = sl >= 14, i = c2 ? sl - 14 : sl - 8;
-                    const float* row = rs + c2 * (RH * RWA) + i * RWA;
+                    const float* row = rs + c2 * CHP + i * RWA;
                     d[i][0] = row[0]; d[i][1] = row[1]; d[i][2] = row[2]; d[i][3] = row[3];
                 } else if (sl == 12 || sl == 13 || sl == 18 || sl == 19) {    // rows of B^T d, two columns per slot
                     const int c2 = sl >= 18, j0 = 2 * (sl & 1);
@@ -453,6 +526,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         *reinterpret_cast<float2*>(vd + (rr * 4 + 2) * 512) = make_float2(t[0][rr][2] - t[0][rr][1], t[1][rr][2] - t[1][rr][1]);
                         *reinterpret_cast<float2*>(vd + (rr * 4 + 3) * 512) = make_float2(t[0][rr][1] - t[0][rr][3], t[1][rr][1] - t[1][rr][3]);
                     }
+#endif
                 }
                 if (FLAT && sl == 28) {     // single raw buffer: every wave has read this chunk's patches (slots 8-17)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -702,10 +776,8 @@ bool sk_decide(long long regions, int nch, bool epi, bool have_ws, int64_t ws_fl
 
 template <int TRW, bool FLAT, bool EPI>
 int launch(WArgs& a, hipStream_t st) {
-    constexpr int TRH = 64 / TRW;
     // U and V images (double-buffered, 128 KB) + the raw input region(s): see FLAT in the kernel
-    constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);     // 16-byte words, see the kernel
-    constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
+    constexpr size_t smem = RawGeo<TRW, FLAT>::SMEM;
     static std::atomic<uint64_t> configured{0};     // per device, see configure_dynamic_lds
     if (configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, EPI>, smem, configured) != hipSuccess)
         return fail(DMH_ELAUNCH, "%s: cannot raise the dynamic LDS limit", "dmh_wino_conv3x3");
@@ -737,9 +809,7 @@ int launch_split(WArgs& a, hipStream_t st, bool epi, float* ws, int64_t ws_float
         if (sk_decide(regions, nch, epi, ws != nullptr, ws_floats, G, units)) {
             a.csplit = 1; a.nitems = (int)regions; a.part = ws; a.sk_units = (int)units; a.sk_grid = G; a.sk_per = (int)(units / G); a.sk_rem = (int)(units % G);
             static std::atomic<uint64_t> configured{0};
-            constexpr int TRH = 64 / TRW;
-            constexpr int RAWN = CK * (FLAT ? 4 * TRH : 2 * TRH + 2) * ((2 * TRW + 2 + 6) / 4);
-            constexpr size_t smem = (size_t)4 * 16 * 2 * 64 * 16 + (size_t)(FLAT ? 1 : 2) * RAWN * 16;
+            constexpr size_t smem = RawGeo<TRW, FLAT>::SMEM;
             static std::atomic<uint64_t> configured_epi{0};
             if ((epi ? configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, true, true>, smem, configured_epi)
                      : configure_dynamic_lds(wino_conv_kernel<TRW, FLAT, false, true>, smem, configured)) != hipSuccess)

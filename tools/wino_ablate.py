@@ -32,4 +32,5 @@ for n in sys.argv[7:]:
         run()
     e1.record()
     torch.cuda.synchronize()
-    print("ablate %-3s C%d K%d %dx%d B%d: %.1f us" % (n, Cc, K, Ho, Wo, B, e0.elapsed_time(e1) * 100), flush=True)
+    bits = int(y.view(torch.int32).to(torch.int64).sum())     # equal for two builds that compute the same bits
+    print("ablate %-3s C%d K%d %dx%d B%d: %.1f us   bits %d" % (n, Cc, K, Ho, Wo, B, e0.elapsed_time(e1) * 100, bits), flush=True)
