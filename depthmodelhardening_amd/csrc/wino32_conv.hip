@@ -29,6 +29,25 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// DMH_W32_PK (round 6, as DMH_WINO_PK in wino_conv.hip): the input transform on packed fp32 adds -- the raw rows of a thread's
+// channel pair are interleaved in LDS ([pair][row][channel of the pair][word]), one ds_read2_b32 fetches a patch element of both
+// channels into a register pair, both stages are v_pk_add_f32 on such pairs (56 instead of 112 per chunk), and the results are
+// the (channel, channel + 1) pairs the 8-byte image writes want.  Same additions in the same order: bit-identical results.
+#ifndef DMH_W32_PK
+#define DMH_W32_PK 1
+#endif
+__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) {     // asm: hipcc splits <2 x float> additions
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 
 constexpr int CK = 8;                       // input channels per chunk
 constexpr int NT = 256;
@@ -39,6 +58,7 @@ constexpr int RWA = 4 * NWR;                // LDS row pitch in floats (72)
 constexpr int RAW_N = CK * RH * NWR;        // 1440 words
 constexpr int RAW_PER_T = (RAW_N + NT - 1) / NT;   // 6 loads per thread and chunk (dword loads: 21)
 constexpr int RAW_BUF = RAW_N * 4;          // floats per raw buffer (23 KB)
+constexpr int PKI = DMH_W32_PK ? 2 : 1;     // DMH_W32_PK: the rows of a channel pair are interleaved
 constexpr int UBUF = 16 * 2 * 32;           // f32x4 words of one U chunk image (16 KB)
 constexpr int VBUF = 16 * 2 * 128;          // f32x4 words of the V image (64 KB)
 
@@ -103,7 +123,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     const int coff = (4 - (a.pad & 3)) & 3;                 // columns of the first word in front of the region
     const bool partial = a.pad > 0 && (a.W & 3) != 0;       // a word can straddle the right image edge
     f32x4* const raw4 = reinterpret_cast<f32x4*>(raw);
-    const float* rsrc0 = raw + (2 * wv) * (RH * RWA) + (4 * tl0y) * RWA + 2 * tlx + coff;  // upper tile; the lower one: + 2 rows
+    const float* rsrc0 = raw + (2 * wv) * (RH * RWA) + (4 * tl0y) * (PKI * RWA) + 2 * tlx + coff;  // upper tile; the lower one: + 2 rows
     float* vdst0 = reinterpret_cast<float*>(V_lds + (wv >> 1) * 128 + 64 * tl0y + tlx) + 2 * (wv & 1);   // +32 words: the tile below
     // MFMA role: wave wv multiplies the 32 channels by tiles [32 wv, 32 wv + 32)
     const int aidx = (lane >> 5) * 32 + (lane & 31);
@@ -131,7 +151,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const int cbase = (it.b * a.C + cb_ * CK) * (int)HW;                                      \
         _Pragma("unroll") for (int k = 0; k < RAW_PER_T; ++k) {                                   \
             const int e = tid_o + NT * k;                                                         \
-            const int c = e / (RH * NWR), rem = e - c * (RH * NWR), rr = rem / NWR, xx = 4 * (rem - rr * NWR); \
+            /* LDS order: [channel][row][word]; DMH_W32_PK: [channel pair][row][channel of the pair][word] */ \
+            const int cq = e / (PKI * RH * NWR), r1 = e - cq * (PKI * RH * NWR), rr = r1 / (PKI * NWR), r2 = r1 - rr * (PKI * NWR); \
+            const int c = PKI * cq + r2 / NWR, xx = 4 * (r2 % NWR);                               \
             const int iy = iy0 + rr, ix = ix0 + xx;                                               \
             const bool ok = e < RAW_N && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;              \
             ROFF[k] = ok ? (unsigned)(cbase + c * (int)HW + iy * a.W + ix) * 4u : 0xFFFFFFFFu;    \
@@ -171,6 +193,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // the raw patch at RS): the horizontal stage d B is taken once per raw row -- six rows instead of two times four (24
     // instead of 32 LDS words read, 56 instead of 64 additions per channel) --, the vertical stage B^T (.) per tile.
     // V words at VD (upper tile) and VD + 32 words (the tile below it).
+#if DMH_W32_PK
+#define DMH_W32_TRANSFORM_PAIR(RS, VD)                                                            \
+    {                                                                                             \
+        f32x2 h_[6][4];         /* (channel, channel + 1) pairs */                                \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                                           \
+            const float* row_ = (RS) + 2 * i * RWA;                       /* 4-byte aligned only */ \
+            const f32x2 d0_ = {row_[0], row_[RWA]}, d1_ = {row_[1], row_[RWA + 1]};               \
+            const f32x2 d2_ = {row_[2], row_[RWA + 2]}, d3_ = {row_[3], row_[RWA + 3]};           \
+            h_[i][0] = pk_sub(d0_, d2_);                                                          \
+            h_[i][1] = pk_add(d1_, d2_);                                                          \
+            h_[i][2] = pk_sub(d2_, d1_);                                                          \
+            h_[i][3] = pk_sub(d1_, d3_);                                                          \
+        }                                                                                         \
+        _Pragma("unroll") for (int tv_ = 0; tv_ < 2; ++tv_) {                                     \
+            float* const vd_ = (VD) + tv_ * (32 * 4);                                             \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                       \
+                *reinterpret_cast<f32x2*>(vd_ + (0 * 4 + j) * 1024) = pk_sub(h_[2 * tv_][j], h_[2 * tv_ + 2][j]); \
+                *reinterpret_cast<f32x2*>(vd_ + (1 * 4 + j) * 1024) = pk_add(h_[2 * tv_ + 1][j], h_[2 * tv_ + 2][j]); \
+                *reinterpret_cast<f32x2*>(vd_ + (2 * 4 + j) * 1024) = pk_sub(h_[2 * tv_ + 2][j], h_[2 * tv_ + 1][j]); \
+                *reinterpret_cast<f32x2*>(vd_ + (3 * 4 + j) * 1024) = pk_sub(h_[2 * tv_ + 1][j], h_[2 * tv_ + 3][j]); \
+            }                                                                                     \
+        }                                                                                         \
+    }
+#else
 #define DMH_W32_TRANSFORM_PAIR(RS, VD)                                                            \
     {                                                                                             \
         float h_[2][6][4];                                                                        \
@@ -196,6 +242,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             }                                                                                     \
         }                                                                                         \
     }
+#endif
 #define DMH_W32_TRANSFORM(BUFI) DMH_W32_TRANSFORM_PAIR(rsrc0 + (BUFI) * RAW_BUF, vdst0)
 
     f32x16 acc[16];
