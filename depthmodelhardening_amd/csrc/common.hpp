@@ -82,6 +82,32 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, bytes, 0x00020000);
 }
+// Packed fp32 additions (v_pk_add_f32: two IEEE additions per instruction) for the Winograd transforms of K10 / K17 / K18, which
+// sit beside fp32 MFMAs that shadow no vector instruction.  As asm: hipcc splits <2 x float> additions into v_add_f32 pairs once
+// the operands come out of ds_read2_b32, and -fno-slp-vectorize (build.py) keeps it from forming them by itself.  The operand
+// selects were checked on the device (tools/micro/pk_opsel.hip).  (x, y) below = (low, high) half of a register pair.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define DMH_PK_FORM(NAME, MODS)                                                  \
+    __device__ __forceinline__ f32x2 NAME(const f32x2 a, const f32x2 b) {        \
+        f32x2 r;                                                                 \
+        asm("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r) : "v"(a), "v"(b));         \
+        return r;                                                                \
+    }
+DMH_PK_FORM(pk_add, "")                                                              // (a.x + b.x, a.y + b.y)
+DMH_PK_FORM(pk_sub, "neg_lo:[0,1] neg_hi:[0,1]")                                     // (a.x - b.x, a.y - b.y)
+DMH_PK_FORM(pk_bfly, "op_sel:[0,1] op_sel_hi:[0,1] neg_hi:[0,1]")                    // (a.x + b.y, a.x - b.y)
+DMH_PK_FORM(pk_bfly_neg, "op_sel:[0,1] op_sel_hi:[0,1] neg_lo:[1,1] neg_hi:[1,0]")   // (-a.x - b.y, -a.x + b.y)
+DMH_PK_FORM(pk_col01, "op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1]")                   // (a.x - b.x, a.y + b.x)
+DMH_PK_FORM(pk_col23, "op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]")      // (-a.y + b.x, a.y - b.y)
+#define DMH_PK_MOV(NAME, MODS)                                                   \
+    __device__ __forceinline__ f32x2 NAME(const f32x2 a, const f32x2 b) {        \
+        f32x2 r;                                                                 \
+        asm("v_pk_mov_b32 %0, %1, %2 " MODS : "=v"(r) : "v"(a), "v"(b));         \
+        return r;                                                                \
+    }
+DMH_PK_MOV(pk_lo_lo, "op_sel:[0,0]")     // (a.x, b.x): one instruction regroups two results of packed additions
+DMH_PK_MOV(pk_hi_hi, "op_sel:[1,1]")     // (a.y, b.y)
+
 __device__ __forceinline__ float ldb(rsrc_t rs, unsigned byte_off, unsigned s_off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, byte_off, s_off, 0));
 }

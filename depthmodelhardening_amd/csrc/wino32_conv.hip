@@ -29,7 +29,6 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // DMH_W32_PK (round 6, as DMH_WINO_PK in wino_conv.hip): the input transform on packed fp32 adds -- the raw rows of a thread's
 // channel pair are interleaved in LDS ([pair][row][channel of the pair][word]), one ds_read2_b32 fetches a patch element of both
@@ -38,17 +37,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef DMH_W32_PK
 #define DMH_W32_PK 1
 #endif
-__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) {     // asm: hipcc splits <2 x float> additions
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
 constexpr int CK = 8;                       // input channels per chunk
 constexpr int NT = 256;
 constexpr int TRW = 32, TRH = 4;            // tile region of an item

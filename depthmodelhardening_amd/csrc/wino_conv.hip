@@ -41,7 +41,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));    // native vector: arrays of it stay in registers
 
 #ifndef DMH_WINO_ABLATE          // tools/wino_ablate.sh: 1 no global loads, 2 no input transform, 4 no LDS staging writes,
-#define DMH_WINO_ABLATE 0        // 16 no MFMAs in the steady-state loop, 32 no stores in the epilogue, 64 the epilogue's transform + stores twice (timing only)
+#define DMH_WINO_ABLATE 0        // 16 no MFMAs in the steady-state loop, 32 no stores in the epilogue, 64 the epilogue's transform + stores twice,
+                                 // 128 no barrier at the end of a chunk, 256 no counted wait before it (timing only)
 #endif
 constexpr int CK = 8;            // input channels per chunk
 constexpr int NT = 256;
@@ -155,19 +156,6 @@ __global__ __launch_bounds__(NT) void wino_weight_batch_kernel(const WtBatch b) 
 #ifndef DMH_WINO_PK
 #define DMH_WINO_PK 1
 #endif
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-// as asm: hipcc splits the <2 x float> additions of the transform into v_add_f32 pairs (its own v_pk_add_f32 patterns lose to the
-// scalar form once the operands come out of ds_read2_b32)
-__device__ __forceinline__ f32x2 pk_add(const f32x2 a, const f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ f32x2 pk_sub(const f32x2 a, const f32x2 b) {
-    f32x2 r;
-    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 // 16-byte words of one channel's raw region (rows x words per row), and the channel pitch in words
 template <int TRW, bool FLAT>
 struct RawGeo {
@@ -544,8 +532,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             // all older vector-memory operations (the LDS-DMA of U[nxt] and the loads consumed above) have landed when
             // only this iteration's RAW_PER_T raw loads are still outstanding; a raw s_barrier keeps those in flight
             // (__syncthreads() would drain them: its fence waits vmcnt(0) once an LDS-DMA has been issued)
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RAW_PER_T) : "memory");
-            __builtin_amdgcn_s_barrier();
+            if (!(DMH_WINO_ABLATE & 256)) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RAW_PER_T) : "memory");
+            if (!(DMH_WINO_ABLATE & 128)) __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             ++g;
         };
@@ -588,59 +576,80 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll 1
             for (int rep = 0; rep < ((DMH_WINO_ABLATE & 64) ? 2 : 1); ++rep)      // timing experiment: the transform + stores twice
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int ko = kbase + (v & 3) + 8 * (v >> 2);
-                float2 r0 = make_float2(0.f, 0.f), r1 = r0;
-                if (EPI) {
-                    r0 = rq0[v % RPF];
-                    r1 = rq1[v % RPF];
-                    if (v + RPF < 16) res_fetch(v + RPF, rq0[v % RPF], rq1[v % RPF]);
-                }
-                float s0[4], s1[4];
+            for (int vp = 0; vp < 8; ++vp) {
+                // Round 6: the output transform on packed adds over the channel PAIR (v, v + 1) = two adjacent registers of every
+                // accumulator (channels ko, ko + 1); one v_pk_mov_b32 per store regroups (y00 of both channels, y01 of both) into a
+                // channel's pixel pair.  The same additions in the same order as the scalar form: bit-identical.
+                const int v0 = 2 * vp, ko0 = kbase + (v0 & 3) + 8 * (v0 >> 2);
+                f32x2 S0[4], S1[4];
+#define DMH_ACC2(P) (f32x2{acc[P][v0], acc[P][v0 + 1]})
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    s0[j] = acc[j][v] + acc[4 + j][v] + acc[8 + j][v];
-                    s1[j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
+                    S0[j] = pk_add(pk_add(DMH_ACC2(j), DMH_ACC2(4 + j)), DMH_ACC2(8 + j));
+                    S1[j] = pk_sub(pk_sub(DMH_ACC2(4 + j), DMH_ACC2(8 + j)), DMH_ACC2(12 + j));
                 }
-                if (SK && pn < nch) {       // a partial item: its raw sums to the workgroup's slot, finished by wino_sk_fixup_kernel
-                    // buffer store: the slot's base is a descriptor in SGPRs, the (slot, channel) offset an SGPR, the thread's
-                    // 16 bytes one VGPR -- no 64-bit per-lane address beside the 256 live accumulators
-                    const int slot = 2 * (int)blockIdx.x + ((item != item0 && item == item_last) ? 1 : 0);
-                    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slot * 16 + v) * (NT * 16));
-                    const f32x4 pv = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pv),
-                                                           prs, (unsigned)(wv_s * 64 + lane_o) * 16u, soff, 0);
-                } else if (inside && ko < a.K) {
-                    const float bs = (a.bias && it.c0 == 0) ? a.bias[ko] : 0.f;
-                    float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
-                    float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
-                    float* yp = yb + (size_t)ko * a.Ho * a.Wo;
-                    if (EPI) {      // fused eval-mode BatchNorm (scale in the filter, shift = bias) + identity + ReLU
-                        if (a.res) {
-                            if (a.relu & 2) {   // the tensor is a saved ReLU output: pass the gradient where it was positive
-                                y00 = r0.x > 0.f ? y00 : 0.f; y01 = r0.y > 0.f ? y01 : 0.f;
-                                y10 = r1.x > 0.f ? y10 : 0.f; y11 = r1.y > 0.f ? y11 : 0.f;
-                            } else {
-                                y00 += r0.x; y01 += r0.y; y10 += r1.x; y11 += r1.y;
+#undef DMH_ACC2
+                f32x2 Y00 = pk_add(pk_add(S0[0], S0[1]), S0[2]), Y01 = pk_sub(pk_sub(S0[1], S0[2]), S0[3]);
+                f32x2 Y10 = pk_add(pk_add(S1[0], S1[1]), S1[2]), Y11 = pk_sub(pk_sub(S1[1], S1[2]), S1[3]);
+                const bool whole = !(SK && pn < nch);
+                if (whole) {
+                    f32x2 BS = {0.f, 0.f};
+                    if (a.bias && it.c0 == 0) {
+                        BS.x = ko0 < a.K ? a.bias[ko0] : 0.f;
+                        BS.y = ko0 + 1 < a.K ? a.bias[ko0 + 1] : 0.f;
+                    }
+                    Y00 = pk_add(Y00, BS); Y01 = pk_add(Y01, BS); Y10 = pk_add(Y10, BS); Y11 = pk_add(Y11, BS);
+                }
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const int v = v0 + c2, ko = ko0 + c2;
+                    float2 r0 = make_float2(0.f, 0.f), r1 = r0;
+                    if (EPI) {
+                        r0 = rq0[v % RPF];
+                        r1 = rq1[v % RPF];
+                        if (v + RPF < 16) res_fetch(v + RPF, rq0[v % RPF], rq1[v % RPF]);
+                    }
+                    // this channel's two pixel pairs (y00, y01), (y10, y11)
+                    f32x2 P0 = c2 ? pk_hi_hi(Y00, Y01) : pk_lo_lo(Y00, Y01), P1 = c2 ? pk_hi_hi(Y10, Y11) : pk_lo_lo(Y10, Y11);
+                    if (!whole) {       // a partial item: its raw sums to the workgroup's slot, finished by wino_sk_fixup_kernel
+                        // buffer stores: the slot's base is a descriptor in SGPRs, the (slot, channel) offset an SGPR, the thread's
+                        // 16 bytes (y00, y01 | y10, y11) one VGPR offset -- no 64-bit per-lane address beside the 256 live accumulators
+                        const int slot = 2 * (int)blockIdx.x + ((item != item0 && item == item_last) ? 1 : 0);
+                        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slot * 16 + v) * (NT * 16));
+                        typedef unsigned u32x2_t __attribute__((__vector_size__(2 * sizeof(unsigned))));
+                        const unsigned vo = (unsigned)(wv_s * 64 + lane_o) * 16u;
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, P0), prs, vo, soff, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, P1), prs, vo + 8u, soff, 0);
+                    } else if (inside && ko < a.K) {
+                        float* yp = yb + (size_t)ko * a.Ho * a.Wo;
+                        if (EPI) {      // fused eval-mode BatchNorm (scale in the filter, shift = bias) + identity + ReLU
+                            if (a.res) {
+                                if (a.relu & 2) {   // the tensor is a saved ReLU output: pass the gradient where it was positive
+                                    P0.x = r0.x > 0.f ? P0.x : 0.f; P0.y = r0.y > 0.f ? P0.y : 0.f;
+                                    P1.x = r1.x > 0.f ? P1.x : 0.f; P1.y = r1.y > 0.f ? P1.y : 0.f;
+                                } else {
+                                    P0 = pk_add(P0, f32x2{r0.x, r0.y});
+                                    P1 = pk_add(P1, f32x2{r1.x, r1.y});
+                                }
+                            }
+                            if (a.relu & 1) {
+                                P0.x = fmaxf(P0.x, 0.f); P0.y = fmaxf(P0.y, 0.f); P1.x = fmaxf(P1.x, 0.f); P1.y = fmaxf(P1.y, 0.f);
                             }
                         }
-                        if (a.relu & 1) {
-                            y00 = fmaxf(y00, 0.f); y01 = fmaxf(y01, 0.f); y10 = fmaxf(y10, 0.f); y11 = fmaxf(y11, 0.f);
+                        if ((DMH_WINO_ABLATE & 32) && a.K > 0) {     // timing experiment: everything but the stores
+                            asm volatile("" ::"v"(P0), "v"(P1));
+                        } else if (EPI || a.csplit == 1) {
+                            *reinterpret_cast<f32x2*>(yp) = P0;
+                            *reinterpret_cast<f32x2*>(yp + a.Wo) = P1;
+                        } else {    // two partial sums into zeros: 0 + a + b is the same in either order (deterministic)
+                            unsafeAtomicAdd(yp, P0.x);
+                            unsafeAtomicAdd(yp + 1, P0.y);
+                            unsafeAtomicAdd(yp + a.Wo, P1.x);
+                            unsafeAtomicAdd(yp + a.Wo + 1, P1.y);
                         }
                     }
-                    if ((DMH_WINO_ABLATE & 32) && a.K > 0) {     // timing experiment: everything but the stores
-                        asm volatile("" ::"v"(y00), "v"(y01), "v"(y10), "v"(y11));
-                    } else if (EPI || a.csplit == 1) {
-                        *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
-                        *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
-                    } else {    // two partial sums into zeros: 0 + a + b is the same in either order (deterministic)
-                        unsafeAtomicAdd(yp, y00);
-                        unsafeAtomicAdd(yp + 1, y01);
-                        unsafeAtomicAdd(yp + a.Wo, y10);
-                        unsafeAtomicAdd(yp + a.Wo + 1, y11);
-                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one output channel at a time: hoisted accumulator reads spill
+                __builtin_amdgcn_sched_barrier(0);   // one channel pair at a time: hoisted accumulator reads spill
             }
         }
 #pragma unroll

@@ -121,6 +121,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     auto chunk_at = [&](int ch) __attribute__((always_inline)) {
         ch = min(max(ch, c_first), max(c_end - 1, c_first));
         ch = min(ch, a.nchunks - 1);
+        // (chunks walk along the rows of tiles; walking an image in column strips, so that consecutive chunks share two of their
+        // four input rows, measured 4 % SLOWER: the row pieces of consecutive chunks are then no longer neighbours in memory)
         const int b = ch / (a.Ht * a.cpr), rem = ch - b * (a.Ht * a.cpr), ty = rem / a.cpr, tx0 = (rem - ty * a.cpr) * TPC;
         const int iy0 = 2 * ty - a.pad, ixa = 2 * tx0 - a.pad - coff;          // ixa: multiple of 4 (tx0 is a multiple of 8)
         Chunk c;
@@ -292,12 +294,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             x_off_r[k] = ch * XCS + coff + 2 * ((q & 1) + 2 * (q >> 1));
             x_off_w[k] = (q & 1) * (4 * CCH) + 2 * ch + (q >> 1);
         }
-        float dt[16], xt[NXI][16];                                  // a tile's patch, then its 16 transformed values
+        // Round 6: both transforms on packed adds (common.hpp: the fp32 MFMA shadows no vector instruction, and this loop carried
+        // 88 scalar additions per chunk beside its 64 MFMAs).  A patch row arrives as column pairs -- ds_read2_b32 puts two
+        // adjacent columns into a register pair --, the row pass works on such pairs, the column pass and the 2 x 2 butterflies of
+        // the d-tile use the operand selects of v_pk_add_f32.  The same additions on the same operands: bit-identical sums.
+        f32x2 dr0, dr1, xp[NXI][4][2];                              // the tiles' patches: d rows; x rows as (columns 0-1, columns 2-3)
+        float dt[16], xt[NXI][16];                                  // the 16 transformed values of a tile
         auto t_read = [&](const int buf, const int J) __attribute__((always_inline)) {
             if (has_d) {
                 const float* ds = raw + buf * RAWBUF + d_off_r + 8 * J;
-                const float2 r0 = *reinterpret_cast<const float2*>(ds), r1 = *reinterpret_cast<const float2*>(ds + DC);
-                dt[0] = r0.x; dt[1] = r0.y; dt[2] = r1.x; dt[3] = r1.y;
+                dr0 = *reinterpret_cast<const f32x2*>(ds);
+                dr1 = *reinterpret_cast<const f32x2*>(ds + DC);
             }
 #pragma unroll
             for (int k = 0; k < NXI; ++k)
@@ -305,40 +312,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                     const float* xs = raw + buf * RAWBUF + x_off_r[k] + 8 * J;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const float* row = xs + i * XC;
-                        xt[k][4 * i] = row[0]; xt[k][4 * i + 1] = row[1]; xt[k][4 * i + 2] = row[2]; xt[k][4 * i + 3] = row[3];
+                        const float* row = xs + i * XC;             // 4-byte aligned only (coff is odd for pad 1)
+                        xp[k][i][0] = f32x2{row[0], row[1]};
+                        xp[k][i][1] = f32x2{row[2], row[3]};
                     }
                 }
         };
         auto t_math_d = [&]() __attribute__((always_inline)) {          // dM = A dY A^T, A = [[1,0],[1,1],[1,-1],[0,-1]]
             if (has_d) {
-                const float a0 = dt[0], a1 = dt[1], b0 = dt[2], b1 = dt[3];
-                const float u0[4] = {a0, a0 + b0, a0 - b0, -b0}, u1[4] = {a1, a1 + b1, a1 - b1, -b1};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    dt[4 * i + 0] = u0[i];
-                    dt[4 * i + 1] = u0[i] + u1[i];
-                    dt[4 * i + 2] = u0[i] - u1[i];
-                    dt[4 * i + 3] = -u1[i];
-                }
+                // rows of A dY: u(i) = (u0[i], u1[i]) = dr0, dr0 + dr1, dr0 - dr1, -dr1; then (u0, u0 + u1, u0 - u1, -u1) of each
+                const f32x2 u1 = pk_add(dr0, dr1), u2 = pk_sub(dr0, dr1);
+                const f32x2 m0 = pk_bfly(dr0, dr0), m1 = pk_bfly(u1, u1), m2 = pk_bfly(u2, u2), m3 = pk_bfly_neg(dr1, dr1);
+                dt[0] = dr0.x;  dt[1] = m0.x;  dt[2] = m0.y;  dt[3] = -dr0.y;
+                dt[4] = u1.x;   dt[5] = m1.x;  dt[6] = m1.y;  dt[7] = -u1.y;
+                dt[8] = u2.x;   dt[9] = m2.x;  dt[10] = m2.y; dt[11] = -u2.y;
+                dt[12] = -dr1.x; dt[13] = m3.x; dt[14] = m3.y; dt[15] = dr1.y;
             }
         };
         auto t_math_x = [&](const int k) __attribute__((always_inline)) {     // V = B^T d B
             if (has_x[k]) {
-                float q[4][4];
+                f32x2 q[4][2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    q[0][j] = xt[k][j] - xt[k][8 + j];
-                    q[1][j] = xt[k][4 + j] + xt[k][8 + j];
-                    q[2][j] = xt[k][8 + j] - xt[k][4 + j];
-                    q[3][j] = xt[k][4 + j] - xt[k][12 + j];
+                for (int jp = 0; jp < 2; ++jp) {
+                    q[0][jp] = pk_sub(xp[k][0][jp], xp[k][2][jp]);
+                    q[1][jp] = pk_add(xp[k][1][jp], xp[k][2][jp]);
+                    q[2][jp] = pk_sub(xp[k][2][jp], xp[k][1][jp]);
+                    q[3][jp] = pk_sub(xp[k][1][jp], xp[k][3][jp]);
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    xt[k][4 * i + 0] = q[i][0] - q[i][2];
-                    xt[k][4 * i + 1] = q[i][1] + q[i][2];
-                    xt[k][4 * i + 2] = q[i][2] - q[i][1];
-                    xt[k][4 * i + 3] = q[i][1] - q[i][3];
+                    const f32x2 o01 = pk_col01(q[i][0], q[i][1]), o23 = pk_col23(q[i][0], q[i][1]);
+                    xt[k][4 * i + 0] = o01.x;       // q0 - q2
+                    xt[k][4 * i + 1] = o01.y;       // q1 + q2
+                    xt[k][4 * i + 2] = o23.x;       // q2 - q1
+                    xt[k][4 * i + 3] = o23.y;       // q1 - q3
                 }
             }
         };
@@ -449,10 +456,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         store_raw(1);
         load_chunk(c_first + 2);
         __syncthreads();
-        for (int g = 0; g < n; ++g) {
-            const int cur = g & 1, nxt = cur ^ 1;
-            phase(0, cur, 1, false, 0, g);          // A: k-steps 0-1 of chunk g      | tiles J = 1 of chunk g     (raw[cur])
-            phase(1, nxt, 0, true, cur, g);         // B: k-steps 2-3 of chunk g      | tiles J = 0 of chunk g + 1 (raw[nxt]); staging
+        // two chunks per trip: the raw buffer of every phase is then a constant, and its LDS addresses are immediates instead of
+        // 16 vector additions per chunk
+        int g = 0;
+        for (; g + 1 < n; g += 2) {
+            phase(0, 0, 1, false, 0, g);            // A: k-steps 0-1 of chunk g      | tiles J = 1 of chunk g     (raw[cur])
+            phase(1, 1, 0, true, 0, g);             // B: k-steps 2-3 of chunk g      | tiles J = 0 of chunk g + 1 (raw[nxt]); staging
+            phase(0, 1, 1, false, 0, g + 1);
+            phase(1, 0, 0, true, 1, g + 1);
+        }
+        if (g < n) {
+            phase(0, 0, 1, false, 0, g);
+            phase(1, 1, 0, true, 0, g);
         }
     }
     if (!IL && n > 0) {
