@@ -313,6 +313,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const bool inside = oy < a.Ho && ox < a.Wo;
             float* yb = a.y + (size_t)it.b * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
             const int kbase = it.k0 + 4 * (lane_o >> 5);
+            // (scalar: the packed form of K10's epilogue -- channel pairs, v_pk_add_f32 / v_pk_mov_b32 -- was measured here and taken
+            // out again: +5 % at upconv(1,1)'s backward-data, -13 % at the attack's ragged window launches, a dozen spilled registers)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int ko = kbase + (v & 3) + 8 * (v >> 2);

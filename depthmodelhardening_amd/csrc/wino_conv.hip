@@ -616,10 +616,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                         // 16 bytes (y00, y01 | y10, y11) one VGPR offset -- no 64-bit per-lane address beside the 256 live accumulators
                         const int slot = 2 * (int)blockIdx.x + ((item != item0 && item == item_last) ? 1 : 0);
                         const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slot * 16 + v) * (NT * 16));
-                        typedef unsigned u32x2_t __attribute__((__vector_size__(2 * sizeof(unsigned))));
-                        const unsigned vo = (unsigned)(wv_s * 64 + lane_o) * 16u;
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, P0), prs, vo, soff, 0);
-                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, P1), prs, vo + 8u, soff, 0);
+                        const f32x4 pv = {P0.x, P0.y, P1.x, P1.y};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pv),
+                                                               prs, (unsigned)(wv_s * 64 + lane_o) * 16u, soff, 0);
+                        // the next instruction that writes these four registers is a v_pk_mov_b32 written as asm: the compiler's
+                        // hazard recognizer leaves the 16-byte store's data alone for its own vector instructions but does not see
+                        // into the asm -- without the two wait states the store sent the NEXT channel's values now and then
+                        asm volatile("s_nop 1" ::: "memory");
                     } else if (inside && ko < a.K) {
                         float* yp = yb + (size_t)ko * a.Ho * a.Wo;
                         if (EPI) {      // fused eval-mode BatchNorm (scale in the filter, shift = bias) + identity + ReLU
