@@ -67,6 +67,7 @@ class Phy_obj_atk(Attack):
         self._model_negates = None      # does model.masked_sq_mean take negate=...?  (asked once)
         self._capture_fault = False     # test hook: make the capture of _graph_steps fail after its first launch
         self.graph_failure = None       # why use_graph switched itself off (a failed capture), else None
+        self._one = None                # the constant 1 handed to autograd.grad as d cost / d cost (made once per attack)
         self._graph = None      # (graph of the previous attack, event behind its last replay): destroyed once it has run
         # Data-parallel "shared patch" mode: shard = (rank, world, process group or None).  The
         # reference attacks ONE patch on batch_size scenes per iteration (MD2/trainer.py:300-307, mono_dataset.py:178-184);
@@ -180,6 +181,9 @@ class Phy_obj_atk(Attack):
                 clean, _ = ops.eot_paste(scene_imgs, self.obj_img, torch.zeros_like(mask), coeffs[0], l_pad, t_pad,
                                          self.scene_size)
 
+        # d cost / d cost = 1 for every step: handed to autograd.grad as a tensor made once per attack (autograd otherwise fills
+        # a fresh one-element tensor per step: one more launch in a chain of ~120 short dependent ones)
+        self._one = torch.ones((), device=self.device, dtype=torch.float32)
         first = 0
         if graph:
             obj_img_adv, first = self._graph_steps(scene_imgs, obj_img_adv, mask, coeffs, plans[0], tabs, clean, l_pad, t_pad)
@@ -198,7 +202,8 @@ class Phy_obj_atk(Attack):
                 cost = -ops.masked_sq_mean(adv_depth, obj_masks_out)  # -MSE(adv_depth * mask, 0)
             if mine is not None:
                 cost = cost * share     # the local mean's part of the mean over the global batch
-            grad = torch.autograd.grad(cost, obj_img_adv, retain_graph=False, create_graph=False)[0]
+            grad = torch.autograd.grad(cost, obj_img_adv, grad_outputs=self._one if cost.dim() == 0 and cost.dtype == torch.float32 else None,
+                                       retain_graph=False, create_graph=False)[0]
             if mine is not None:        # 0.94 MB: the one exchange of the shared-patch attack, before the sign
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
             if self.trace is not None:
@@ -230,7 +235,7 @@ class Phy_obj_atk(Attack):
             p = patch_in.detach().requires_grad_(True)
             adv, m = ops.eot_paste(scene_imgs, p, mask, coeff_cur, l_pad, t_pad, self.scene_size)
             cost = self._neg_cost(adv, m, plan, tab_cur, clean)
-            (grad,) = torch.autograd.grad(cost, p)
+            (grad,) = torch.autograd.grad(cost, p, grad_outputs=self._one)
             ops.pgd_linf_step(p, self.obj_img, grad, self.alpha, self.eps, out=patch_out)
             patch_in.copy_(patch_out)
 
