@@ -560,6 +560,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             constexpr int RPF = 4;
             float2 rq0[RPF], rq1[RPF];
             const bool use_res = EPI && a.res != nullptr;
+            // The accumulators are read below by v_accvgpr_read_b32 written as asm, which the compiler's hazard recognizer does not
+            // see into: a 16-pass MFMA's result may be read 19 wait states after its issue at the earliest.  The item's last MFMA
+            // lies a barrier and the item decode behind us; these 20 wait states make that independent of how the code is laid out.
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
             auto res_fetch = [&](const int v, float2& q0, float2& q1) __attribute__((always_inline)) {
                 const int ko = kbase + (v & 3) + 8 * (v >> 2);
                 q0 = q1 = make_float2(0.f, 0.f);
@@ -582,13 +586,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
                 // channel's pixel pair.  The same additions in the same order as the scalar form: bit-identical.
                 const int v0 = 2 * vp, ko0 = kbase + (v0 & 3) + 8 * (v0 >> 2);
                 f32x2 S0[4], S1[4];
-#define DMH_ACC2(P) (f32x2{acc[P][v0], acc[P][v0 + 1]})
+                // every accumulator value is read ONCE, by a volatile v_accvgpr_read_b32 (left to itself hipcc re-reads the
+                // accumulator file for every use -- 610 reads per item for 256 values -- and shuffles register pairs with v_mov_b64)
+                f32x2 A2[16];
+#pragma unroll
+                for (int pq = 0; pq < 16; ++pq) {
+                    float lo_, hi_;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo_) : "a"(acc[pq][v0]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi_) : "a"(acc[pq][v0 + 1]));
+                    A2[pq] = f32x2{lo_, hi_};
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    S0[j] = pk_add(pk_add(DMH_ACC2(j), DMH_ACC2(4 + j)), DMH_ACC2(8 + j));
-                    S1[j] = pk_sub(pk_sub(DMH_ACC2(4 + j), DMH_ACC2(8 + j)), DMH_ACC2(12 + j));
+                    S0[j] = pk_add(pk_add(A2[j], A2[4 + j]), A2[8 + j]);
+                    S1[j] = pk_sub(pk_sub(A2[4 + j], A2[8 + j]), A2[12 + j]);
                 }
-#undef DMH_ACC2
                 f32x2 Y00 = pk_add(pk_add(S0[0], S0[1]), S0[2]), Y01 = pk_sub(pk_sub(S0[1], S0[2]), S0[3]);
                 f32x2 Y10 = pk_add(pk_add(S1[0], S1[1]), S1[2]), Y11 = pk_sub(pk_sub(S1[1], S1[2]), S1[3]);
                 const bool whole = !(SK && pn < nch);
