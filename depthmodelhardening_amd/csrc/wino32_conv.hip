@@ -21,6 +21,8 @@
 // Filter layout: U[C/8][16 positions][2 halves][Kp][4 floats], Kp = K rounded up to 32 (dmh_wino32_weight_transform).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 using namespace dmh;
@@ -233,11 +235,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #endif
 #define DMH_W32_TRANSFORM(BUFI) DMH_W32_TRANSFORM_PAIR(rsrc0 + (BUFI) * RAW_BUF, vdst0)
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) acc[p][v] = 0.f;
+    f32x16 acc[16];         // never cleared: the first chunk of a piece multiplies onto a zero C operand (an inline constant), as in K10
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // Pipeline over the flattened (item, chunk) sequence.  Iteration g runs
     //   M(g)    64 MFMAs on U[g&1] and V; interleaved: LDS-DMA of filter chunk g+1 -> U[(g+1)&1]; registers (raw chunk
@@ -263,7 +262,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         const int item = item0 + mi;
         DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n, ixa_n)
         if (SK) pn = (item == item_last ? ce_last : nch) - (item == item0 ? cb0 : 0);
-        for (int ch = 0; ch < pn; ++ch, ++g) {
+        // one chunk; FIRST: the piece's first chunk, whose first MFMA per position starts the accumulation from zero (round 6: the
+        // 256 accumulator writes per item that cleared them are gone)
+        auto chunk = [&](const int ch, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             const int cur = g & 1, nxt = cur ^ 1;
             const f32x4* Uc = U_lds + cur * UBUF + aidx;
             const f32x4* Vc = V_lds + bidx;
@@ -278,8 +280,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
 #pragma unroll
             for (int sl = 0; sl < 32; ++sl) {
                 const int p0 = 2 * (sl >> 2), p1 = p0 + 1, ks = sl & 3;
-                acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], acc[p0], 0, 0, 0);
-                acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], acc[p1], 0, 0, 0);
+                if (FIRST && ks == 0) {
+                    acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], zero16, 0, 0, 0);
+                    acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], zero16, 0, 0, 0);
+                } else {
+                    acc[p0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p0][ks], vb[p0][ks], acc[p0], 0, 0, 0);
+                    acc[p1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[p1][ks], vb[p1][ks], acc[p1], 0, 0, 0);
+                }
                 if (p0 + 2 < 16) {                          // operands of the next position pair, one read per slot
                     if (ks == 0) ua[p0 + 2] = Uc[(p0 + 2) * 64];
                     if (ks == 1) vb[p0 + 2] = Vc[(p0 + 2) * 256];
@@ -303,8 +310,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-        }
-        // ---- item done: output transform Y = A^T M A, store, clear the accumulators; lane -> tile, register -> channel
+            ++g;
+        };
+        chunk(0, std::true_type());
+        for (int ch = 1; ch < pn; ++ch) chunk(ch, std::false_type());
+        // ---- item done: output transform Y = A^T M A, store; lane -> tile, register -> channel
         {
             const Item it = decode_item(a, item);
             int lane_o;
@@ -313,37 +323,57 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
             const bool inside = oy < a.Ho && ox < a.Wo;
             float* yb = a.y + (size_t)it.b * a.K * a.Ho * a.Wo + (size_t)oy * a.Wo + ox;
             const int kbase = it.k0 + 4 * (lane_o >> 5);
-            // (scalar: the packed form of K10's epilogue -- channel pairs, v_pk_add_f32 / v_pk_mov_b32 -- was measured here and taken
-            // out again: +5 % at upconv(1,1)'s backward-data, -13 % at the attack's ragged window launches, a dozen spilled registers)
+            // The output transform as in K10 (round 6): every accumulator value read ONCE by an asm v_accvgpr_read_b32 (hipcc re-reads
+            // the accumulator file for every use and spills around it), packed additions over the channel pair (v0, v0 + 1) = two
+            // adjacent registers of every accumulator, one v_pk_mov_b32 per store regroups the pairs into a channel's pixel pairs.
+            // The same additions in the same order: bit-identical.  The asm reads are invisible to the compiler's hazard recognizer:
+            // 20 wait states put the item's last 16-pass MFMA behind us whatever the code layout (a barrier and the item decode lie
+            // between anyway).
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" ::: "memory");
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int ko = kbase + (v & 3) + 8 * (v >> 2);
-                float s0[4], s1[4];
+            for (int vp = 0; vp < 8; ++vp) {
+                const int v0 = 2 * vp, ko0 = kbase + (v0 & 3) + 8 * (v0 >> 2);
+                f32x2 A2[16], S0[4], S1[4];
+#pragma unroll
+                for (int pq = 0; pq < 16; ++pq) {
+                    float lo_, hi_;
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(lo_) : "a"(acc[pq][v0]));
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(hi_) : "a"(acc[pq][v0 + 1]));
+                    A2[pq] = f32x2{lo_, hi_};
+                }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    s0[j] = acc[j][v] + acc[4 + j][v] + acc[8 + j][v];
-                    s1[j] = acc[4 + j][v] - acc[8 + j][v] - acc[12 + j][v];
+                    S0[j] = pk_add(pk_add(A2[j], A2[4 + j]), A2[8 + j]);
+                    S1[j] = pk_sub(pk_sub(A2[4 + j], A2[8 + j]), A2[12 + j]);
                 }
-                if (SK && pn < nch) {       // a partial item: its raw sums to the workgroup's slot (wino32_sk_fixup_kernel adds them)
-                    const int slot = 2 * (int)blockIdx.x + ((item != item0 && item == item_last) ? 1 : 0);
-                    const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slot * 16 + v) * (NT * 16));
-                    const f32x4 pv = {s0[0] + s0[1] + s0[2], s0[1] - s0[2] - s0[3], s1[0] + s1[1] + s1[2], s1[1] - s1[2] - s1[3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pv),
-                                                           prs, (unsigned)(wv_s * 64 + lane_o) * 16u, soff, 0);
-                } else if (inside && ko < a.K) {
-                    const float bs = a.bias ? a.bias[ko] : 0.f;
-                    const float y00 = s0[0] + s0[1] + s0[2] + bs, y01 = s0[1] - s0[2] - s0[3] + bs;
-                    const float y10 = s1[0] + s1[1] + s1[2] + bs, y11 = s1[1] - s1[2] - s1[3] + bs;
-                    float* yp = yb + (size_t)ko * a.Ho * a.Wo;
-                    *reinterpret_cast<float2*>(yp) = make_float2(y00, y01);
-                    *reinterpret_cast<float2*>(yp + a.Wo) = make_float2(y10, y11);
+                f32x2 Y00 = pk_add(pk_add(S0[0], S0[1]), S0[2]), Y01 = pk_sub(pk_sub(S0[1], S0[2]), S0[3]);
+                f32x2 Y10 = pk_add(pk_add(S1[0], S1[1]), S1[2]), Y11 = pk_sub(pk_sub(S1[1], S1[2]), S1[3]);
+                const bool whole = !(SK && pn < nch);
+                if (whole) {
+                    const f32x2 BS = {(a.bias && ko0 < a.K) ? a.bias[ko0] : 0.f, (a.bias && ko0 + 1 < a.K) ? a.bias[ko0 + 1] : 0.f};
+                    Y00 = pk_add(Y00, BS); Y01 = pk_add(Y01, BS); Y10 = pk_add(Y10, BS); Y11 = pk_add(Y11, BS);
                 }
-                __builtin_amdgcn_sched_barrier(0);   // one output channel at a time: hoisted accumulator reads spill
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2) {
+                    const int v = v0 + c2, ko = ko0 + c2;
+                    const f32x2 P0 = c2 ? pk_hi_hi(Y00, Y01) : pk_lo_lo(Y00, Y01), P1 = c2 ? pk_hi_hi(Y10, Y11) : pk_lo_lo(Y10, Y11);
+                    if (!whole) {       // a partial item: its raw sums to the workgroup's slot (wino32_sk_fixup_kernel adds them)
+                        const int slot = 2 * (int)blockIdx.x + ((item != item0 && item == item_last) ? 1 : 0);
+                        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane((slot * 16 + v) * (NT * 16));
+                        const f32x4 pv = {P0.x, P0.y, P1.x, P1.y};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, pv),
+                                                               prs, (unsigned)(wv_s * 64 + lane_o) * 16u, soff, 0);
+                        // the next writer of these four registers is an asm v_pk_mov_b32 the hazard recognizer does not see: two wait
+                        // states keep it off the 16-byte store's data (see K10)
+                        asm volatile("s_nop 1" ::: "memory");
+                    } else if (inside && ko < a.K) {
+                        float* yp = yb + (size_t)ko * a.Ho * a.Wo;
+                        *reinterpret_cast<f32x2*>(yp) = P0;
+                        *reinterpret_cast<f32x2*>(yp + a.Wo) = P1;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one channel pair at a time: hoisted accumulator reads spill
             }
-#pragma unroll
-            for (int pp = 0; pp < 16; ++pp)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[pp][v] = 0.f;
         }
 #pragma unroll
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
