@@ -322,8 +322,8 @@ def launch_ranks(n, argv, device_type="cuda"):
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=sorted(BASELINE_CONFIGS),
                     help="BASELINE.json configs[N-1]: sets the flags of that workload (2 = the headline metric's)")
     ap.add_argument("--batch_size", type=int, default=32, help="per-GPU batch (weak scaling)")
