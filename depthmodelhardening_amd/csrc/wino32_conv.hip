@@ -76,6 +76,17 @@ __device__ __forceinline__ Item decode_item(const W32Args& a, int item) {
     it.b = item / a.gy;
     return it;
 }
+// the item after `it`: a workgroup walks a contiguous range, so only its first item is decoded by division (see K10)
+__device__ __forceinline__ Item next_item(const W32Args& a, Item it) {
+    if ((it.k0 += 32) < a.kg * 32) return it;
+    it.k0 = 0;
+    if ((it.tx0 += TRW) < a.gx * TRW) return it;
+    it.tx0 = 0;
+    if ((it.ty0 += TRH) < a.gy * TRH) return it;
+    it.ty0 = 0;
+    ++it.b;
+    return it;
+}
 
 template <bool SK>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino32_conv_kernel(W32Args a) {
@@ -128,9 +139,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     unsigned uoff = 0, uoff_n = 0;
     int ixa = 0, ixa_n = 0;
     // raw-load constants of an item.  The thread index is rebuilt from v_mbcnt so that nothing of this is hoisted and spilled.
-#define DMH_W32_ITEM_CONSTS(ITEM, ROFF, UOFF, IXA)                                                 \
+#define DMH_W32_ITEM_CONSTS(ITEM, IT, ROFF, UOFF, IXA)                                             \
     {                                                                                             \
-        const Item it = decode_item(a, ITEM);                                                     \
+        const Item it = (IT);                                                                     \
         const int ix0 = 2 * it.tx0 - a.pad - coff, iy0 = 2 * it.ty0 - a.pad;                      \
         IXA = ix0;                                                                                \
         int tid_o;                                                                                \
@@ -244,7 +255,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     //   barrier, T(g+1): raw[(g+1)&1] -> V, barrier
     const unsigned chunk_bytes = (unsigned)(CK * HW * 4);
     const unsigned uchunk_bytes = (unsigned)(32 * a.Kp * 16);
-    DMH_W32_ITEM_CONSTS(item0, roff, uoff, ixa)
+    Item it_cur = decode_item(a, item0);
+    DMH_W32_ITEM_CONSTS(item0, it_cur, roff, uoff, ixa)
     DMH_W32_LOAD_RAW(0u, roff)
 #pragma unroll
     for (int k4 = 0; k4 < 4; ++k4) DMH_W32_GLDS_U_ROW(uoff, 0, k4)
@@ -260,7 +272,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int g = 0;
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
-        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n, ixa_n)
+        const Item it_nxt = item < item_last ? next_item(a, it_cur) : it_cur;
+        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), it_nxt, roff_n, uoff_n, ixa_n)
         if (SK) pn = (item == item_last ? ce_last : nch) - (item == item0 ? cb0 : 0);
         // one chunk; FIRST: the piece's first chunk, whose first MFMA per position starts the accumulation from zero (round 6: the
         // 256 accumulator writes per item that cleared them are gone)
@@ -316,7 +329,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int ch = 1; ch < pn; ++ch) chunk(ch, std::false_type());
         // ---- item done: output transform Y = A^T M A, store; lane -> tile, register -> channel
         {
-            const Item it = decode_item(a, item);
+            const Item it = it_cur;
             int lane_o;
             asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_o));
             const int oy = 2 * (it.ty0 + wv_s), ox = 2 * (it.tx0 + (lane_o & 31));
@@ -379,6 +392,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
         uoff = uoff_n;
         ixa = ixa_n;
+        it_cur = it_nxt;
     }
 }
 

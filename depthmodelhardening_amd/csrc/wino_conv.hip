@@ -188,6 +188,26 @@ __device__ __forceinline__ Item decode_item(const WArgs& a, int item) {
     it.b = item / a.gy;
     return it;
 }
+// the item after `it` (items are numbered with the channel split fastest, then the channel group, the region column, its row,
+// the image): a workgroup walks a contiguous range, so only its first item is decoded by division (round 6: two decodes per
+// item were ~300 scalar instructions of an epilogue that has no MFMA to hide them behind)
+template <int TRW>
+__device__ __forceinline__ Item next_item(const WArgs& a, Item it) {
+    constexpr int TRH = 64 / TRW;
+    if (++it.si < a.csplit) {
+        it.c0 += a.C / CK / a.csplit;
+        return it;
+    }
+    it.si = 0; it.c0 = 0;
+    if ((it.k0 += 64) < a.kg * 64) return it;
+    it.k0 = 0;
+    if ((it.tx0 += TRW) < a.gx * TRW) return it;
+    it.tx0 = 0;
+    if ((it.ty0 += TRH) < a.gy * TRH) return it;
+    it.ty0 = 0;
+    ++it.b;
+    return it;
+}
 
 template <int TRW, bool FLAT, bool EPI, bool SK = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_conv_kernel(WArgs a) {
@@ -270,9 +290,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     unsigned roff[RAW_PER_T], roff_n[RAW_PER_T];
     unsigned uoff = 0, uoff_n = 0;           // byte offset of the item's first filter chunk (uniform)
     int ixa = 0, ixa_n = 0;                  // first staged column of the item (uniform; `partial` only)
-#define DMH_WINO_ITEM_CONSTS(ITEM, ROFF, UOFF, IXA)                                               \
+#define DMH_WINO_ITEM_CONSTS(ITEM, IT, ROFF, UOFF, IXA)                                           \
     {                                                                                             \
-        Item it = decode_item<TRW>(a, ITEM);                                                      \
+        Item it = (IT);                                                                           \
         if (SK) it.c0 = ((ITEM) == item0) ? cb0 : 0;      /* a workgroup's first piece may start inside its item */ \
         const int ix0 = 2 * it.tx0 - a.pad - coff;        /* multiple of 4: tx0 is a multiple of 16 */ \
         IXA = ix0;                                                                                \
@@ -368,7 +388,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     // first chunks into buffers nobody reads any more.
     const unsigned chunk_bytes = (unsigned)(CK * HW * 4);          // one chunk of 8 input channels
     const unsigned uchunk_bytes = (unsigned)(32 * a.Kp * 16);      // one filter chunk
-    DMH_WINO_ITEM_CONSTS(item0, roff, uoff, ixa)
+    Item it_cur = decode_item<TRW>(a, item0);
+    DMH_WINO_ITEM_CONSTS(item0, it_cur, roff, uoff, ixa)
     DMH_WINO_LOAD_RAW(0u, roff)
     DMH_WINO_GLDS_U(uoff, 0)
     DMH_WINO_WRITE_RAW(0, ixa)
@@ -409,7 +430,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     int g = 0;
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
-        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), roff_n, uoff_n, ixa_n)
+        const Item it_nxt = item < item_last ? next_item<TRW>(a, it_cur) : it_cur;
+        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), it_nxt, roff_n, uoff_n, ixa_n)
         // one chunk; FIRST: the item's first chunk, whose first MFMA per position starts the accumulation from zero
         auto chunk = [&](const int ch, auto first_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -543,7 +565,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         // ---- item done: output transform  Y = A^T M A, store; lane -> tile,
         //      register -> output channel
         {
-            const Item it = decode_item<TRW>(a, item);
+            const Item it = it_cur;
             // lane index from v_mbcnt (not a register kept since kernel entry: see DMH_WINO_ITEM_CONSTS); opaque, so the
             // per-lane store addresses are not hoisted out of the item loop
             int lane_o;
@@ -671,6 +693,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
         for (int k = 0; k < RAW_PER_T; ++k) roff[k] = roff_n[k];
         uoff = uoff_n;
         ixa = ixa_n;
+        it_cur = it_nxt;
     }
 }
 
