@@ -12,6 +12,8 @@ H, W = Ho + 2 - 2 * pad, Wo + 2 - 2 * pad
 x = torch.rand(B, Cc, H, W, device=dev) - 0.5
 w = torch.rand(K, Cc, 3, 3, device=dev) - 0.5
 y = torch.empty(B, K, Ho, Wo, device=dev)
+import os
+bias = (torch.rand(K, device=dev) - 0.5) if os.environ.get("BIAS") == "1" else None      # BIAS=1: with a bias vector
 vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 for n in sys.argv[7:]:
@@ -22,7 +24,7 @@ for n in sys.argv[7:]:
     assert lib.dmh_wino_weight_transform(vp(w), K, Cc, 0, vp(U), st) == 0
 
     def run():
-        rc = lib.dmh_wino_conv3x3(vp(x), vp(U), None, B, Cc, K, H, W, pad, vp(y), st)
+        rc = lib.dmh_wino_conv3x3(vp(x), vp(U), None if bias is None else vp(bias), B, Cc, K, H, W, pad, vp(y), st)
         assert rc == 0, lib.dmh_last_error()
     run()
     torch.cuda.synchronize()
