@@ -273,7 +273,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
         const Item it_nxt = item < item_last ? next_item(a, it_cur) : it_cur;
-        DMH_W32_ITEM_CONSTS(min(item + 1, item_last), it_nxt, roff_n, uoff_n, ixa_n)
+        if (item < item_last) {
+            DMH_W32_ITEM_CONSTS(item + 1, it_nxt, roff_n, uoff_n, ixa_n)
+        } else {    // the last item: the stages past its end re-stage its own first chunks
+#pragma unroll
+            for (int k = 0; k < RAW_PER_T; ++k) roff_n[k] = roff[k];
+            uoff_n = uoff;
+            ixa_n = ixa;
+        }
         if (SK) pn = (item == item_last ? ce_last : nch) - (item == item0 ? cb0 : 0);
         // one chunk; FIRST: the piece's first chunk, whose first MFMA per position starts the accumulation from zero (round 6: the
         // 256 accumulator writes per item that cleared them are gone)

@@ -431,7 +431,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     for (int mi = 0; mi < nmine; ++mi) {
         const int item = item0 + mi;
         const Item it_nxt = item < item_last ? next_item<TRW>(a, it_cur) : it_cur;
-        DMH_WINO_ITEM_CONSTS(min(item + 1, item_last), it_nxt, roff_n, uoff_n, ixa_n)
+        if (item < item_last) {
+            DMH_WINO_ITEM_CONSTS(item + 1, it_nxt, roff_n, uoff_n, ixa_n)
+        } else {    // the last item (the only one of most attack launches): the stages past its end re-stage its own first chunks
+#pragma unroll
+            for (int k = 0; k < RAW_PER_T; ++k) roff_n[k] = roff[k];
+            uoff_n = uoff;
+            ixa_n = ixa;
+        }
         // one chunk; FIRST: the item's first chunk, whose first MFMA per position starts the accumulation from zero
         auto chunk = [&](const int ch, auto first_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
