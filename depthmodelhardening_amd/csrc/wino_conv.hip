@@ -822,10 +822,13 @@ bool sk_decide(long long regions, int nch, bool epi, bool have_ws, int64_t ws_fl
     if (!(G >= 2 && units < ((long long)1 << 30) && (long long)2 * G * SK_SLOT <= ws_floats)) return false;
     const int cs = (!epi && regions < (3 * cus) / 4 && nch % 2 == 0 && nch >= 6) ? 2 : 1;   // what the legacy path would do
     const long long items = regions * cs;
-    const double t_cur = (double)((items + cus - 1) / cus) * ((nch / cs) * 3.05 + 4.0) + (cs > 1 ? 6.0 : 0.0);
+    // microseconds per chunk, per item epilogue, for the second launch; the margin (DMH_SK_MODEL="chunk,epilogue,launch,margin": A/B)
+    static const struct Model { double c = 3.05, e = 4.0, l = 6.0, m = 0.92; Model() {
+        if (const char* v = getenv("DMH_SK_MODEL")) sscanf(v, "%lf,%lf,%lf,%lf", &c, &e, &l, &m); } } M;
+    const double t_cur = (double)((items + cus - 1) / cus) * ((nch / cs) * M.c + M.e) + (cs > 1 ? M.l : 0.0);
     const double per = (double)units / G;
-    const double t_sk = per * 3.05 + 4.0 * (per / nch + 1.5) + 6.0;
-    return t_sk < 0.92 * t_cur;
+    const double t_sk = per * M.c + M.e * (per / nch + 1.5) + M.l;
+    return t_sk < M.m * t_cur;
 }
 
 template <int TRW, bool FLAT, bool EPI>
